@@ -1,0 +1,234 @@
+"""fp32 CPU restatement of the neural modules the reference calls (TEST INFRASTRUCTURE, see oracle/__init__).
+
+The reference obtains these from `diffusers` / `transformers` (call sites
+/root/reference/diffusert/lcm/lcm_controlnet.py:175 CLIP, :299 TAESD encode, :558 ControlNet,
+:568 UNet, :594 TAESD decode).  Architecture: SURVEY.md Appendix A.  All functions are purely
+functional over a dict of tensors keyed by the diffusers parameter names (videosd_amd/weights.py),
+NCHW fp32.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _f(w, name):
+    return w[name].float()
+
+
+def conv(w, name, x, stride=1, padding=1):
+    b = w.get(name + ".bias")
+    return F.conv2d(x, _f(w, name + ".weight"), None if b is None else b.float(), stride=stride, padding=padding)
+
+
+def linear(w, name, x):
+    b = w.get(name + ".bias")
+    return F.linear(x, _f(w, name + ".weight"), None if b is None else b.float())
+
+
+def group_norm(w, name, x, groups, eps):
+    return F.group_norm(x, groups, _f(w, name + ".weight"), _f(w, name + ".bias"), eps)
+
+
+def layer_norm(w, name, x, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), _f(w, name + ".weight"), _f(w, name + ".bias"), eps)
+
+
+def timestep_sinusoid(t, dim):
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    arg = t.float()[:, None] * freqs[None, :]
+    return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
+
+
+def time_embedding(w, cfg, t, w_emb=None):
+    t_emb = timestep_sinusoid(t, cfg.block_out_channels[0])
+    if w_emb is not None:
+        t_emb = t_emb + linear(w, "time_embedding.cond_proj", w_emb)
+    h = linear(w, "time_embedding.linear_1", t_emb)
+    return linear(w, "time_embedding.linear_2", F.silu(h))
+
+
+def resnet(w, p, cfg, x, temb):
+    h = F.silu(group_norm(w, p + ".norm1", x, cfg.groups, 1e-5))
+    h = conv(w, p + ".conv1", h)
+    h = h + linear(w, p + ".time_emb_proj", F.silu(temb))[:, :, None, None]
+    h = F.silu(group_norm(w, p + ".norm2", h, cfg.groups, 1e-5))
+    h = conv(w, p + ".conv2", h)
+    if (p + ".conv_shortcut.weight") in w:
+        x = conv(w, p + ".conv_shortcut", x, padding=0)
+    return x + h
+
+
+def attention(w, p, x, ctx, heads):
+    b, s, c = x.shape
+    q = linear(w, p + ".to_q", x)
+    k = linear(w, p + ".to_k", ctx)
+    v = linear(w, p + ".to_v", ctx)
+    d = c // heads
+
+    def split(t):
+        return t.view(b, -1, heads, d).transpose(1, 2)
+
+    q, k, v = split(q), split(k), split(v)
+    att = torch.softmax(q @ k.transpose(-1, -2) * (d ** -0.5), dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(b, s, c)
+    return linear(w, p + ".to_out.0", o)
+
+
+def transformer(w, p, cfg, x, text):
+    b, c, hh, ww = x.shape
+    res = x
+    h = group_norm(w, p + ".norm", x, cfg.groups, 1e-6)
+    h = conv(w, p + ".proj_in", h, padding=0)
+    h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
+    t = p + ".transformer_blocks.0"
+    n = layer_norm(w, t + ".norm1", h)
+    h = h + attention(w, t + ".attn1", n, n, cfg.heads)
+    n = layer_norm(w, t + ".norm2", h)
+    h = h + attention(w, t + ".attn2", n, text, cfg.heads)
+    n = layer_norm(w, t + ".norm3", h)
+    g = linear(w, t + ".ff.net.0.proj", n)
+    hid, gate = g.chunk(2, dim=-1)
+    h = h + linear(w, t + ".ff.net.2", hid * F.gelu(gate))
+    h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)
+    h = conv(w, p + ".proj_out", h, padding=0)
+    return h + res
+
+
+def _down_and_mid(w, cfg, h, temb, text):
+    skips = [h]
+    ch = cfg.block_out_channels
+    for i in range(len(ch)):
+        for j in range(cfg.layers_per_block):
+            h = resnet(w, f"down_blocks.{i}.resnets.{j}", cfg, h, temb)
+            if cfg.down_attn[i]:
+                h = transformer(w, f"down_blocks.{i}.attentions.{j}", cfg, h, text)
+            skips.append(h)
+        if i < len(ch) - 1:
+            h = conv(w, f"down_blocks.{i}.downsamplers.0.conv", h, stride=2, padding=1)
+            skips.append(h)
+    h = resnet(w, "mid_block.resnets.0", cfg, h, temb)
+    h = transformer(w, "mid_block.attentions.0", cfg, h, text)
+    h = resnet(w, "mid_block.resnets.1", cfg, h, temb)
+    return h, skips
+
+
+def unet_forward(w, cfg, sample, t, text, w_emb=None, down_res=None, mid_res=None):
+    """UNet2DConditionModel.forward as used at lcm_controlnet.py:568-577.  t: int64 [B]."""
+    temb = time_embedding(w, cfg, t, w_emb)
+    h = conv(w, "conv_in", sample)
+    h, skips = _down_and_mid(w, cfg, h, temb, text)
+    if down_res is not None:
+        skips = [s + r for s, r in zip(skips, down_res)]
+        h = h + mid_res
+    # diffusers: any latent dim not divisible by 2**(num_upsamplers) -> upsample to the skip's size
+    n_up = len(cfg.block_out_channels) - 1
+    fwd_size = any(d % (2 ** n_up) != 0 for d in sample.shape[-2:])
+    nb = len(cfg.block_out_channels)
+    for i in range(nb):
+        for j in range(cfg.layers_per_block + 1):
+            h = torch.cat([h, skips.pop()], dim=1)
+            h = resnet(w, f"up_blocks.{i}.resnets.{j}", cfg, h, temb)
+            if cfg.up_attn[i]:
+                h = transformer(w, f"up_blocks.{i}.attentions.{j}", cfg, h, text)
+        if i < nb - 1:
+            if fwd_size:
+                h = F.interpolate(h, size=skips[-1].shape[2:], mode="nearest")
+            else:
+                h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = conv(w, f"up_blocks.{i}.upsamplers.0.conv", h)
+    h = F.silu(group_norm(w, "conv_norm_out", h, cfg.groups, 1e-5))
+    return conv(w, "conv_out", h)
+
+
+def controlnet_cond_embedding(w, ccfg, cond):
+    h = F.silu(conv(w, "controlnet_cond_embedding.conv_in", cond))
+    nblk = 2 * (len(ccfg.cond_channels) - 1)
+    for k in range(nblk):
+        h = F.silu(conv(w, f"controlnet_cond_embedding.blocks.{k}", h, stride=2 if k % 2 == 1 else 1))
+    return conv(w, "controlnet_cond_embedding.conv_out", h)
+
+
+def controlnet_forward(w, ccfg, sample, t, text, cond, conditioning_scale=1.0, guess_mode=True):
+    """ControlNetModel.forward as used at lcm_controlnet.py:558-566 (guess_mode always True there)."""
+    cfg = ccfg.unet
+    temb = time_embedding(w, cfg, t, None)
+    h = conv(w, "conv_in", sample) + controlnet_cond_embedding(w, ccfg, cond)
+    h, skips = _down_and_mid(w, cfg, h, temb, text)
+    down = [conv(w, f"controlnet_down_blocks.{i}", s, padding=0) for i, s in enumerate(skips)]
+    mid = conv(w, "controlnet_mid_block", h, padding=0)
+    if guess_mode:
+        scales = torch.logspace(-1, 0, len(down) + 1) * conditioning_scale
+        down = [d * s for d, s in zip(down, scales)]
+        mid = mid * scales[-1]
+    else:
+        down = [d * conditioning_scale for d in down]
+        mid = mid * conditioning_scale
+    return down, mid
+
+
+def _taesd_block(w, p, x):
+    h = F.relu(conv(w, p + ".conv.0", x))
+    h = F.relu(conv(w, p + ".conv.2", h))
+    h = conv(w, p + ".conv.4", h)
+    return F.relu(h + x)
+
+
+def taesd_encode(w, x):
+    """AutoencoderTiny.encode(x).latents; x in [-1,1] NCHW."""
+    e = "encoder.layers"
+    h = conv(w, f"{e}.0", (x + 1) / 2)
+    h = _taesd_block(w, f"{e}.1", h)
+    n = 2
+    for _ in range(3):
+        h = conv(w, f"{e}.{n}", h, stride=2)
+        n += 1
+        for _ in range(3):
+            h = _taesd_block(w, f"{e}.{n}", h)
+            n += 1
+    return conv(w, f"{e}.{n}", h)
+
+
+def taesd_decode(w, z):
+    """AutoencoderTiny.decode(z).sample; returns image in ~[-1,1]."""
+    d = "decoder.layers"
+    h = torch.tanh(z / 3) * 3
+    h = F.relu(conv(w, f"{d}.0", h))
+    n = 2
+    for nb in (3, 3, 3):
+        for _ in range(nb):
+            h = _taesd_block(w, f"{d}.{n}", h)
+            n += 1
+        h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+        n += 1
+        h = conv(w, f"{d}.{n}", h)
+        n += 1
+    h = _taesd_block(w, f"{d}.{n}", h)
+    n += 1
+    h = conv(w, f"{d}.{n}", h)
+    return h * 2 - 1
+
+
+def clip_text_forward(w, cfg, ids):
+    """CLIPTextModel(ids)[0] (last_hidden_state): causal mask, quick-GELU, final LayerNorm."""
+    t = "text_model"
+    b, s = ids.shape
+    x = _f(w, f"{t}.embeddings.token_embedding.weight")[ids] + _f(w, f"{t}.embeddings.position_embedding.weight")[:s]
+    mask = torch.full((s, s), float("-inf")).triu(1)
+    d = cfg.width // cfg.heads
+    for i in range(cfg.layers):
+        p = f"{t}.encoder.layers.{i}"
+        n = layer_norm(w, p + ".layer_norm1", x, cfg.eps)
+        q = linear(w, p + ".self_attn.q_proj", n).view(b, s, cfg.heads, d).transpose(1, 2)
+        k = linear(w, p + ".self_attn.k_proj", n).view(b, s, cfg.heads, d).transpose(1, 2)
+        v = linear(w, p + ".self_attn.v_proj", n).view(b, s, cfg.heads, d).transpose(1, 2)
+        att = torch.softmax(q @ k.transpose(-1, -2) * (d ** -0.5) + mask, dim=-1)
+        o = (att @ v).transpose(1, 2).reshape(b, s, cfg.width)
+        x = x + linear(w, p + ".self_attn.out_proj", o)
+        n = layer_norm(w, p + ".layer_norm2", x, cfg.eps)
+        h = linear(w, p + ".mlp.fc1", n)
+        h = h * torch.sigmoid(1.702 * h)
+        x = x + linear(w, p + ".mlp.fc2", h)
+    return layer_norm(w, f"{t}.final_layer_norm", x, cfg.eps)
