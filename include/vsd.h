@@ -1,0 +1,168 @@
+/* libvsd — C-ABI of the MI355X (gfx950) per-frame SD1.5/LCM denoising kernels.
+ *
+ * Drop-in boundary: the reference has no FFI; its seam is the Python class VideoSDPipeline
+ * (/root/reference/diffusert/videopipeline.py:11-128) whose `infer` drives diffusers modules on
+ * PyTorch-CUDA.  This library replaces everything below that class: each entry point here stands in
+ * for the library kernels one reference call site launches (cited per function).  The host side
+ * (videosd_amd/engine.py, Python like the reference) sequences these calls once, captures them into a
+ * hipGraph and replays the graph per frame.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name says `host`; caller-owned; no torch types.
+ *   - activations: fp16, channels-last ("NHWC"): a [H*W][C] row-major matrix, row stride given as ld*.
+ *   - weights: fp16, [N][Kp] row-major with K = ksize*ksize*Cin ordered (ky, kx, c), Kp = K rounded
+ *     up to 64 and zero-filled (packing: videosd_amd/packing.py).
+ *   - `stream` is a hipStream_t passed as void*.
+ *   - return value: 0 = ok, negative = vsd_status; vsd_last_error() gives the text.  Never aborts.
+ */
+#ifndef VSD_H
+#define VSD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vsd_ctx vsd_ctx;
+
+enum vsd_status {
+  VSD_OK = 0,
+  VSD_ERR_ARG = -1,      /* bad shape / unsupported configuration */
+  VSD_ERR_HIP = -2,      /* a HIP runtime call failed */
+  VSD_ERR_NOMEM = -3,
+  VSD_ERR_STATE = -4     /* call order (e.g. graph end without begin) */
+};
+
+enum vsd_act { VSD_ACT_NONE = 0, VSD_ACT_RELU = 1, VSD_ACT_SILU = 2, VSD_ACT_GEGLU = 3, VSD_ACT_QUICKGELU = 4 };
+
+/* tile shapes of the implicit-GEMM kernel (BM x BN output tile per 256-thread workgroup) */
+enum vsd_tile { VSD_TILE_128x128 = 0, VSD_TILE_128x64 = 1, VSD_TILE_64x64 = 2, VSD_TILE_64x128 = 3 };
+
+/* kernel families for vsd_stage_times */
+enum vsd_family {
+  VSD_FAM_CONV_GEMM = 0, VSD_FAM_SPLITK_REDUCE = 1, VSD_FAM_GROUPNORM = 2, VSD_FAM_LAYERNORM = 3,
+  VSD_FAM_ATTENTION = 4, VSD_FAM_ELEMENTWISE = 5, VSD_FAM_COUNT = 6
+};
+
+int vsd_version(void);
+
+/* One context per GPU / per worker process (reference: one Ray actor per GPU, videopipeline.py:11,20). */
+vsd_ctx* vsd_create(int device_id);
+void vsd_destroy(vsd_ctx* ctx);
+const char* vsd_last_error(vsd_ctx* ctx);
+
+/* ---- implicit-GEMM convolution / linear layer -------------------------------------------------
+ * out[m][n] = epilogue( sum_k A[m][k] * W[n][k] ),  m = output pixel, k = (ky,kx,c).
+ * A is gathered on the fly from one or two NHWC sources (channel concat), with optional nearest
+ * resize of the source to (hi,wi) before the convolution and stride 1/2.
+ * Replaces: F.conv2d / F.linear / torch.cat / F.interpolate(nearest) launched by diffusers'
+ * ResnetBlock2D, Transformer2DModel, Downsample2D, Upsample2D, Attention and FeedForward under
+ * lcm_controlnet.py:558 (ControlNet), :568 (UNet), :299/:594 (TAESD).
+ * epilogue: v = acc + bias[n] + rowvec[n]; v = act(v); v *= out_scale; v += residual + residual2;
+ *           out = v;  out2 = v + add2 (optional second output).
+ * act == GEGLU: weights/bias are tile-packed (64 hidden + 64 gate rows per 128-row tile); the output
+ * has n/2 columns: out[m][j] = (h_j + b) * gelu_erf(g_j + b).
+ * Columns >= t_col0 (when out_t != NULL) are written TRANSPOSED to out_t[(n - t_col0) * ldt + m]
+ * (this is how the attention V operand is produced as V^T).                                        */
+typedef struct vsd_conv_desc {
+  const void* src0;
+  const void* src1;       /* second concat source or NULL */
+  int32_t c0, c1;         /* channels of src0 / src1 (multiples of 8; of 64 when c1 != 0) */
+  int32_t hs, ws;         /* stored spatial size of the sources */
+  int32_t hi, wi;         /* logical input size after nearest resize (== hs, ws when no resize) */
+  int32_t ho, wo;         /* output spatial size; M = ho * wo */
+  int32_t ksize, stride, pad;
+  const void* weight;     /* fp16 [n][kp] */
+  int32_t n, k, kp;
+  const void* bias;       /* fp16 [n] or NULL */
+  const void* rowvec;     /* fp16 [n] or NULL */
+  const void* residual;   /* fp16 [M][ldr] or NULL */
+  const void* residual2;  /* fp16 [M][ldr] or NULL */
+  int32_t ldr;
+  float out_scale;
+  int32_t act;            /* vsd_act */
+  void* out;              /* fp16 [M][ldo] */
+  int32_t ldo;
+  void* out2;             /* optional: out2 = out + add2, both [M][ldo] */
+  const void* add2;
+  void* out_t;            /* optional transposed output */
+  int32_t ldt, t_col0;
+  int32_t tile;           /* vsd_tile */
+  int32_t split_k;        /* >= 1; > 1 needs workspace of split_k * M * n floats */
+  void* workspace;
+} vsd_conv_desc;
+
+int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream);
+
+/* ---- GroupNorm (+SiLU) over an NHWC tensor, optionally the channel-concat of two tensors ---------
+ * Replaces torch.nn.GroupNorm + SiLU in ResnetBlock2D / Transformer2DModel / conv_norm_out.
+ * workspace: >= vsd_groupnorm_workspace_bytes(hw, c0 + c1, groups) bytes.                            */
+int64_t vsd_groupnorm_workspace_bytes(int hw, int c, int groups);
+int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int groups, float eps,
+                  const void* gamma, const void* beta, int silu, void* out, void* workspace, void* stream);
+
+/* ---- LayerNorm over the last dimension (BasicTransformerBlock.norm1/2/3, CLIP layer norms) -------- */
+int vsd_layernorm(vsd_ctx* ctx, const void* x, int rows, int c, const void* gamma, const void* beta, float eps,
+                  void* out, void* stream);
+
+/* ---- fused softmax(Q K^T * scale) V, flash style (replaces F.scaled_dot_product_attention) ---------
+ * q: [sq][ldq] with head h at columns [h*d, (h+1)*d); k likewise; vt: V transposed, row (h*d + j) holds
+ * component j of every key, row stride ldvt >= round_up(sk, 64) and ZERO beyond sk.
+ * d in {8..160}, multiple of 8.  causal != 0: key j visible to query i iff j <= i (CLIP).            */
+int vsd_attention(vsd_ctx* ctx, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out,
+                  int ldo, int sq, int sk, int heads, int d, float scale, int causal, void* stream);
+
+/* ---- per-frame elementwise kernels -----------------------------------------------------------------
+ * Latent-like tensors (4 channels) are stored with row stride 8 (channels 4..7 zero).                 */
+
+/* u8 RGB HWC -> fp16 [h*w][8]: channels 0..2 = TAESD encoder input ((x+1)/2 of the [-1,1] image),
+ * channels 3..7 = 0.  Replaces VaeImageProcessor.preprocess (lcm_controlnet.py:457) + H2D.           */
+int vsd_preprocess_rgb(vsd_ctx* ctx, const void* rgb_u8, int h, int w, void* out, void* stream);
+
+/* Sobel "canny" of the reference (canny_gpu.py:27-44) on device: L conversion, two 3x3 filters,
+ * magnitude, division by the global max, thresholds, byte truncation.  Writes the u8 edge map (h*w) and
+ * the ControlNet conditioning tensor fp16 [h*w][8] (edge/255 in channels 0..2).
+ * workspace: >= 4 * (1 + ceil(h*w/256)) bytes.                                                        */
+int vsd_sobel_control(vsd_ctx* ctx, const void* rgb_u8, int h, int w, float low, float high, void* edge_u8,
+                      void* control_out, void* workspace, void* stream);
+
+/* latents = sqrt_a * x0 + sqrt_b * noise  (LCMScheduler_X.add_noise, lcm_controlnet.py:1046-1071).
+ * x0/out: fp16 [hw][8]; noise: fp32 NCHW [4][hw] (as torch.randn produces it).                        */
+int vsd_add_noise(vsd_ctx* ctx, const void* x0, const void* noise_f32, float sqrt_a, float sqrt_b, int hw, void* out,
+                  void* stream);
+
+/* One LCMScheduler_X.step (lcm_controlnet.py:948-1043) on fp16 [hw][8] tensors:
+ *   pred_x0 = (sample - sqrt_b * eps) / sqrt_a;  denoised = c_out * pred_x0 + c_skip * sample;
+ *   prev = sqrt_a_prev * denoised + sqrt_b_prev * noise   (noise NULL => prev = denoised).
+ * coef = {sqrt_a, sqrt_b, c_skip, c_out, sqrt_a_prev, sqrt_b_prev}.
+ * dec_in (optional): 3*tanh(denoised/3), the TAESD decoder input clamp (DecoderTiny.forward).        */
+int vsd_lcm_step(vsd_ctx* ctx, const void* eps, const void* sample, const void* noise_f32, const float* coef_host,
+                 int hw, void* prev, void* denoised, void* dec_in, void* stream);
+
+/* decoder output fp16 [hw][ld] (3 channels used; value c of the last conv) -> u8 RGB HWC:
+ * y = fp16(2c - 1) (DecoderTiny), (y/2 + 0.5).clamp(0,1)*255 rounded half-to-even
+ * (VaeImageProcessor.postprocess, lcm_controlnet.py:609-611).                                         */
+int vsd_postprocess_rgb(vsd_ctx* ctx, const void* img, int ld, int hw, void* rgb_u8, void* stream);
+
+/* out = a + b * scale   (fp16, n elements, n % 8 == 0) */
+int vsd_axpy(vsd_ctx* ctx, const void* a, const void* b, float scale, int64_t n, void* out, void* stream);
+
+/* ---- hipGraph capture / replay (reference intent: compile_model, videopipeline.py:35-47) ----------- */
+int vsd_graph_begin(vsd_ctx* ctx, void* stream);
+int vsd_graph_end(vsd_ctx* ctx, void* stream, void** graph_exec_out);
+int vsd_graph_launch(vsd_ctx* ctx, void* graph_exec, void* stream);
+int vsd_graph_destroy(vsd_ctx* ctx, void* graph_exec);
+
+/* ---- per-family device timing ------------------------------------------------------------------------
+ * While profiling is on, every launch is bracketed by HIP events on its stream (do not capture graphs
+ * in this mode).  vsd_stage_times synchronises and returns, per vsd_family: total ms, launch count and
+ * the algorithmic FLOPs (2*M*N*K for conv_gemm; 4*sq*sk*heads*d for attention) accumulated since
+ * vsd_profile_begin.                                                                                   */
+int vsd_profile_begin(vsd_ctx* ctx);
+int vsd_profile_end(vsd_ctx* ctx);
+int vsd_stage_times(vsd_ctx* ctx, float* ms, int64_t* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSD_H */

@@ -1,0 +1,408 @@
+"""Per-kernel parity on the MI355X: every C-ABI op against a plain PyTorch fp32 CPU reference of the
+same op on the same fp16-rounded inputs.  Tolerance (proposed; the reference states none):
+max-abs <= 2^-8 * max|ref| and relative L2 <= 2e-3 for fp16 outputs; integer outputs exact or +-1 LSB."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from videosd_amd.ops import HipOps
+
+    return HipOps(0)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+def to_nhwc(x):  # [1,C,H,W] -> [H*W, C]
+    return x[0].permute(1, 2, 0).reshape(-1, x.shape[1]).contiguous()
+
+
+def from_nhwc(y, h, w):  # [H*W, C] -> [1,C,H,W]
+    return y.reshape(h, w, -1).permute(2, 0, 1)[None]
+
+
+def check(got, ref, what="", atol_scale=2.0 ** -8, rel=2e-3):
+    got = got.float().cpu()
+    ref = ref.float()
+    assert torch.isfinite(got).all(), what
+    err = (got - ref).abs().max().item()
+    lim = atol_scale * ref.abs().max().item() + 1e-6
+    l2 = ((got - ref).norm() / (ref.norm() + 1e-12)).item()
+    assert err <= lim and l2 <= rel, f"{what}: max-abs {err:.4g} (limit {lim:.4g}), rel-L2 {l2:.3g}"
+
+
+def run_conv(ops, x_list, h, w, weight, bias, *, ksize, stride=1, up_to=None, tile=None, split_k=None, act=0,
+             rowvec=None, residual=None, residual2=None, out_scale=1.0, cin_pad=None):
+    """x_list: NCHW fp16 CPU tensors (concat sources). Returns (got [M,N] fp16 on cpu, ref NCHW fp32)."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    pw = pack_conv(weight, bias, cin_pad=cin_pad)
+    pw.weight = pw.weight.cuda()
+    pw.bias = None if pw.bias is None else pw.bias.cuda()
+    g = Geom.conv(h, w, ksize=ksize, stride=stride, up_to=up_to)
+    srcs = []
+    for x in x_list:
+        xn = to_nhwc(x)
+        if cin_pad is not None and xn.shape[1] != cin_pad:
+            xn = F.pad(xn, (0, cin_pad - xn.shape[1]))
+        srcs.append(xn.cuda())
+    n = weight.shape[0]
+    ldo = max(8, (n + 7) // 8 * 8)
+    out = torch.zeros(g.m, ldo, dtype=torch.float16, device="cuda")
+    kw = {}
+    if rowvec is not None:
+        kw["rowvec"] = rowvec.cuda()
+    if residual is not None:
+        kw["residual"] = residual.cuda()
+        kw["ldr"] = residual.shape[1]
+    if residual2 is not None:
+        kw["residual2"] = residual2.cuda()
+    c0 = srcs[0].shape[1]
+    c1 = srcs[1].shape[1] if len(srcs) > 1 else 0
+    ops.conv(srcs[0], srcs[1] if len(srcs) > 1 else None, g, pw, out, ldo=ldo, c0=c0, c1=c1, act=act, out_scale=out_scale,
+             tile=tile, split_k=split_k, **kw)
+    ops.synchronize()
+    # reference
+    xin = torch.cat([x.float() for x in x_list], dim=1)
+    if up_to is not None:
+        xin = F.interpolate(xin, size=up_to, mode="nearest")
+    ref = F.conv2d(xin, weight.float(), None if bias is None else bias.float(), stride=stride, padding=ksize // 2)
+    if rowvec is not None:
+        ref = ref + rowvec.float()[None, :, None, None]
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 2:
+        ref = F.silu(ref)
+    elif act == 4:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    ref = ref * out_scale
+    if residual is not None:
+        ref = ref + from_nhwc(residual.float(), g.ho, g.wo)
+    if residual2 is not None:
+        ref = ref + from_nhwc(residual2.float(), g.ho, g.wo)
+    return out[:, :n].cpu(), to_nhwc(ref)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("split_k", [1, 3])
+def test_conv3x3_all_tiles_splitk(ops, tile, split_k):
+    h, w, cin, cout = 18, 14, 128, 192  # M=252: ragged in M for every tile
+    x = rnd(1, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
+    b = rnd(cout, seed=3, scale=0.1)
+    rv = rnd(cout, seed=4, scale=0.1)
+    res = rnd(h * w, cout, seed=5)
+    got, ref = run_conv(ops, [x], h, w, wt, b, ksize=3, tile=tile, split_k=split_k, rowvec=rv, residual=res)
+    check(got, ref, f"conv3x3 tile={tile} split={split_k}")
+
+
+def test_conv3x3_sd_width_deep_k(ops):
+    h, w, cin, cout = 8, 8, 2560, 1280  # the deepest K of the UNet (23040), small M -> split-K heuristic path
+    x = rnd(1, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
+    got, ref = run_conv(ops, [x[:, :1280], x[:, 1280:]], h, w, wt, None, ksize=3)
+    check(got, ref, "conv 2560->1280 concat")
+
+
+@pytest.mark.parametrize("c0,c1", [(128, 64), (64, 128), (320, 320)])
+def test_conv_concat_sources(ops, c0, c1):
+    h, w, cout = 12, 10, 128
+    a, b = rnd(1, c0, h, w, seed=1), rnd(1, c1, h, w, seed=2)
+    wt = rnd(cout, c0 + c1, 3, 3, seed=3, scale=((c0 + c1) * 9) ** -0.5)
+    got, ref = run_conv(ops, [a, b], h, w, wt, rnd(cout, seed=4, scale=0.1), ksize=3)
+    check(got, ref, "concat conv3x3")
+    wt1 = rnd(cout, c0 + c1, 1, 1, seed=5, scale=(c0 + c1) ** -0.5)
+    got, ref = run_conv(ops, [a, b], h, w, wt1, None, ksize=1)
+    check(got, ref, "concat conv1x1 (shortcut)")
+
+
+@pytest.mark.parametrize("hs,ws,up", [(7, 12, (14, 24)), (14, 24, (27, 48)), (4, 4, (8, 8))])
+def test_conv_nearest_upsample_folded(ops, hs, ws, up):
+    cin, cout = 128, 64
+    x = rnd(1, cin, hs, ws, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
+    got, ref = run_conv(ops, [x], hs, ws, wt, rnd(cout, seed=3, scale=0.1), ksize=3, up_to=up)
+    check(got, ref, f"upsample {hs}x{ws}->{up}")
+
+
+@pytest.mark.parametrize("h,w", [(16, 16), (27, 48), (7, 12), (1, 1)])
+def test_conv_stride2(ops, h, w):
+    cin, cout = 64, 64
+    x = rnd(1, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
+    got, ref = run_conv(ops, [x], h, w, wt, None, ksize=3, stride=2)
+    check(got, ref, f"stride2 {h}x{w}")
+
+
+@pytest.mark.parametrize("cin,cout,pad", [(3, 64, 8), (4, 320, 8), (16, 32, None), (96, 256, None), (64, 3, None), (320, 4, None)])
+def test_conv_small_channels_generic_path(ops, cin, cout, pad):
+    h, w = 20, 12
+    x = rnd(1, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
+    got, ref = run_conv(ops, [x], h, w, wt, rnd(cout, seed=3, scale=0.1), ksize=3, cin_pad=pad, act=2)
+    check(got, ref, f"generic conv {cin}->{cout}")
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 4])
+def test_linear_epilogues(ops, act):
+    m, k, n = 77, 768, 320
+    x = rnd(1, k, 1, m, seed=1)
+    wt = rnd(n, k, 1, 1, seed=2, scale=k ** -0.5)
+    res, res2 = rnd(m, n, seed=3), rnd(m, n, seed=4)
+    got, ref = run_conv(ops, [x], 1, m, wt, rnd(n, seed=5, scale=0.1), ksize=1, act=act, residual=res, residual2=res2,
+                        out_scale=0.37)
+    check(got, ref, f"linear act={act}")
+
+
+@pytest.mark.parametrize("tile", [0, 3])
+def test_geglu_fused(ops, tile):
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_geglu
+
+    m, c = 200, 320
+    x = rnd(m, c, seed=1)
+    wt = rnd(8 * c, c, seed=2, scale=c ** -0.5)
+    b = rnd(8 * c, seed=3, scale=0.1)
+    pw = pack_geglu(wt, b)
+    pw.weight, pw.bias = pw.weight.cuda(), pw.bias.cuda()
+    out = torch.zeros(m, 4 * c, dtype=torch.float16, device="cuda")
+    ops.conv(x.cuda(), None, Geom.linear(m), pw, out, tile=tile)
+    ops.synchronize()
+    y = F.linear(x.float(), wt.float(), b.float())
+    hid, gate = y.chunk(2, dim=-1)
+    check(out, hid * F.gelu(gate), "geglu")
+
+
+def test_qkv_transposed_output_and_dual_output(ops):
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_linear_cat
+
+    s, c = 300, 128
+    x = rnd(s, c, seed=1)
+    wq, wk, wv = (rnd(c, c, seed=i, scale=c ** -0.5) for i in (2, 3, 4))
+    pw = pack_linear_cat([wq, wk, wv])
+    pw.weight = pw.weight.cuda()
+    ldt = (s + 63) // 64 * 64
+    qk = torch.zeros(s, 2 * c, dtype=torch.float16, device="cuda")
+    vt = torch.zeros(c, ldt, dtype=torch.float16, device="cuda")
+    for split in (1, 2):
+        qk.zero_()
+        vt.zero_()
+        ops.conv(x.cuda(), None, Geom.linear(s), pw, qk, ldo=2 * c, out_t=vt, ldt=ldt, t_col0=2 * c, split_k=split, tile=2)
+        ops.synchronize()
+        check(qk[:, :c], F.linear(x.float(), wq.float()), "q")
+        check(qk[:, c:], F.linear(x.float(), wk.float()), "k")
+        check(vt[:, :s], F.linear(x.float(), wv.float()).t(), "v^T")
+        assert (vt[:, s:] == 0).all()
+    # dual output: out2 = out + add2
+    pwq = pack_linear_cat([wq])
+    pwq.weight = pwq.weight.cuda()
+    o1 = torch.zeros(s, c, dtype=torch.float16, device="cuda")
+    o2 = torch.zeros(s, c, dtype=torch.float16, device="cuda")
+    add = rnd(s, c, seed=9)
+    ops.conv(x.cuda(), None, Geom.linear(s), pwq, o1, out2=o2, add2=add.cuda())
+    ops.synchronize()
+    ref = F.linear(x.float(), wq.float())
+    check(o1, ref, "out")
+    check(o2, ref + add.float(), "out2")
+
+
+@pytest.mark.parametrize("c0,c1,hw,silu,eps", [(320, 0, 4096, True, 1e-5), (1280, 640, 256, True, 1e-5),
+                                                (2560, 0, 64, False, 1e-6), (64, 0, 100, True, 1e-5),
+                                                (128, 64, 35, False, 1e-5), (640, 320, 1024, True, 1e-5)])
+def test_groupnorm(ops, c0, c1, hw, silu, eps):
+    c = c0 + c1
+    a = rnd(hw, c0, seed=1) * 2 + 0.5
+    b = rnd(hw, c1, seed=2) if c1 else None
+    gamma, beta = (1 + 0.1 * rnd(c, seed=3).float()).half(), rnd(c, seed=4, scale=0.1)
+    out = torch.zeros(hw, c, dtype=torch.float16, device="cuda")
+    ops.groupnorm(a.cuda(), None if b is None else b.cuda(), c0, c1, hw, 32, eps, gamma.cuda(), beta.cuda(), silu, out)
+    ops.synchronize()
+    x = a.float() if b is None else torch.cat([a.float(), b.float()], dim=1)
+    ref = F.group_norm(x.t()[None], 32, gamma.float(), beta.float(), eps)[0].t()
+    if silu:
+        ref = F.silu(ref)
+    check(out, ref, f"groupnorm C={c} hw={hw}")
+
+
+@pytest.mark.parametrize("rows,c", [(4096, 320), (77, 768), (5, 1280), (1000, 64), (64, 1536)])
+def test_layernorm(ops, rows, c):
+    x = rnd(rows, c, seed=1) * 3 + 1
+    gamma, beta = (1 + 0.1 * rnd(c, seed=3).float()).half(), rnd(c, seed=4, scale=0.1)
+    out = torch.zeros(rows, c, dtype=torch.float16, device="cuda")
+    ops.layernorm(x.cuda(), rows, c, gamma.cuda(), beta.cuda(), 1e-5, out)
+    ops.synchronize()
+    check(out, F.layer_norm(x.float(), (c,), gamma.float(), beta.float(), 1e-5), f"layernorm {rows}x{c}")
+
+
+def attention_ref(q, k, v, heads, scale, causal=False):
+    sq, c = q.shape
+    sk = k.shape[0]
+    d = c // heads
+    qh = q.float().view(sq, heads, d).transpose(0, 1)
+    kh = k.float().view(sk, heads, d).transpose(0, 1)
+    vh = v.float().view(sk, heads, d).transpose(0, 1)
+    s = qh @ kh.transpose(-1, -2) * scale
+    if causal:
+        s = s + torch.full((sq, sk), float("-inf")).triu(1)
+    return (torch.softmax(s, dim=-1) @ vh).transpose(0, 1).reshape(sq, c)
+
+
+@pytest.mark.parametrize("sq,sk,heads,d,causal", [
+    (4096, 4096, 8, 40, False), (1024, 1024, 8, 80, False), (256, 256, 8, 160, False), (64, 64, 8, 160, False),
+    (4096, 77, 8, 40, False), (1024, 77, 8, 80, False), (77, 77, 12, 64, True), (130, 200, 2, 8, False),
+    (100, 100, 3, 16, False), (1296, 1296, 4, 32, False), (300, 77, 2, 64, False), (60, 200, 2, 128, True)])
+def test_attention(ops, sq, sk, heads, d, causal):
+    c = heads * d
+    q, k, v = rnd(sq, c, seed=1), rnd(sk, c, seed=2), rnd(sk, c, seed=3)
+    # one spiky key so that the online-softmax rescale branch is exercised on a late tile
+    if sk > 70:
+        k[sk - 3] *= 6.0
+    ldvt = (sk + 63) // 64 * 64
+    vt = torch.zeros(c, ldvt, dtype=torch.float16)
+    vt[:, :sk] = v.t()
+    out = torch.zeros(sq, c, dtype=torch.float16, device="cuda")
+    scale = d ** -0.5
+    ops.attention(q.cuda(), c, k.cuda(), c, vt.cuda(), ldvt, out, c, sq, sk, heads, d, scale, causal)
+    ops.synchronize()
+    check(out, attention_ref(q, k, v, heads, scale, causal), f"attention {sq}x{sk} h{heads} d{d}", rel=3e-3)
+
+
+def test_preprocess_and_postprocess(ops):
+    h, w = 40, 56
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    out = torch.zeros(h * w, 8, dtype=torch.float16, device="cuda")
+    ops.preprocess_rgb(torch.from_numpy(img).cuda(), h, w, out)
+    ops.synchronize()
+    ref = torch.from_numpy(img.astype(np.float32) / 255.0).reshape(h * w, 3)
+    check(out[:, :3], ref, "preprocess", atol_scale=2.0 ** -10)
+    assert (out[:, 3:] == 0).all()
+    # postprocess: decoder value c -> u8
+    cvals = torch.linspace(-0.2, 1.2, h * w * 3).reshape(h * w, 3)
+    dec = torch.zeros(h * w, 8, dtype=torch.float16)
+    dec[:, :3] = cvals.half()
+    u8 = torch.zeros(h * w * 3, dtype=torch.uint8, device="cuda")
+    ops.postprocess_rgb(dec.cuda(), 8, h * w, u8)
+    ops.synchronize()
+    y = dec[:, :3].float() * 2 - 1
+    ref8 = ((y / 2 + 0.5).clamp(0, 1) * 255).round().reshape(-1)
+    assert (u8.cpu().float() - ref8).abs().max() <= 1
+
+
+def test_sobel_control_matches_oracle(ops):
+    from PIL import Image
+
+    from oracle.pipeline import sobel_edges
+
+    h, w = 48, 64
+    rng = np.random.default_rng(1)
+    base = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    grad = ((xx * 4 + yy * 2) % 256).astype(np.uint8)[..., None]
+    img = (base // 2 + grad // 2).astype(np.uint8)
+    ref = np.asarray(sobel_edges(Image.fromarray(img, "RGB"), 0.11, 0.8))
+    edge = torch.zeros(h * w, dtype=torch.uint8, device="cuda")
+    ctrl = torch.zeros(h * w, 8, dtype=torch.float16, device="cuda")
+    ops.sobel_control(torch.from_numpy(img).cuda(), h, w, 0.11, 0.8, edge, ctrl)
+    ops.synchronize()
+    got = edge.cpu().numpy().reshape(h, w)
+    diff = np.abs(got.astype(int) - ref.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01, (diff.max(), (diff > 0).mean())
+    check(ctrl[:, 0], torch.from_numpy(got.reshape(-1).astype(np.float32) / 255.0), "control", atol_scale=2.0 ** -10)
+    assert (ctrl[:, 0] == ctrl[:, 2]).all() and (ctrl[:, 3:] == 0).all()
+
+
+def test_scheduler_kernels_match_oracle(ops):
+    from oracle.scheduler import LCMSchedulerOracle
+    from videosd_amd.lcm import LCMSchedule
+
+    hw = 24 * 20
+    sch = LCMSchedulerOracle()
+    ts = sch.set_timesteps(0.6, 4)
+    plan = LCMSchedule(0.6, 4)
+    assert plan.timesteps == ts.tolist()
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(1, 4, 24, 20, generator=g).half()
+    noise = torch.randn(1, 4, 24, 20, generator=g)
+    x0p = F.pad(to_nhwc(x0), (0, 4)).cuda()
+    lat = torch.zeros(hw, 8, dtype=torch.float16, device="cuda")
+    sa, sb = plan.add_noise_coef()
+    ops.add_noise(x0p, noise.cuda(), sa, sb, hw, lat)
+    ops.synchronize()
+    ref = sch.add_noise(x0.float(), noise, ts[:1])
+    check(lat[:, :4], to_nhwc(ref), "add_noise", atol_scale=2.0 ** -10)
+    assert (lat[:, 4:] == 0).all()
+    cur = ref
+    for i, t in enumerate(ts):
+        eps = torch.randn(1, 4, 24, 20, generator=g).half()
+        torch.manual_seed(100 + i)
+        prev_ref, den_ref = sch.step(eps.float(), i, t, cur.half().float())
+        torch.manual_seed(100 + i)
+        nz = torch.randn(1, 4, 24, 20)
+        prev = torch.zeros(hw, 8, dtype=torch.float16, device="cuda")
+        den = torch.zeros(hw, 8, dtype=torch.float16, device="cuda")
+        dec = torch.zeros(hw, 8, dtype=torch.float16, device="cuda")
+        ops.lcm_step(F.pad(to_nhwc(eps), (0, 4)).cuda(), F.pad(to_nhwc(cur.half()), (0, 4)).cuda(), nz.cuda(),
+                     plan.step_coef(i), hw, prev, den, dec)
+        ops.synchronize()
+        check(den[:, :4], to_nhwc(den_ref), f"denoised step {i}", atol_scale=2.0 ** -9)
+        check(prev[:, :4], to_nhwc(prev_ref), f"prev step {i}", atol_scale=2.0 ** -9)
+        check(dec[:, :4], to_nhwc(torch.tanh(den_ref / 3) * 3), f"dec_in step {i}", atol_scale=2.0 ** -9)
+        cur = prev_ref
+
+
+def test_graph_replay_equals_eager(ops):
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    h, w, c = 16, 16, 64
+    x = rnd(h * w, c, seed=1).cuda()
+    pw = pack_conv(rnd(c, c, 3, 3, seed=2, scale=(9 * c) ** -0.5), rnd(c, seed=3, scale=0.1))
+    pw.weight, pw.bias = pw.weight.cuda(), pw.bias.cuda()
+    gamma, beta = torch.ones(c, dtype=torch.float16, device="cuda"), torch.zeros(c, dtype=torch.float16, device="cuda")
+    t1, t2 = (torch.zeros(h * w, c, dtype=torch.float16, device="cuda") for _ in range(2))
+
+    def body():
+        ops.groupnorm(x, None, c, 0, h * w, 32, 1e-5, gamma, beta, True, t1)
+        ops.conv(t1, None, Geom.conv(h, w), pw, t2, residual=x, split_k=2, tile=2)
+
+    body()
+    ops.synchronize()
+    eager = t2.clone()
+    t2.zero_()
+    ops.workspace("splitk", 2 * h * w * c * 4)
+    ops.graph_begin()
+    body()
+    g = ops.graph_end()
+    for _ in range(3):
+        t2.zero_()
+        ops.graph_launch(g)
+        ops.synchronize()
+        assert torch.equal(t2, eager)
+    ops.graph_destroy(g)
+
+
+def test_errors_are_reported_not_fatal(ops):
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    pw = pack_conv(rnd(64, 64, 3, 3), None)
+    pw.weight = pw.weight.cuda()
+    x = rnd(16, 64).cuda()
+    out = torch.zeros(16, 64, dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError, match="concat|multiple|K="):
+        ops.conv(x, x, Geom.conv(4, 4), pw, out, c0=40, c1=24)
+    with pytest.raises(RuntimeError, match="head_dim"):
+        ops.attention(x, 64, x, 64, x, 64, out, 64, 16, 16, 1, 12, 1.0)

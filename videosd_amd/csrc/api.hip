@@ -1,0 +1,104 @@
+// Context, hipGraph capture/replay and per-family timing for libvsd.
+#include <stdarg.h>
+
+#include "common.h"
+
+extern "C" int vsd_version(void) { return 1; }
+
+extern "C" vsd_ctx* vsd_create(int device_id) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return nullptr;
+  if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+  vsd_ctx* c = new vsd_ctx();
+  c->device = device_id;
+  for (int i = 0; i < VSD_FAM_COUNT; ++i) {
+    c->fam_flops[i] = 0;
+    c->fam_launch[i] = 0;
+  }
+  return c;
+}
+
+static void drop_events(vsd_ctx* ctx) {
+  for (auto& e : ctx->events) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  ctx->events.clear();
+}
+
+extern "C" void vsd_destroy(vsd_ctx* ctx) {
+  if (!ctx) return;
+  drop_events(ctx);
+  delete ctx;
+}
+
+extern "C" const char* vsd_last_error(vsd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int vsd_graph_begin(vsd_ctx* ctx, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (ctx->capturing) return vsd_fail(ctx, VSD_ERR_STATE, "graph_begin: already capturing");
+  if (ctx->profiling) return vsd_fail(ctx, VSD_ERR_STATE, "graph_begin: profiling is on");
+  VSD_HIP(ctx, hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  ctx->capturing = true;
+  return VSD_OK;
+}
+
+extern "C" int vsd_graph_end(vsd_ctx* ctx, void* stream, void** graph_exec_out) {
+  if (!ctx || !graph_exec_out) return VSD_ERR_ARG;
+  if (!ctx->capturing) return vsd_fail(ctx, VSD_ERR_STATE, "graph_end: not capturing");
+  ctx->capturing = false;
+  hipGraph_t g = nullptr;
+  VSD_HIP(ctx, hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e != hipSuccess) return vsd_fail(ctx, VSD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  *graph_exec_out = (void*)ge;
+  return VSD_OK;
+}
+
+extern "C" int vsd_graph_launch(vsd_ctx* ctx, void* graph_exec, void* stream) {
+  if (!ctx || !graph_exec) return VSD_ERR_ARG;
+  VSD_HIP(ctx, hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return VSD_OK;
+}
+
+extern "C" int vsd_graph_destroy(vsd_ctx* ctx, void* graph_exec) {
+  if (!ctx || !graph_exec) return VSD_ERR_ARG;
+  VSD_HIP(ctx, hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return VSD_OK;
+}
+
+extern "C" int vsd_profile_begin(vsd_ctx* ctx) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (ctx->capturing) return vsd_fail(ctx, VSD_ERR_STATE, "profile_begin: capturing a graph");
+  drop_events(ctx);
+  for (int i = 0; i < VSD_FAM_COUNT; ++i) {
+    ctx->fam_flops[i] = 0;
+    ctx->fam_launch[i] = 0;
+  }
+  ctx->profiling = true;
+  return VSD_OK;
+}
+
+extern "C" int vsd_profile_end(vsd_ctx* ctx) {
+  if (!ctx) return VSD_ERR_ARG;
+  ctx->profiling = false;
+  return VSD_OK;
+}
+
+extern "C" int vsd_stage_times(vsd_ctx* ctx, float* ms, int64_t* launches, double* flops) {
+  if (!ctx || !ms) return VSD_ERR_ARG;
+  for (int i = 0; i < VSD_FAM_COUNT; ++i) ms[i] = 0.f;
+  for (auto& e : ctx->events) {
+    VSD_HIP(ctx, hipEventSynchronize(e.b));
+    float t = 0.f;
+    VSD_HIP(ctx, hipEventElapsedTime(&t, e.a, e.b));
+    ms[e.fam] += t;
+  }
+  for (int i = 0; i < VSD_FAM_COUNT; ++i) {
+    if (launches) launches[i] = ctx->fam_launch[i];
+    if (flops) flops[i] = ctx->fam_flops[i];
+  }
+  return VSD_OK;
+}

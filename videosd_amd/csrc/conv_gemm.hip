@@ -1,0 +1,491 @@
+// Implicit-GEMM convolution / linear layer on MFMA (gfx950, wave64, v_mfma_f32_16x16x32_f16).
+//
+//   out[m][n] = epilogue( sum_k A[m][k] * W[n][k] )
+//
+// A is never materialised: each 64-wide K tile is gathered straight from the NHWC source(s)
+// (3x3 taps, stride, zero padding, nearest resize and channel concat are all address arithmetic in
+// the tile loader).  Tiles are staged global -> registers -> LDS (XOR-swizzled 128-B rows, conflict
+// free for ds_read_b128 fragment reads), double buffered with one barrier per K tile; the next
+// tile's global loads are issued before the current tile's MFMAs (issue-early / write-late).
+// The accumulator tile is transposed through LDS so that bias / residual reads and the output
+// stores are 16-byte row-contiguous.  K can be split across workgroups (fp32 slabs + a reduce
+// kernel that applies the same epilogue) for the small-M, huge-K layers of the 16x16 / 8x8 levels.
+//
+// Algorithmic work per launch: 2*M*N*K FLOP, fp16 bytes: N*Kp (weights) + M*Cin (input) + M*N (output).
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;  // halfs per K tile (128-byte LDS rows)
+
+struct ConvParams {
+  const half_t* src0;
+  const half_t* src1;
+  int c0, c1, cin;
+  int hs, ws, hi, wi, ho, wo;
+  int ksize, stride, pad;
+  int resize;   // hi != hs || wi != ws
+  int generic;  // cin % 64 != 0: per-chunk tap computation
+  const half_t* w;
+  int M, N, K, Kp;
+  const half_t* bias;
+  const half_t* rowvec;
+  const half_t* residual;
+  const half_t* residual2;
+  int ldr;
+  float out_scale;
+  int act;
+  half_t* out;
+  int ldo;
+  half_t* out2;
+  const half_t* add2;
+  half_t* out_t;
+  int ldt, t_col0;
+  int split_k, kt_per_split;
+  float* ws_partial;
+  int tiles_m, tiles_n;
+};
+
+// ---------------------------------------------------------------- epilogue (shared with the reducer)
+__device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int n, float (&v)[8]) {
+  // n is a multiple of 8; handles n + 8 > N by scalar fallback
+  const bool full = (n + 8 <= p.N);
+  if (p.bias) {
+    if (full) {
+      half8 b = *reinterpret_cast<const half8*>(p.bias + n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += (float)b[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (n + i < p.N) v[i] += (float)p.bias[n + i];
+    }
+  }
+  if (p.rowvec) {
+    if (full) {
+      half8 b = *reinterpret_cast<const half8*>(p.rowvec + n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += (float)b[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (n + i < p.N) v[i] += (float)p.rowvec[n + i];
+    }
+  }
+  if (p.act == VSD_ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
+  } else if (p.act == VSD_ACT_SILU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
+  } else if (p.act == VSD_ACT_QUICKGELU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = quick_gelu_f(v[i]);
+  }
+  if (p.out_scale != 1.0f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= p.out_scale;
+  }
+  if (p.out_t && n >= p.t_col0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (n + i < p.N) p.out_t[(size_t)(n + i - p.t_col0) * p.ldt + m] = (half_t)v[i];
+    return;
+  }
+  if (full) {
+    if (p.residual) {
+      half8 r = *reinterpret_cast<const half8*>(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += (float)r[i];
+    }
+    if (p.residual2) {
+      half8 r = *reinterpret_cast<const half8*>(p.residual2 + (size_t)m * p.ldr + n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += (float)r[i];
+    }
+    half8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (half_t)v[i];
+    *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
+    if (p.out2) {
+      half8 a = *reinterpret_cast<const half8*>(p.add2 + (size_t)m * p.ldo + n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (half_t)(v[i] + (float)a[i]);
+      *reinterpret_cast<half8*>(p.out2 + (size_t)m * p.ldo + n) = o;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (n + i >= p.N) continue;
+      float x = v[i];
+      if (p.residual) x += (float)p.residual[(size_t)m * p.ldr + n + i];
+      if (p.residual2) x += (float)p.residual2[(size_t)m * p.ldr + n + i];
+      p.out[(size_t)m * p.ldo + n + i] = (half_t)x;
+      if (p.out2) p.out2[(size_t)m * p.ldo + n + i] = (half_t)(x + (float)p.add2[(size_t)m * p.ldo + n + i]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- main kernel
+template <int BM, int BN, bool GENERIC>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+  constexpr int WM = 2, WN = 2;             // 2x2 waves
+  constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
+  constexpr int FM = TM / 16, FN = TN / 16;  // 16x16 fragments per wave
+  constexpr int AR = BM / 32, BR = BN / 32;  // 16-byte chunks per thread per K tile
+  constexpr int BNP = BN + 4;                // fp32 epilogue row pitch
+  constexpr int STAGE_BYTES = 2 * (BM + BN) * BK * 2;
+  constexpr int EPI_BYTES = BM * BNP * 4;
+  constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  half_t* As = reinterpret_cast<half_t*>(smem);                // [2][BM][64]
+  half_t* Bs = reinterpret_cast<half_t*>(smem) + 2 * BM * BK;  // [2][BN][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // block -> (tile_m fastest, tile_n, split)
+  int bid = blockIdx.x;
+  const int tile_m = bid % p.tiles_m;
+  bid /= p.tiles_m;
+  const int tile_n = bid % p.tiles_n;
+  const int split = bid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int KT = p.Kp / BK;
+  const int kt_begin = split * p.kt_per_split;
+  const int kt_end = min(KT, kt_begin + p.kt_per_split);
+
+  // ---- loader coordinates
+  const int cc = tid & 7;    // 16-byte chunk within the 128-byte tile row
+  const int lr = tid >> 3;   // 0..31
+  int iy0[AR], ix0[AR];
+  bool mvalid[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    int m = m0 + lr + 32 * i;
+    mvalid[i] = m < p.M;
+    int mm = mvalid[i] ? m : 0;
+    int oy = mm / p.wo, ox = mm - oy * p.wo;
+    iy0[i] = oy * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.pad;
+  }
+  const half_t* wrow[BR];
+  bool nvalid[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    int n = n0 + lr + 32 * i;
+    nvalid[i] = n < p.N;
+    wrow[i] = p.w + (size_t)(nvalid[i] ? n : 0) * p.Kp + cc * 8;
+  }
+
+  u32x4 areg[AR], breg[BR];
+  const u32x4 zero4 = (u32x4){0u, 0u, 0u, 0u};
+
+// Tile loader (macro, not a lambda: keeps areg/breg in registers).  Loads are unconditional from a
+// clamped, always-valid address and zeroed by a select, so there is no divergent control flow.
+#define VSD_LOAD_TILE(KT_)                                                                          \
+  {                                                                                                 \
+    const int kt_ = (KT_);                                                                          \
+    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                \
+      u32x4 v = *reinterpret_cast<const u32x4*>(wrow[i] + (size_t)kt_ * BK);                        \
+      breg[i] = nvalid[i] ? v : zero4;                                                              \
+    }                                                                                               \
+    int k_, cs_;                                                                                    \
+    const half_t* src_;                                                                             \
+    bool kok_ = true;                                                                               \
+    if (!GENERIC) {                                                                                 \
+      k_ = kt_ * BK; /* uniform: the whole tile lies inside one tap and one source */              \
+    } else {                                                                                        \
+      k_ = kt_ * BK + cc * 8;                                                                       \
+      kok_ = k_ < p.K;                                                                              \
+    }                                                                                               \
+    const int tap_ = k_ / p.cin;                                                                    \
+    int c_ = k_ - tap_ * p.cin;                                                                     \
+    const int ky_ = tap_ / p.ksize, kx_ = tap_ - ky_ * p.ksize;                                     \
+    if (!GENERIC && c_ >= p.c0) {                                                                   \
+      src_ = p.src1; cs_ = p.c1; c_ -= p.c0;                                                        \
+    } else {                                                                                        \
+      src_ = p.src0; cs_ = p.c0;                                                                    \
+    }                                                                                               \
+    if (!GENERIC) c_ += cc * 8;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                \
+      int iy = iy0[i] + ky_, ix = ix0[i] + kx_;                                                     \
+      bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi; \
+      int sy = iy, sx = ix;                                                                         \
+      if (p.resize) {                                                                               \
+        sy = (iy * p.hs) / p.hi;                                                                    \
+        sx = (ix * p.ws) / p.wi;                                                                    \
+      }                                                                                             \
+      size_t off = ok ? ((size_t)(sy * p.ws + sx)) * cs_ + c_ : 0;                                  \
+      u32x4 v = *reinterpret_cast<const u32x4*>(src_ + off);                                        \
+      areg[i] = ok ? v : zero4;                                                                     \
+    }                                                                                               \
+  }
+#define VSD_STORE_TILE(BUF_)                                                                        \
+  {                                                                                                 \
+    half_t* a_ = As + (BUF_) * BM * BK;                                                             \
+    half_t* b_ = Bs + (BUF_) * BN * BK;                                                             \
+    _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                \
+      int r = lr + 32 * i;                                                                          \
+      *reinterpret_cast<u32x4*>(a_ + r * BK + ((cc ^ (r & 7)) << 3)) = areg[i];                     \
+    }                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                \
+      int r = lr + 32 * i;                                                                          \
+      *reinterpret_cast<u32x4*>(b_ + r * BK + ((cc ^ (r & 7)) << 3)) = breg[i];                     \
+    }                                                                                               \
+  }
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;  // fragment row (A) / column (B)
+  const int fq = lane >> 4;  // k-chunk quarter
+
+  if (kt_begin < kt_end) {
+    VSD_LOAD_TILE(kt_begin)
+    VSD_STORE_TILE(0)
+  }
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) VSD_LOAD_TILE(kt + 1)
+    const half_t* a = As + buf * BM * BK;
+    const half_t* b = Bs + buf * BN * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 af[FM], bf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        int r = wm * TM + i * 16 + fr;
+        af[i] = *reinterpret_cast<const half8*>(a + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        int r = wn * TN + j * 16 + fr;
+        bf[j] = *reinterpret_cast<const half8*>(b + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) VSD_STORE_TILE(buf ^ 1)
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32) -> row-contiguous 8-wide chunks
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      int col = wn * TN + j * 16 + fr;
+      int row = wm * TM + i * 16 + fq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[(row + r) * BNP + col] = acc[i][j][r];
+    }
+  __syncthreads();
+
+  if (p.split_k > 1) {
+    constexpr int CH = BN / 8;
+    float* slab = p.ws_partial + (size_t)split * p.M * p.N;
+    for (int q = tid; q < BM * CH; q += 256) {
+      int r = q / CH, c8 = (q - r * CH) * 8;
+      int m = m0 + r, n = n0 + c8;
+      if (m >= p.M || n >= p.N) continue;
+      const float* s = Cs + r * BNP + c8;
+      float* d = slab + (size_t)m * p.N + n;
+      if (n + 8 <= p.N) {
+        *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(s);
+        *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(s + 4);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (n + i < p.N) d[i] = s[i];
+      }
+    }
+    return;
+  }
+
+  if (p.act == VSD_ACT_GEGLU) {
+    constexpr int CH = BN / 16;  // chunks over the hidden half
+    const int no = p.N >> 1;
+    for (int q = tid; q < BM * CH; q += 256) {
+      int r = q / CH, c8 = (q - r * CH) * 8;
+      int m = m0 + r;
+      if (m >= p.M) continue;
+      const float* s = Cs + r * BNP + c8;
+      half8 bh = *reinterpret_cast<const half8*>(p.bias + n0 + c8);
+      half8 bg = *reinterpret_cast<const half8*>(p.bias + n0 + BN / 2 + c8);
+      half8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float h = s[i] + (float)bh[i];
+        float g = s[BN / 2 + i] + (float)bg[i];
+        o[i] = (half_t)(h * gelu_erf_f(g));
+      }
+      int n = (n0 >> 1) + c8;
+      if (n < no) *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
+    }
+    return;
+  }
+
+  const bool transposed_tile = p.out_t && n0 >= p.t_col0;
+  if (transposed_tile) {
+    // lanes run along m so that the 2-byte transposed stores coalesce
+    constexpr int CH = BN / 8;
+    for (int q = tid; q < BM * CH; q += 256) {
+      int r = q % BM, c8 = (q / BM) * 8;
+      int m = m0 + r, n = n0 + c8;
+      if (m >= p.M || n >= p.N) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = Cs[r * BNP + c8 + i];
+      epilogue_store8(p, m, n, v);
+    }
+  } else {
+    constexpr int CH = BN / 8;
+    for (int q = tid; q < BM * CH; q += 256) {
+      int r = q / CH, c8 = (q - r * CH) * 8;
+      int m = m0 + r, n = n0 + c8;
+      if (m >= p.M || n >= p.N) continue;
+      float v[8];
+      f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8);
+      f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8 + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = lo[i];
+        v[4 + i] = hi[i];
+      }
+      epilogue_store8(p, m, n, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- split-K reducer
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
+  const int nch = (p.N + 7) / 8;
+  const size_t total = (size_t)p.M * nch;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+    int m = (int)(q / nch);
+    int n = (int)(q - (size_t)m * nch) * 8;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t slab = (size_t)p.M * p.N;
+    const float* s = p.ws_partial + (size_t)m * p.N + n;
+    if (n + 8 <= p.N) {
+      for (int k = 0; k < p.split_k; ++k) {
+        f32x4 lo = *reinterpret_cast<const f32x4*>(s + k * slab);
+        f32x4 hi = *reinterpret_cast<const f32x4*>(s + k * slab + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] += lo[i];
+          v[4 + i] += hi[i];
+        }
+      }
+    } else {
+      for (int k = 0; k < p.split_k; ++k) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (n + i < p.N) v[i] += s[k * slab + i];
+      }
+    }
+    epilogue_store8(p, m, n, v);
+  }
+}
+
+template <int BM, int BN>
+void launch(const ConvParams& p, int grid, hipStream_t s) {
+  if (p.generic) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true>), dim3(grid), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false>), dim3(grid), dim3(256), 0, s, p);
+}
+
+}  // namespace
+
+extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream) {
+  if (!ctx || !d) return VSD_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  ConvParams p;
+  p.src0 = (const half_t*)d->src0;
+  p.src1 = (const half_t*)d->src1;
+  p.c0 = d->c0;
+  p.c1 = d->src1 ? d->c1 : 0;
+  p.cin = p.c0 + p.c1;
+  p.hs = d->hs; p.ws = d->ws; p.hi = d->hi; p.wi = d->wi; p.ho = d->ho; p.wo = d->wo;
+  p.ksize = d->ksize; p.stride = d->stride; p.pad = d->pad;
+  p.resize = (d->hi != d->hs) || (d->wi != d->ws);
+  p.generic = (p.cin % 64) != 0;
+  p.w = (const half_t*)d->weight;
+  p.M = d->ho * d->wo;
+  p.N = d->n; p.K = d->k; p.Kp = d->kp;
+  p.bias = (const half_t*)d->bias;
+  p.rowvec = (const half_t*)d->rowvec;
+  p.residual = (const half_t*)d->residual;
+  p.residual2 = (const half_t*)d->residual2;
+  p.ldr = d->ldr;
+  p.out_scale = d->out_scale;
+  p.act = d->act;
+  p.out = (half_t*)d->out; p.ldo = d->ldo;
+  p.out2 = (half_t*)d->out2; p.add2 = (const half_t*)d->add2;
+  p.out_t = (half_t*)d->out_t; p.ldt = d->ldt; p.t_col0 = d->t_col0;
+  p.split_k = d->split_k < 1 ? 1 : d->split_k;
+  p.ws_partial = (float*)d->workspace;
+
+  if (!p.src0 || !p.w || !p.out) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: null src/weight/out");
+  if (p.M <= 0 || p.N <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: empty problem M=%d N=%d", p.M, p.N);
+  if (p.c0 % 8 || p.c1 % 8) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: channels must be multiples of 8 (%d,%d)", p.c0, p.c1);
+  if (p.c1 && (p.c0 % 64 || p.c1 % 64)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: concat sources need C %% 64 == 0");
+  if (p.K != p.ksize * p.ksize * p.cin) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: K=%d != ks^2*Cin=%d", p.K, p.ksize * p.ksize * p.cin);
+  if (p.Kp % BK || p.Kp < p.K) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: Kp=%d must be K rounded up to 64", p.Kp);
+  if (p.ksize != 1 && p.ksize != 3) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: ksize %d", p.ksize);
+  if (p.ldo % 8 || (p.residual && p.ldr % 8)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: ld must be a multiple of 8");
+  if (p.out2 && !p.add2) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: out2 without add2");
+  if (p.split_k > 1 && !p.ws_partial) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: split_k needs a workspace");
+  int BM, BN;
+  switch (d->tile) {
+    case VSD_TILE_128x128: BM = 128; BN = 128; break;
+    case VSD_TILE_128x64: BM = 128; BN = 64; break;
+    case VSD_TILE_64x64: BM = 64; BN = 64; break;
+    case VSD_TILE_64x128: BM = 64; BN = 128; break;
+    default: return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: tile %d", d->tile);
+  }
+  if (p.act == VSD_ACT_GEGLU) {
+    if (BN != 128 || p.N % 128 || p.split_k != 1 || !p.bias || p.out_t)
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: GEGLU needs BN=128, N %% 128 == 0, bias, no split-K");
+  }
+  if (p.out_t && (p.t_col0 % BN)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: t_col0 must be a multiple of BN");
+  p.tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.N, BN);
+  const int KT = p.Kp / BK;
+  if (p.split_k > KT) p.split_k = KT;
+  p.kt_per_split = cdiv(KT, p.split_k);
+  p.split_k = cdiv(KT, p.kt_per_split);
+  const int grid = p.tiles_m * p.tiles_n * p.split_k;
+  {
+    LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
+    if (BM == 128 && BN == 128) launch<128, 128>(p, grid, s);
+    else if (BM == 128 && BN == 64) launch<128, 64>(p, grid, s);
+    else if (BM == 64 && BN == 64) launch<64, 64>(p, grid, s);
+    else launch<64, 128>(p, grid, s);
+    int rc = ls.finish();
+    if (rc) return rc;
+  }
+  if (p.split_k > 1) {
+    LaunchScope ls(ctx, s, VSD_FAM_SPLITK_REDUCE, 0.0);
+    size_t total = (size_t)p.M * ((p.N + 7) / 8);
+    int g = (int)((total + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
+    int rc = ls.finish();
+    if (rc) return rc;
+  }
+  return VSD_OK;
+}

@@ -1,0 +1,208 @@
+// Per-frame elementwise kernels (gfx950): image pre/post-processing, Sobel edge map, LCM scheduler
+// arithmetic.  All are tiny and HBM/launch-bound; they exist so that a frame needs no host round trip
+// between the u8 upload and the u8 download (the reference syncs twice per frame: canny_gpu.py:44 and
+// lcm_controlnet.py:609-611).
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace {
+
+__global__ void preprocess_rgb_kernel(const unsigned char* __restrict__ rgb, int hw, half_t* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hw) return;
+  half8 o = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float x = (float)rgb[i * 3 + c] / 255.0f;          // pil_to_numpy
+    half_t y = (half_t)(2.0f * x - 1.0f);              // normalize, cast to fp16 (prepare_latents dtype)
+    half_t z = (half_t)((float)y + 1.0f);              // EncoderTiny: x.add(1)
+    o[c] = (half_t)((float)z * 0.5f);                  //              .div(2)
+  }
+  *reinterpret_cast<half8*>(out + (size_t)i * 8) = o;
+}
+
+__device__ __forceinline__ float gray01(const unsigned char* rgb, int h, int w, int y, int x) {
+  if ((unsigned)y >= (unsigned)h || (unsigned)x >= (unsigned)w) return 0.f;
+  const unsigned char* p = rgb + ((size_t)y * w + x) * 3;
+  unsigned l = (p[0] * 19595u + p[1] * 38470u + p[2] * 7471u + 0x8000u) >> 16;  // PIL convert("L")
+  return (float)l / 255.0f;                                                      // ToTensor
+}
+
+__device__ __forceinline__ float sobel_mag(const unsigned char* rgb, int h, int w, int y, int x) {
+  float a = gray01(rgb, h, w, y - 1, x - 1), b = gray01(rgb, h, w, y - 1, x), c = gray01(rgb, h, w, y - 1, x + 1);
+  float d = gray01(rgb, h, w, y, x - 1), f = gray01(rgb, h, w, y, x + 1);
+  float g = gray01(rgb, h, w, y + 1, x - 1), hh = gray01(rgb, h, w, y + 1, x), i = gray01(rgb, h, w, y + 1, x + 1);
+  float ex = (c - a) + 2.0f * (f - d) + (i - g);
+  float ey = (g - a) + 2.0f * (hh - b) + (i - c);
+  return sqrtf(ex * ex + ey * ey);
+}
+
+__global__ void sobel_max_kernel(const unsigned char* __restrict__ rgb, int h, int w, unsigned* gmax) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float m = 0.f;
+  if (i < h * w) m = sobel_mag(rgb, h, w, i / w, i % w);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    atomicMax(gmax, __float_as_uint(m));  // magnitudes are >= 0: uint order == float order; max is order independent
+  }
+}
+
+__global__ void sobel_apply_kernel(const unsigned char* __restrict__ rgb, int h, int w, float low, float high,
+                                   const unsigned* gmax, unsigned char* __restrict__ edge, half_t* __restrict__ ctrl) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h * w) return;
+  float mx = __uint_as_float(*gmax);
+  float e = sobel_mag(rgb, h, w, i / w, i % w) / mx;  // 0/0 -> NaN on an all-black frame, like the reference
+  if (e >= high) e = 1.0f;
+  if (e <= low) e = 0.0f;
+  float s = e * 255.0f;
+  unsigned char u = (s == s) ? (unsigned char)(int)s : 0;  // .byte() truncation; NaN -> 0
+  edge[i] = u;
+  half_t v = (half_t)((float)u / 255.0f);
+  *reinterpret_cast<half8*>(ctrl + (size_t)i * 8) = (half8){v, v, v, 0, 0, 0, 0, 0};
+}
+
+__global__ void add_noise_kernel(const half_t* __restrict__ x0, const float* __restrict__ noise, float sa, float sb, int hw,
+                                 half_t* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hw) return;
+  half8 x = *reinterpret_cast<const half8*>(x0 + (size_t)i * 8);
+  half8 o = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o[c] = (half_t)(sa * (float)x[c] + sb * noise[(size_t)c * hw + i]);
+  *reinterpret_cast<half8*>(out + (size_t)i * 8) = o;
+}
+
+struct StepCoef {
+  float sa, sb, cskip, cout, sap, sbp;
+};
+
+__global__ void lcm_step_kernel(const half_t* __restrict__ eps, const half_t* __restrict__ sample,
+                                const float* __restrict__ noise, StepCoef k, int hw, half_t* __restrict__ prev,
+                                half_t* __restrict__ den, half_t* __restrict__ dec_in) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hw) return;
+  half8 e = *reinterpret_cast<const half8*>(eps + (size_t)i * 8);
+  half8 x = *reinterpret_cast<const half8*>(sample + (size_t)i * 8);
+  half8 op = (half8){0, 0, 0, 0, 0, 0, 0, 0}, od = op, oi = op;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float xs = (float)x[c];
+    float px0 = (xs - k.sb * (float)e[c]) / k.sa;
+    float d = k.cout * px0 + k.cskip * xs;
+    od[c] = (half_t)d;
+    float pv = noise ? k.sap * d + k.sbp * noise[(size_t)c * hw + i] : d;
+    op[c] = (half_t)pv;
+    oi[c] = (half_t)(tanhf((float)od[c] / 3.0f) * 3.0f);
+  }
+  if (prev) *reinterpret_cast<half8*>(prev + (size_t)i * 8) = op;
+  if (den) *reinterpret_cast<half8*>(den + (size_t)i * 8) = od;
+  if (dec_in) *reinterpret_cast<half8*>(dec_in + (size_t)i * 8) = oi;
+}
+
+__global__ void postprocess_kernel(const half_t* __restrict__ img, int ld, int hw, unsigned char* __restrict__ rgb) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hw) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    half_t y = (half_t)((float)img[(size_t)i * ld + c] * 2.0f - 1.0f);   // DecoderTiny: x.mul(2).sub(1)
+    half_t z = (half_t)((float)y * 0.5f + 0.5f);                          // postprocess denormalize (fp16)
+    float f = fminf(fmaxf((float)z, 0.0f), 1.0f);
+    rgb[(size_t)i * 3 + c] = (unsigned char)rintf(f * 255.0f);            // numpy round: half to even
+  }
+}
+
+__global__ void axpy_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, float scale, int64_t n8,
+                            half_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    half8 x = reinterpret_cast<const half8*>(a)[i];
+    half8 y = reinterpret_cast<const half8*>(b)[i];
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)x[j] + scale * (float)y[j]);
+    reinterpret_cast<half8*>(out)[i] = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int vsd_preprocess_rgb(vsd_ctx* ctx, const void* rgb_u8, int h, int w, void* out, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (!rgb_u8 || !out || h <= 0 || w <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "preprocess_rgb: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
+  hipLaunchKernelGGL(preprocess_rgb_kernel, dim3(cdiv(h * w, 256)), dim3(256), 0, s, (const unsigned char*)rgb_u8, h * w,
+                     (half_t*)out);
+  return ls.finish();
+}
+
+extern "C" int vsd_sobel_control(vsd_ctx* ctx, const void* rgb_u8, int h, int w, float low, float high, void* edge_u8,
+                                 void* control_out, void* workspace, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (!rgb_u8 || !edge_u8 || !control_out || !workspace || h <= 0 || w <= 0)
+    return vsd_fail(ctx, VSD_ERR_ARG, "sobel_control: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  VSD_HIP(ctx, hipMemsetAsync(workspace, 0, 16, s));
+  {
+    LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
+    hipLaunchKernelGGL(sobel_max_kernel, dim3(cdiv(h * w, 256)), dim3(256), 0, s, (const unsigned char*)rgb_u8, h, w,
+                       (unsigned*)workspace);
+    int rc = ls.finish();
+    if (rc) return rc;
+  }
+  LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
+  hipLaunchKernelGGL(sobel_apply_kernel, dim3(cdiv(h * w, 256)), dim3(256), 0, s, (const unsigned char*)rgb_u8, h, w, low,
+                     high, (const unsigned*)workspace, (unsigned char*)edge_u8, (half_t*)control_out);
+  return ls.finish();
+}
+
+extern "C" int vsd_add_noise(vsd_ctx* ctx, const void* x0, const void* noise_f32, float sqrt_a, float sqrt_b, int hw,
+                             void* out, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (!x0 || !noise_f32 || !out || hw <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "add_noise: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
+  hipLaunchKernelGGL(add_noise_kernel, dim3(cdiv(hw, 256)), dim3(256), 0, s, (const half_t*)x0, (const float*)noise_f32,
+                     sqrt_a, sqrt_b, hw, (half_t*)out);
+  return ls.finish();
+}
+
+extern "C" int vsd_lcm_step(vsd_ctx* ctx, const void* eps, const void* sample, const void* noise_f32,
+                            const float* coef_host, int hw, void* prev, void* denoised, void* dec_in, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (!eps || !sample || !coef_host || hw <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "lcm_step: bad arguments");
+  StepCoef k = {coef_host[0], coef_host[1], coef_host[2], coef_host[3], coef_host[4], coef_host[5]};
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
+  hipLaunchKernelGGL(lcm_step_kernel, dim3(cdiv(hw, 256)), dim3(256), 0, s, (const half_t*)eps, (const half_t*)sample,
+                     (const float*)noise_f32, k, hw, (half_t*)prev, (half_t*)denoised, (half_t*)dec_in);
+  return ls.finish();
+}
+
+extern "C" int vsd_postprocess_rgb(vsd_ctx* ctx, const void* img, int ld, int hw, void* rgb_u8, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (!img || !rgb_u8 || hw <= 0 || ld < 3) return vsd_fail(ctx, VSD_ERR_ARG, "postprocess_rgb: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
+  hipLaunchKernelGGL(postprocess_kernel, dim3(cdiv(hw, 256)), dim3(256), 0, s, (const half_t*)img, ld, hw,
+                     (unsigned char*)rgb_u8);
+  return ls.finish();
+}
+
+extern "C" int vsd_axpy(vsd_ctx* ctx, const void* a, const void* b, float scale, int64_t n, void* out, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (!a || !b || !out || n <= 0 || n % 8) return vsd_fail(ctx, VSD_ERR_ARG, "axpy: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t n8 = n / 8;
+  int grid = (int)((n8 + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, s, (const half_t*)a, (const half_t*)b, scale, n8, (half_t*)out);
+  return ls.finish();
+}

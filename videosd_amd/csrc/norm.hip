@@ -1,0 +1,247 @@
+// GroupNorm(+SiLU) and LayerNorm for NHWC fp16 tensors (gfx950).  HBM/L2-bound streaming kernels:
+// 16-byte vector loads, per-thread fixed channel chunk so that per-channel scale/shift live in
+// registers, wave-shuffle / LDS reductions in fp32.
+//
+// GroupNorm is two launches: `gn_stats` writes per-workgroup partial (sum, sumsq) per group in a fixed
+// order (deterministic, no atomics), `gn_apply` folds the partials, then streams y = x*a[c] + b[c]
+// (+SiLU).  The input may be the channel concat of two tensors (UNet up blocks) and the output is the
+// concatenated, normalised tensor.  Algorithmic bytes: 2 reads + 1 write of hw*C fp16.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int GN_MAX_PART = 64;
+
+struct GnParams {
+  const half_t* src0;
+  const half_t* src1;
+  int c0, c1, c, c8;  // c8 = c / 8
+  int hw, groups, cpg;
+  float eps;
+  const half_t* gamma;
+  const half_t* beta;
+  int silu;
+  half_t* out;
+  float* part;  // [nblk][groups][2]
+  int nblk;     // stats workgroups
+  int rpp;      // rows per pass = blockDim / c8
+};
+
+__device__ __forceinline__ half8 gn_load(const GnParams& p, int row, int ch8) {
+  int c = ch8 * 8;
+  const half_t* s = (c < p.c0) ? p.src0 + (size_t)row * p.c0 + c : p.src1 + (size_t)row * p.c1 + (c - p.c0);
+  return *reinterpret_cast<const half8*>(s);
+}
+
+__global__ void gn_stats_kernel(const GnParams p) {
+  extern __shared__ float sm[];  // [rpp][c][2] per-thread channel sums, folded in a fixed order
+  const int t = threadIdx.x;
+  const int ch8 = t % p.c8;
+  const int rl = t / p.c8;
+  const int rows_per_blk = (p.hw + p.nblk - 1) / p.nblk;
+  const int r0 = blockIdx.x * rows_per_blk;
+  const int r1 = min(p.hw, r0 + rows_per_blk);
+  float s[8], q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+  for (int r = r0 + rl; r < r1; r += p.rpp) {
+    half8 x = gn_load(p, r, ch8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = (float)x[i];
+      s[i] += v;
+      q[i] += v * v;
+    }
+  }
+  float* mine = sm + ((size_t)rl * p.c + ch8 * 8) * 2;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    mine[2 * i] = s[i];
+    mine[2 * i + 1] = q[i];
+  }
+  __syncthreads();
+  for (int g = t; g < p.groups; g += blockDim.x) {
+    float gs = 0.f, gq = 0.f;
+    for (int r = 0; r < p.rpp; ++r) {
+      const float* row = sm + ((size_t)r * p.c + g * p.cpg) * 2;
+      for (int c = 0; c < p.cpg; ++c) {
+        gs += row[2 * c];
+        gq += row[2 * c + 1];
+      }
+    }
+    p.part[((size_t)blockIdx.x * p.groups + g) * 2] = gs;
+    p.part[((size_t)blockIdx.x * p.groups + g) * 2 + 1] = gq;
+  }
+}
+
+__global__ void gn_apply_kernel(const GnParams p) {
+  extern __shared__ float sm[];  // [groups][2] -> mean, rstd
+  const int t = threadIdx.x;
+  if (t < p.groups) {
+    float s = 0.f, q = 0.f;
+    for (int b = 0; b < p.nblk; ++b) {
+      s += p.part[((size_t)b * p.groups + t) * 2];
+      q += p.part[((size_t)b * p.groups + t) * 2 + 1];
+    }
+    float n = (float)p.hw * (float)p.cpg;
+    float mean = s / n;
+    float var = fmaxf(q / n - mean * mean, 0.f);
+    sm[t * 2] = mean;
+    sm[t * 2 + 1] = rsqrtf(var + p.eps);
+  }
+  __syncthreads();
+  const int ch8 = t % p.c8;
+  const int rl = t / p.c8;
+  float a[8], b[8];
+  {
+    half8 ga = *reinterpret_cast<const half8*>(p.gamma + ch8 * 8);
+    half8 be = *reinterpret_cast<const half8*>(p.beta + ch8 * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int g = (ch8 * 8 + i) / p.cpg;
+      float mean = sm[g * 2], rstd = sm[g * 2 + 1];
+      a[i] = rstd * (float)ga[i];
+      b[i] = (float)be[i] - mean * a[i];
+    }
+  }
+  const int rows_per_blk = (p.hw + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per_blk;
+  const int r1 = min(p.hw, r0 + rows_per_blk);
+  for (int r = r0 + rl; r < r1; r += p.rpp) {
+    half8 x = gn_load(p, r, ch8);
+    half8 y;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = (float)x[i] * a[i] + b[i];
+      if (p.silu) v = silu_f(v);
+      y[i] = (half_t)v;
+    }
+    *reinterpret_cast<half8*>(p.out + (size_t)r * p.c + ch8 * 8) = y;
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wave per row
+template <int NCH>  // 16-byte chunks per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, int rows, int c, const half_t* gamma,
+                                                        const half_t* beta, float eps, half_t* out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c8 = c >> 3;
+  half8 v[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int ch = lane + 64 * i;
+    if (ch < c8) {
+      v[i] = *reinterpret_cast<const half8*>(x + (size_t)row * c + ch * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)c;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int ch = lane + 64 * i;
+    if (ch < c8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float d = (float)v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / (float)c + eps);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int ch = lane + 64 * i;
+    if (ch < c8) {
+      half8 g = *reinterpret_cast<const half8*>(gamma + ch * 8);
+      half8 b = *reinterpret_cast<const half8*>(beta + ch * 8);
+      half8 y;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = (half_t)(((float)v[i][j] - mean) * rstd * (float)g[j] + (float)b[j]);
+      *reinterpret_cast<half8*>(out + (size_t)row * c + ch * 8) = y;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t vsd_groupnorm_workspace_bytes(int hw, int c, int groups) {
+  (void)hw;
+  (void)c;
+  return (int64_t)GN_MAX_PART * groups * 2 * sizeof(float);
+}
+
+extern "C" int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int groups,
+                             float eps, const void* gamma, const void* beta, int silu, void* out, void* workspace,
+                             void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  GnParams p;
+  p.src0 = (const half_t*)src0;
+  p.src1 = (const half_t*)src1;
+  p.c0 = c0;
+  p.c1 = src1 ? c1 : 0;
+  p.c = p.c0 + p.c1;
+  if (!src0 || !out || !gamma || !beta || !workspace) return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm: null pointer");
+  if (p.c0 % 8 || p.c1 % 8 || hw <= 0 || groups <= 0 || p.c % groups)
+    return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm: bad shape c0=%d c1=%d hw=%d groups=%d", c0, c1, hw, groups);
+  p.c8 = p.c / 8;
+  if (p.c8 > 1024) return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm: C=%d too large", p.c);
+  if (groups > 256) return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm: groups=%d too large", groups);
+  p.hw = hw; p.groups = groups; p.cpg = p.c / groups; p.eps = eps;
+  p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.silu = silu;
+  p.out = (half_t*)out; p.part = (float*)workspace;
+  p.rpp = p.c8 >= 256 ? 1 : 256 / p.c8;
+  const int threads = p.c8 * p.rpp;
+  int nblk = cdiv(hw, 4 * p.rpp);
+  if (nblk > GN_MAX_PART) nblk = GN_MAX_PART;
+  if (nblk < 1) nblk = 1;
+  p.nblk = nblk;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t smem = (size_t)groups * 2 * sizeof(float);
+  {
+    const size_t smem_stats = (size_t)p.rpp * p.c * 2 * sizeof(float);
+    LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk), dim3(threads), smem_stats, s, p);
+    int rc = ls.finish();
+    if (rc) return rc;
+  }
+  {
+    int ablk = cdiv(hw, 2 * p.rpp);
+    if (ablk > 512) ablk = 512;
+    LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk), dim3(threads), smem, s, p);
+    return ls.finish();
+  }
+}
+
+extern "C" int vsd_layernorm(vsd_ctx* ctx, const void* x, int rows, int c, const void* gamma, const void* beta,
+                             float eps, void* out, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (!x || !out || !gamma || !beta) return vsd_fail(ctx, VSD_ERR_ARG, "layernorm: null pointer");
+  if (c % 8 || c <= 0 || c > 8 * 64 * 4 || rows <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "layernorm: bad shape rows=%d c=%d", rows, c);
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = cdiv(c / 8, 64);
+  LaunchScope ls(ctx, s, VSD_FAM_LAYERNORM, 0.0);
+  dim3 grid(cdiv(rows, 4)), block(256);
+  const half_t* xx = (const half_t*)x;
+  const half_t* g = (const half_t*)gamma;
+  const half_t* b = (const half_t*)beta;
+  half_t* o = (half_t*)out;
+  switch (nch) {
+    case 1: hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, s, xx, rows, c, g, b, eps, o); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, s, xx, rows, c, g, b, eps, o); break;
+    case 3: hipLaunchKernelGGL((layernorm_kernel<3>), grid, block, 0, s, xx, rows, c, g, b, eps, o); break;
+    default: hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, s, xx, rows, c, g, b, eps, o); break;
+  }
+  return ls.finish();
+}

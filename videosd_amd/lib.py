@@ -1,0 +1,122 @@
+"""ctypes binding of libvsd.so (include/vsd.h).  No fallback: if the HIP library is missing or a call
+fails, a RuntimeError is raised."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvsd.so")
+
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_QUICKGELU = range(5)
+TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = range(4)
+TILE_DIMS = {TILE_128x128: (128, 128), TILE_128x64: (128, 64), TILE_64x64: (64, 64), TILE_64x128: (64, 128)}
+FAMILIES = ["conv_gemm", "splitk_reduce", "groupnorm", "layernorm", "attention", "elementwise"]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("src0", C.c_void_p), ("src1", C.c_void_p),
+        ("c0", C.c_int32), ("c1", C.c_int32),
+        ("hs", C.c_int32), ("ws", C.c_int32),
+        ("hi", C.c_int32), ("wi", C.c_int32),
+        ("ho", C.c_int32), ("wo", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("weight", C.c_void_p),
+        ("n", C.c_int32), ("k", C.c_int32), ("kp", C.c_int32),
+        ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("residual", C.c_void_p), ("residual2", C.c_void_p),
+        ("ldr", C.c_int32),
+        ("out_scale", C.c_float),
+        ("act", C.c_int32),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("out2", C.c_void_p), ("add2", C.c_void_p),
+        ("out_t", C.c_void_p), ("ldt", C.c_int32), ("t_col0", C.c_int32),
+        ("tile", C.c_int32), ("split_k", C.c_int32),
+        ("workspace", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/vsd.h
+SIGNATURES = {
+    "vsd_version": (C.c_int, []),
+    "vsd_create": (C.c_void_p, [C.c_int]),
+    "vsd_destroy": (None, [C.c_void_p]),
+    "vsd_last_error": (C.c_char_p, [C.c_void_p]),
+    "vsd_conv_gemm": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p]),
+    "vsd_groupnorm_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "vsd_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsd_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                C.c_void_p, C.c_void_p]),
+    "vsd_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "vsd_preprocess_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vsd_sobel_control": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsd_add_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p,
+                                C.c_void_p]),
+    "vsd_lcm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsd_postprocess_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vsd_axpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]),
+    "vsd_graph_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vsd_graph_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "vsd_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsd_graph_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vsd_profile_begin": (C.c_int, [C.c_void_p]),
+    "vsd_profile_end": (C.c_int, [C.c_void_p]),
+    "vsd_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libvsd.so and bind every symbol.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -m videosd_amd.build` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class Context:
+    """One vsd_ctx (one GPU).  Methods raise RuntimeError with vsd_last_error() on failure."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = load()
+        self.h = self.lib.vsd_create(device_id)
+        if not self.h:
+            raise RuntimeError(f"vsd_create({device_id}) failed: no such HIP device")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vsd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.vsd_last_error(self.h)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def call(self, name: str, *args):
+        self.check(getattr(self.lib, name)(self.h, *args), name)
+
+    def stage_times(self):
+        ms = (C.c_float * len(FAMILIES))()
+        n = (C.c_int64 * len(FAMILIES))()
+        fl = (C.c_double * len(FAMILIES))()
+        self.call("vsd_stage_times", ms, n, fl)
+        return {f: {"ms": float(ms[i]), "launches": int(n[i]), "flops": float(fl[i])} for i, f in enumerate(FAMILIES)}

@@ -1,0 +1,207 @@
+"""HipOps: the op interface the engine is written against, bound to libvsd.so through ctypes.
+
+Tensors are torch CUDA(ROCm) tensors used purely as device buffers (`.data_ptr()`); every compute
+call goes through the C-ABI of include/vsd.h on `self.stream`.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import lib as L
+from .packing import PackedConv
+
+
+@dataclass(frozen=True)
+class Geom:
+    """Spatial geometry of one implicit-GEMM conv: stored source size, logical (resized) input size, output size."""
+    hs: int
+    ws: int
+    hi: int
+    wi: int
+    ho: int
+    wo: int
+    ksize: int = 1
+    stride: int = 1
+    pad: int = 0
+
+    @staticmethod
+    def linear(rows: int) -> "Geom":
+        return Geom(1, rows, 1, rows, 1, rows, 1, 1, 0)
+
+    @staticmethod
+    def conv(h: int, w: int, ksize=3, stride=1, up_to=None) -> "Geom":
+        hi, wi = (h, w) if up_to is None else up_to
+        pad = ksize // 2
+        ho = (hi + 2 * pad - ksize) // stride + 1
+        wo = (wi + 2 * pad - ksize) // stride + 1
+        return Geom(h, w, hi, wi, ho, wo, ksize, stride, pad)
+
+    @property
+    def m(self) -> int:
+        return self.ho * self.wo
+
+
+def choose_tile(m: int, n: int, kp: int, geglu: bool = False, t_col0: int = 0):
+    """Heuristic (tile, split_k): minimise padding waste, prefer big tiles, then split K until the grid
+    covers the 256 CUs.  The engine's autotuner can override this per layer."""
+    cands = [L.TILE_128x128, L.TILE_64x128] if geglu else [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64]
+    pen = {L.TILE_128x128: 1.0, L.TILE_128x64: 1.12, L.TILE_64x128: 1.12, L.TILE_64x64: 1.3}
+    kt = kp // 64
+    best = None
+    for t in cands:
+        bm, bn = L.TILE_DIMS[t]
+        if t_col0 % bn:
+            continue
+        tm, tn = -(-m // bm), -(-n // bn)
+        blocks = tm * tn
+        waste = (tm * bm * tn * bn) / float(m * n)
+        split = 1
+        if not geglu and blocks < 256 and kt >= 8:
+            split = max(1, min(-(-320 // blocks), kt // 4))
+        total = blocks * split
+        fill = min(1.0, total / 256.0)
+        # rounds of 256-CU waves at ~2 blocks/CU
+        cost = waste * pen[t] / max(fill, 0.05) * (1.0 + 0.04 * (split - 1))
+        if best is None or cost < best[0]:
+            best = (cost, t, split)
+    return best[1], best[2]
+
+
+class HipOps:
+    name = "hip"
+
+    def __init__(self, device_id: int = 0, stream: Optional[torch.cuda.Stream] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipOps needs a ROCm GPU; there is no CPU fallback in the product path")
+        self.device = torch.device("cuda", device_id)
+        torch.cuda.set_device(self.device)
+        self.ctx = L.Context(device_id)
+        self.stream = stream or torch.cuda.Stream(device=self.device)
+        self._ws = {}
+        self.tile_override = {}
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def s(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def empty(self, *shape, dtype=torch.float16):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float16):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def to_device(self, t: torch.Tensor):
+        return t.to(self.device)
+
+    def workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        cur = self._ws.get(key)
+        if cur is None or cur.numel() < nbytes:
+            cur = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            self._ws[key] = cur
+        return cur
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    # ------------------------------------------------------------------ ops
+    def conv(self, src0, src1, g: Geom, w: PackedConv, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None,
+             residual2=None, ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0,
+             t_col0=0, tile=None, split_k=None, workspace=None):
+        m = g.m
+        c0 = c0 if c0 is not None else (w.cin - c1)
+        if w.geglu:
+            act = L.ACT_GEGLU
+        key = (m, w.n, w.kp, w.geglu, t_col0)
+        if tile is None:
+            if key in self.tile_override:
+                tile, split_k = self.tile_override[key]
+            else:
+                tile, sk = choose_tile(m, w.n, w.kp, w.geglu, t_col0 if out_t is not None else 0)
+                split_k = sk if split_k is None else split_k
+        split_k = split_k or 1
+        d = L.ConvDesc()
+        d.src0, d.src1 = self._p(src0), self._p(src1)
+        d.c0, d.c1 = c0, c1
+        d.hs, d.ws, d.hi, d.wi, d.ho, d.wo = g.hs, g.ws, g.hi, g.wi, g.ho, g.wo
+        d.ksize, d.stride, d.pad = g.ksize, g.stride, g.pad
+        d.weight = self._p(w.weight)
+        d.n, d.k, d.kp = w.n, w.k, w.kp
+        d.bias = self._p(w.bias)
+        d.rowvec = self._p(rowvec)
+        d.residual, d.residual2 = self._p(residual), self._p(residual2)
+        d.ldr = ldr if ldr is not None else w.n_out
+        d.out_scale = out_scale
+        d.act = act
+        d.out = self._p(out)
+        d.ldo = ldo if ldo is not None else w.n_out
+        d.out2, d.add2 = self._p(out2), self._p(add2)
+        d.out_t, d.ldt, d.t_col0 = self._p(out_t), ldt, t_col0
+        d.tile, d.split_k = tile, split_k
+        if split_k > 1:
+            ws = workspace if workspace is not None else self.workspace("splitk", split_k * m * w.n * 4)
+            d.workspace = self._p(ws)
+        self.ctx.call("vsd_conv_gemm", C.byref(d), self.s)
+
+    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out):
+        ws = self.workspace("gn", int(self.ctx.lib.vsd_groupnorm_workspace_bytes(hw, c0 + c1, groups)))
+        self.ctx.call("vsd_groupnorm", self._p(src0), self._p(src1), c0, c1, hw, groups, eps, self._p(gamma),
+                      self._p(beta), int(silu), self._p(out), self._p(ws), self.s)
+
+    def layernorm(self, x, rows, c, gamma, beta, eps, out):
+        self.ctx.call("vsd_layernorm", self._p(x), rows, c, self._p(gamma), self._p(beta), eps, self._p(out), self.s)
+
+    def attention(self, q, ldq, k, ldk, vt, ldvt, out, ldo, sq, sk, heads, d, scale, causal=False):
+        self.ctx.call("vsd_attention", self._p(q), ldq, self._p(k), ldk, self._p(vt), ldvt, self._p(out), ldo, sq, sk,
+                      heads, d, scale, int(causal), self.s)
+
+    def preprocess_rgb(self, rgb_u8, h, w, out):
+        self.ctx.call("vsd_preprocess_rgb", self._p(rgb_u8), h, w, self._p(out), self.s)
+
+    def sobel_control(self, rgb_u8, h, w, low, high, edge_u8, control_out):
+        ws = self.workspace("sobel", 256)
+        self.ctx.call("vsd_sobel_control", self._p(rgb_u8), h, w, low, high, self._p(edge_u8), self._p(control_out),
+                      self._p(ws), self.s)
+
+    def add_noise(self, x0, noise_f32, sqrt_a, sqrt_b, hw, out):
+        self.ctx.call("vsd_add_noise", self._p(x0), self._p(noise_f32), sqrt_a, sqrt_b, hw, self._p(out), self.s)
+
+    def lcm_step(self, eps, sample, noise_f32, coef, hw, prev, denoised, dec_in=None):
+        arr = (C.c_float * 6)(*[float(x) for x in coef])
+        self.ctx.call("vsd_lcm_step", self._p(eps), self._p(sample), self._p(noise_f32), arr, hw, self._p(prev),
+                      self._p(denoised), self._p(dec_in), self.s)
+
+    def postprocess_rgb(self, img, ld, hw, rgb_u8):
+        self.ctx.call("vsd_postprocess_rgb", self._p(img), ld, hw, self._p(rgb_u8), self.s)
+
+    def axpy(self, a, b, scale, n, out):
+        self.ctx.call("vsd_axpy", self._p(a), self._p(b), scale, n, self._p(out), self.s)
+
+    # ------------------------------------------------------------------ graphs / profiling
+    def graph_begin(self):
+        self.ctx.call("vsd_graph_begin", self.s)
+
+    def graph_end(self):
+        g = C.c_void_p()
+        self.ctx.call("vsd_graph_end", self.s, C.byref(g))
+        return g
+
+    def graph_launch(self, g):
+        self.ctx.call("vsd_graph_launch", g, self.s)
+
+    def graph_destroy(self, g):
+        self.ctx.call("vsd_graph_destroy", g)
+
+    def profile_begin(self):
+        self.ctx.call("vsd_profile_begin")
+
+    def profile_end(self):
+        self.ctx.call("vsd_profile_end")
+        return self.ctx.stage_times()
