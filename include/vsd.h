@@ -33,7 +33,8 @@ enum vsd_status {
   VSD_ERR_STATE = -4     /* call order (e.g. graph end without begin) */
 };
 
-enum vsd_act { VSD_ACT_NONE = 0, VSD_ACT_RELU = 1, VSD_ACT_SILU = 2, VSD_ACT_GEGLU = 3, VSD_ACT_QUICKGELU = 4 };
+enum vsd_act { VSD_ACT_NONE = 0, VSD_ACT_RELU = 1, VSD_ACT_SILU = 2, VSD_ACT_GEGLU = 3, VSD_ACT_QUICKGELU = 4,
+               VSD_ACT_POST = 256 /* flag: apply the activation AFTER the residual adds (TAESD block) */ };
 
 /* tile shapes of the implicit-GEMM kernel (BM x BN output tile per 256-thread workgroup) */
 enum vsd_tile { VSD_TILE_128x128 = 0, VSD_TILE_128x64 = 1, VSD_TILE_64x64 = 2, VSD_TILE_64x128 = 3 };
@@ -59,7 +60,7 @@ const char* vsd_last_error(vsd_ctx* ctx);
  * ResnetBlock2D, Transformer2DModel, Downsample2D, Upsample2D, Attention and FeedForward under
  * lcm_controlnet.py:558 (ControlNet), :568 (UNet), :299/:594 (TAESD).
  * epilogue: v = acc + bias[n] + rowvec[n]; v = act(v); v *= out_scale; v += residual + residual2;
- *           out = v;  out2 = v + add2 (optional second output).
+ *           [act | VSD_ACT_POST: the activation is applied here instead]  out = v;  out2 = v + add2.
  * act == GEGLU: weights/bias are tile-packed (64 hidden + 64 gate rows per 128-row tile); the output
  * has n/2 columns: out[m][j] = (h_j + b) * gelu_erf(g_j + b).
  * Columns >= t_col0 (when out_t != NULL) are written TRANSPOSED to out_t[(n - t_col0) * ldt + m]
@@ -122,7 +123,7 @@ int vsd_preprocess_rgb(vsd_ctx* ctx, const void* rgb_u8, int h, int w, void* out
 /* Sobel "canny" of the reference (canny_gpu.py:27-44) on device: L conversion, two 3x3 filters,
  * magnitude, division by the global max, thresholds, byte truncation.  Writes the u8 edge map (h*w) and
  * the ControlNet conditioning tensor fp16 [h*w][8] (edge/255 in channels 0..2).
- * workspace: >= 4 * (1 + ceil(h*w/256)) bytes.                                                        */
+ * workspace: >= 256 bytes (holds the global maximum).                                                       */
 int vsd_sobel_control(vsd_ctx* ctx, const void* rgb_u8, int h, int w, float low, float high, void* edge_u8,
                       void* control_out, void* workspace, void* stream);
 

@@ -1,0 +1,183 @@
+"""TEST-ONLY stand-in for videosd_amd.ops.HipOps: the same op interface evaluated with torch on the CPU
+(fp32 math, fp16 storage, exactly the buffer/stride/epilogue semantics of include/vsd.h).
+
+It exists so that the engine's HOST logic (weight packing, buffer wiring, skip/concat bookkeeping,
+schedule constants) can be checked against the oracle in the GPU-less container.  The product never
+imports this module and has no CPU fallback: videosd_amd.ops.HipOps raises without a GPU."""
+import torch
+import torch.nn.functional as F
+
+from videosd_amd import lib as L
+
+
+class FakeOps:
+    name = "fake-cpu"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.tile_override = {}
+
+    def empty(self, *shape, dtype=torch.float16):
+        return torch.zeros(*shape, dtype=dtype)
+
+    def zeros(self, *shape, dtype=torch.float16):
+        return torch.zeros(*shape, dtype=dtype)
+
+    def to_device(self, t):
+        return t.clone()
+
+    def synchronize(self):
+        pass
+
+    def upload(self, dst, src):
+        dst.copy_(src.view(dst.shape))
+
+    def download(self, src):
+        return src.clone()
+
+    @staticmethod
+    def _nhwc(t, h, w, c):
+        """[h*w][>=c] buffer (possibly a strided view) -> NCHW fp32"""
+        return t[:, :c].float().reshape(h, w, c).permute(2, 0, 1)[None]
+
+    def conv(self, src0, src1, g, w, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None, residual2=None,
+             ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0, t_col0=0, tile=None,
+             split_k=None, workspace=None):
+        c0 = c0 if c0 is not None else (w.cin - c1)
+        x = self._nhwc(src0, g.hs, g.ws, c0)
+        if src1 is not None and c1:
+            x = torch.cat([x, self._nhwc(src1, g.hs, g.ws, c1)], dim=1)
+        assert x.shape[1] == w.cin, (x.shape, w.cin)
+        if (g.hi, g.wi) != (g.hs, g.ws):
+            x = F.interpolate(x, size=(g.hi, g.wi), mode="nearest")
+        wt = w.weight[:, :w.k].float()
+        bias = None if w.bias is None else w.bias.float()
+        if w.geglu:
+            n = w.n
+            f = n // 2
+            wt = wt.reshape(f // 64, 2, 64, w.k)
+            wt = torch.cat([wt[:, 0].reshape(f, w.k), wt[:, 1].reshape(f, w.k)], dim=0)
+            bb = bias.reshape(f // 64, 2, 64)
+            bias = torch.cat([bb[:, 0].reshape(f), bb[:, 1].reshape(f)], dim=0)
+        wt = wt.reshape(w.n, w.ksize, w.ksize, w.cin).permute(0, 3, 1, 2)
+        y = F.conv2d(x, wt, bias, stride=g.stride, padding=g.pad)
+        assert y.shape[2:] == (g.ho, g.wo), (y.shape, g)
+        y = y[0].permute(1, 2, 0).reshape(g.m, w.n)
+        if rowvec is not None:
+            y = y + rowvec.float()[None, :]
+        post = bool(act & L.ACT_POST)
+        a = act & 0xFF
+        if w.geglu:
+            hid, gate = y.chunk(2, dim=-1)
+            y = hid * F.gelu(gate)
+            a = L.ACT_NONE
+
+        def fa(v):
+            if a == L.ACT_RELU:
+                return F.relu(v)
+            if a == L.ACT_SILU:
+                return F.silu(v)
+            if a == L.ACT_QUICKGELU:
+                return v * torch.sigmoid(1.702 * v)
+            return v
+
+        if not post:
+            y = fa(y)
+        y = y * out_scale
+        nout = y.shape[1]
+        if out_t is not None:
+            yt = y[:, t_col0:]
+            out_t[: yt.shape[1], : g.m] = yt.t().half()
+            y = y[:, :t_col0]
+            nout = t_col0
+        if residual is not None:
+            y = y + residual[:, :nout].float()
+        if residual2 is not None:
+            y = y + residual2[:, :nout].float()
+        if post:
+            y = fa(y)
+        out[:, :nout] = y.half()
+        if out2 is not None:
+            out2[:, :nout] = (y + add2[:, :nout].float()).half()
+
+    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out):
+        x = src0[:, :c0].float()
+        if src1 is not None and c1:
+            x = torch.cat([x, src1[:, :c1].float()], dim=1)
+        y = F.group_norm(x.t()[None], groups, gamma.float(), beta.float(), eps)[0].t()
+        if silu:
+            y = F.silu(y)
+        out[:, : c0 + c1] = y.half()
+
+    def layernorm(self, x, rows, c, gamma, beta, eps, out):
+        out[:, :c] = F.layer_norm(x[:, :c].float(), (c,), gamma.float(), beta.float(), eps).half()
+
+    def attention(self, q, ldq, k, ldk, vt, ldvt, out, ldo, sq, sk, heads, d, scale, causal=False):
+        c = heads * d
+        qh = q[:sq, :c].float().reshape(sq, heads, d).transpose(0, 1)
+        kh = k[:sk, :c].float().reshape(sk, heads, d).transpose(0, 1)
+        vh = vt[:c, :sk].float().t().reshape(sk, heads, d).transpose(0, 1)
+        assert (vt[:c, sk:] == 0).all(), "V^T key padding must be zero"
+        s = qh @ kh.transpose(-1, -2) * scale
+        if causal:
+            s = s + torch.full((sq, sk), float("-inf")).triu(1)
+        o = (torch.softmax(s, dim=-1) @ vh).transpose(0, 1).reshape(sq, c)
+        out[:sq, :c] = o.half()
+
+    def preprocess_rgb(self, rgb_u8, h, w, out):
+        x = rgb_u8.reshape(h * w, 3).float() / 255.0
+        y = (2.0 * x - 1.0).half()
+        out.zero_()
+        out[:, :3] = ((y.float() + 1.0).half().float() * 0.5).half()
+
+    def sobel_control(self, rgb_u8, h, w, low, high, edge_u8, control_out):
+        p = rgb_u8.reshape(h, w, 3).to(torch.int64)
+        lum = (p[..., 0] * 19595 + p[..., 1] * 38470 + p[..., 2] * 7471 + 0x8000) >> 16
+        x = (lum.float() / 255.0)[None, None]
+        kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]]).view(1, 1, 3, 3)
+        ky = torch.tensor([[-1.0, -2.0, -1.0], [0.0, 0.0, 0.0], [1.0, 2.0, 1.0]]).view(1, 1, 3, 3)
+        e = torch.sqrt(F.conv2d(x, kx, padding=1) ** 2 + F.conv2d(x, ky, padding=1) ** 2)
+        e = e / e.max()
+        e[e >= high] = 1.0
+        e[e <= low] = 0.0
+        u = torch.nan_to_num(e, nan=0.0).mul(255).byte().reshape(-1)
+        edge_u8.copy_(u)
+        control_out.zero_()
+        v = (u.float() / 255.0).half()
+        control_out[:, 0] = v
+        control_out[:, 1] = v
+        control_out[:, 2] = v
+
+    def add_noise(self, x0, noise_f32, sqrt_a, sqrt_b, hw, out):
+        out.zero_()
+        out[:, :4] = (sqrt_a * x0[:, :4].float() + sqrt_b * noise_f32.reshape(4, hw).t()).half()
+
+    def lcm_step(self, eps, sample, noise_f32, coef, hw, prev, denoised, dec_in=None):
+        sa, sb, cskip, cout, sap, sbp = [float(torch.tensor(c, dtype=torch.float32)) for c in coef]
+        xs = sample[:, :4].float()
+        px0 = (xs - sb * eps[:, :4].float()) / sa
+        d = cout * px0 + cskip * xs
+        pv = d if noise_f32 is None else sap * d + sbp * noise_f32.reshape(4, hw).t()
+        if prev is not None:
+            prev.zero_()
+            prev[:, :4] = pv.half()
+        if denoised is not None:
+            denoised.zero_()
+            denoised[:, :4] = d.half()
+        if dec_in is not None:
+            dec_in.zero_()
+            dec_in[:, :4] = (torch.tanh(d.half().float() / 3.0) * 3.0).half()
+
+    def postprocess_rgb(self, img, ld, hw, rgb_u8):
+        y = (img[:, :3].float() * 2.0 - 1.0).half()
+        z = (y.float() * 0.5 + 0.5).half().float().clamp(0, 1)
+        rgb_u8.reshape(hw, 3).copy_((z * 255.0).round().to(torch.uint8))
+
+    def axpy(self, a, b, scale, n, out):
+        out.copy_((a.float() + scale * b.float()).half())
+
+    def graph_begin(self):
+        raise RuntimeError("FakeOps has no graphs")
+
+    def graph_destroy(self, g):
+        pass

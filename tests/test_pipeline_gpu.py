@@ -1,0 +1,118 @@
+"""End-to-end parity on the MI355X: the HIP engine (through the C-ABI) against the CPU oracle on the same
+seeded weights, frame, text embeddings and noise draws.
+
+Tolerances (fp16 storage + fp32 accumulation vs an fp32 oracle):
+  TAESD-encoded latents rel-L2 <= 5e-3; final denoised latent rel-L2 <= 2e-2;
+  output image mean |diff| <= 1.5 LSB and PSNR >= 38 dB."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(h, w, seed=1):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    grad = ((xx * 5 + yy * 3) % 256).astype(np.uint8)[..., None]
+    return (base // 2 + grad // 2).astype(np.uint8)
+
+
+def _psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+def _build(unet_cfg, cn_cfg, dev="cuda"):
+    from videosd_amd import config as C
+    from videosd_amd import weights as W
+
+    wu = W.synthesize(W.unet_spec(unet_cfg), "unet.", device=dev)
+    wc = W.synthesize(W.controlnet_spec(cn_cfg), "cn.", device=dev)
+    wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.", device=dev)
+    text = (torch.randn(77, unet_cfg.cross_dim, generator=torch.Generator().manual_seed(7)) * 0.5).half()
+    return wu, wc, wv, text
+
+
+def _cpu(w):
+    return {k: v.cpu() for k, v in w.items()}
+
+
+def _compare(eng, orc, frame, text, H, W, steps, cn, cn_scale=1.5):
+    got = eng.infer_u8(frame)
+    ref = np.asarray(orc.infer(Image.fromarray(frame, "RGB"), text[None].float(), height=H, width=W, strength=0.6,
+                               steps=steps, seed=23, controlnet_scale=cn_scale, use_controlnet=cn, keep_trace=True))
+    h0, w0 = H // 8, W // 8
+    x0 = eng.buffers["x0"][:, :4].float().cpu().reshape(h0, w0, 4).permute(2, 0, 1)
+    ref_x0 = orc.trace["init_latents"][0]
+    r0 = float((x0 - ref_x0).norm() / ref_x0.norm())
+    den = eng.buffers["denoised"][:, :4].float().cpu().reshape(h0, w0, 4).permute(2, 0, 1)
+    ref_den = orc.trace["denoised"][-1][0]
+    r1 = float((den - ref_den).norm() / ref_den.norm())
+    diff = np.abs(got.astype(int) - ref.astype(int))
+    return r0, r1, float(diff.mean()), _psnr(got, ref), got
+
+
+@pytest.fixture(scope="module")
+def mini_setup():
+    from oracle.pipeline import OraclePipeline
+    from videosd_amd import config as C
+    from videosd_amd.engine import Engine
+    from videosd_amd.ops import HipOps
+
+    wu, wc, wv, text = _build(C.MINI_UNET, C.MINI_CONTROLNET)
+    eng = Engine(HipOps(0), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
+    eng.set_text_embeds(text)
+    orc = OraclePipeline(C.MINI_UNET, C.MINI_CONTROLNET, _cpu(wu), _cpu(wc), _cpu(wv))
+    return eng, orc, text
+
+
+@pytest.mark.parametrize("H,W,steps,cn", [(128, 128, 4, True), (96, 160, 2, True), (128, 128, 1, False),
+                                          (120, 72, 2, True), (256, 256, 4, True)])
+def test_mini_pipeline_matches_oracle(mini_setup, H, W, steps, cn):
+    eng, orc, text = mini_setup
+    eng.prepare(H, W, steps, 0.6, controlnet_scale=1.5, use_controlnet=cn)
+    r0, r1, mad, psnr, _ = _compare(eng, orc, _frame(H, W), text, H, W, steps, cn)
+    assert r0 <= 5e-3 and r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (r0, r1, mad, psnr)
+
+
+def test_graph_replay_is_deterministic_and_equals_eager(mini_setup):
+    eng, orc, text = mini_setup
+    f = _frame(128, 128, seed=3)
+    eng.prepare(128, 128, 4, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=True)
+    a = eng.infer_u8(f)
+    b = eng.infer_u8(f)
+    eng.prepare(128, 128, 4, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
+    c = eng.infer_u8(f)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    # a different frame changes the result; re-running the first frame restores it (no state leaks across frames)
+    d = eng.infer_u8(_frame(128, 128, seed=4))
+    assert not np.array_equal(a, d)
+    assert np.array_equal(a, eng.infer_u8(f))
+
+
+def test_sd15_width_pipeline_matches_oracle():
+    """Full SD1.5 channel widths / head dims (40, 80, 160) and the real ControlNet tower, small frame."""
+    from oracle.pipeline import OraclePipeline
+    from videosd_amd import config as C
+    from videosd_amd.engine import Engine
+    from videosd_amd.ops import HipOps
+
+    wu, wc, wv, text = _build(C.SD15_UNET, C.SD15_CONTROLNET)
+    eng = Engine(HipOps(0), C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
+    eng.set_text_embeds(text)
+    orc = OraclePipeline(C.SD15_UNET, C.SD15_CONTROLNET, _cpu(wu), _cpu(wc), _cpu(wv))
+    H, W, steps = 128, 192, 2
+    eng.prepare(H, W, steps, 0.6, controlnet_scale=1.0, use_controlnet=True)
+    r0, r1, mad, psnr, _ = _compare(eng, orc, _frame(H, W), text, H, W, steps, True, cn_scale=1.0)
+    assert r0 <= 5e-3 and r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (r0, r1, mad, psnr)
+    # full-size property checks at the BASELINE size: finite, deterministic, graph == eager
+    H = W = 512
+    eng.prepare(H, W, 4, 0.6, controlnet_scale=1.0, use_controlnet=True)
+    f = _frame(H, W, seed=9)
+    a = eng.infer_u8(f)
+    assert np.array_equal(a, eng.infer_u8(f))
+    assert torch.isfinite(eng.buffers["denoised"].float()).all()
+    assert a.std() > 1.0

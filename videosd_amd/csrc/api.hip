@@ -51,7 +51,7 @@ extern "C" int vsd_graph_end(vsd_ctx* ctx, void* stream, void** graph_exec_out) 
   VSD_HIP(ctx, hipStreamEndCapture((hipStream_t)stream, &g));
   hipGraphExec_t ge = nullptr;
   hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-  hipGraphDestroy(g);
+  (void)hipGraphDestroy(g);
   if (e != hipSuccess) return vsd_fail(ctx, VSD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
   *graph_exec_out = (void*)ge;
   return VSD_OK;

@@ -74,15 +74,17 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
         if (n + i < p.N) v[i] += (float)p.rowvec[n + i];
     }
   }
-  if (p.act == VSD_ACT_RELU) {
+  const int act = p.act & 0xff;
+  const bool post = (p.act & VSD_ACT_POST) != 0;
+  auto apply_act = [&](float x) -> float {
+    if (act == VSD_ACT_RELU) return fmaxf(x, 0.0f);
+    if (act == VSD_ACT_SILU) return silu_f(x);
+    if (act == VSD_ACT_QUICKGELU) return quick_gelu_f(x);
+    return x;
+  };
+  if (act != VSD_ACT_NONE && !post) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
-  } else if (p.act == VSD_ACT_SILU) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = silu_f(v[i]);
-  } else if (p.act == VSD_ACT_QUICKGELU) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = quick_gelu_f(v[i]);
+    for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i]);
   }
   if (p.out_scale != 1.0f) {
 #pragma unroll
@@ -105,6 +107,10 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += (float)r[i];
     }
+    if (post) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i]);
+    }
     half8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = (half_t)v[i];
@@ -122,6 +128,7 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
       float x = v[i];
       if (p.residual) x += (float)p.residual[(size_t)m * p.ldr + n + i];
       if (p.residual2) x += (float)p.residual2[(size_t)m * p.ldr + n + i];
+      if (post) x = apply_act(x);
       p.out[(size_t)m * p.ldo + n + i] = (half_t)x;
       if (p.out2) p.out2[(size_t)m * p.ldo + n + i] = (half_t)(x + (float)p.add2[(size_t)m * p.ldo + n + i]);
     }
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     return;
   }
 
-  if (p.act == VSD_ACT_GEGLU) {
+  if ((p.act & 0xff) == VSD_ACT_GEGLU) {
     constexpr int CH = BN / 16;  // chunks over the hidden half
     const int no = p.N >> 1;
     for (int q = tid; q < BM * CH; q += 256) {
@@ -457,7 +464,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     case VSD_TILE_64x128: BM = 64; BN = 128; break;
     default: return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: tile %d", d->tile);
   }
-  if (p.act == VSD_ACT_GEGLU) {
+  if ((p.act & 0xff) == VSD_ACT_GEGLU) {
     if (BN != 128 || p.N % 128 || p.split_k != 1 || !p.bias || p.out_t)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: GEGLU needs BN=128, N %% 128 == 0, bias, no split-K");
   }

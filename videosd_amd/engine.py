@@ -1,0 +1,678 @@
+"""Per-frame denoising engine: sequences the libvsd kernels for TAESD-encode -> N x (ControlNet, UNet,
+LCM step) -> TAESD-decode, records the sequence once as a static program, and replays it as ONE hipGraph
+per frame.
+
+Replaces the body of LatentConsistencyModelPipeline_controlnet.__call__
+(/root/reference/diffusert/lcm/lcm_controlnet.py:379-618) and the diffusers modules it drives.  All
+compute goes through an `ops` object (videosd_amd.ops.HipOps -> libvsd.so); this module only decides
+which buffers each kernel reads and writes.
+
+Data layout in HBM
+  * activations: fp16 [H*W][C] (channels-last), bump-allocated from one arena that is rewound at every
+    denoising step so all steps reuse the same addresses;
+  * 4-channel latent-like tensors: row stride 8, channels 4..7 zero;
+  * weights: fp16 [N][Kp], K ordered (ky,kx,c) (videosd_amd/packing.py), resident for the process lifetime;
+  * per-(strength,steps) constants: time-embedding projections of every ResnetBlock for every step, the
+    noise draws, scheduler coefficients; per-prompt constants: cross-attention K and V^T of every layer.
+"""
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .config import ControlNetConfig, TAESDConfig, UNetConfig
+from .lcm import LCMSchedule, timestep_sinusoid, w_embedding
+from .ops import Geom
+from .packing import PackedConv, pack_conv, pack_geglu, pack_linear, pack_linear_cat
+from .weights import skip_channels
+
+
+def _ru(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class Arena:
+    """Bump allocator over large device chunks; `mark`/`rewind` give every denoising step the same addresses."""
+
+    def __init__(self, ops, chunk_bytes: int = 256 << 20):
+        self.ops = ops
+        self.chunk_bytes = chunk_bytes
+        self.chunks: List[torch.Tensor] = []
+        self.ci = 0
+        self.off = 0
+        self.peak = 0
+
+    def alloc(self, rows: int, cols: int, dtype=torch.float16) -> torch.Tensor:
+        esz = torch.empty(0, dtype=dtype).element_size()
+        nbytes = _ru(rows * cols * esz, 256)
+        if nbytes > self.chunk_bytes:
+            raise RuntimeError(f"arena: tensor of {nbytes} bytes exceeds chunk size")
+        if self.ci < len(self.chunks) and self.off + nbytes > self.chunk_bytes:
+            self.ci += 1
+            self.off = 0
+        if self.ci >= len(self.chunks):
+            self.chunks.append(self.ops.empty(self.chunk_bytes, dtype=torch.uint8))
+            self.off = 0
+        t = self.chunks[self.ci][self.off:self.off + rows * cols * esz].view(dtype).view(rows, cols)
+        self.off += nbytes
+        self.peak = max(self.peak, self.ci * self.chunk_bytes + self.off)
+        return t
+
+    def mark(self) -> Tuple[int, int]:
+        return (self.ci, self.off)
+
+    def rewind(self, m: Tuple[int, int]):
+        self.ci, self.off = m
+
+
+class Recorder:
+    """Records op calls as a static program; `run` replays them on the real ops object."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.calls = []
+
+    def __getattr__(self, name):
+        fn = getattr(self.ops, name)
+
+        def rec(*a, **k):
+            self.calls.append((fn, a, k))
+
+        return rec
+
+    def run(self):
+        for fn, a, k in self.calls:
+            fn(*a, **k)
+
+
+# ------------------------------------------------------------------------------------------ packed weights
+@dataclass
+class ResnetW:
+    cin: int
+    cout: int
+    n1: Tuple[torch.Tensor, torch.Tensor]
+    conv1: PackedConv          # bias folded into the time projection
+    n2: Tuple[torch.Tensor, torch.Tensor]
+    conv2: PackedConv
+    shortcut: Optional[PackedConv]
+    temb_off: int              # column offset into the concatenated time-projection output
+
+
+@dataclass
+class TransformerW:
+    c: int
+    norm: Tuple[torch.Tensor, torch.Tensor]
+    proj_in: PackedConv
+    ln1: Tuple[torch.Tensor, torch.Tensor]
+    qkv: PackedConv
+    out1: PackedConv
+    ln2: Tuple[torch.Tensor, torch.Tensor]
+    q2: PackedConv
+    kv2: PackedConv
+    out2: PackedConv
+    ln3: Tuple[torch.Tensor, torch.Tensor]
+    ff1: PackedConv
+    ff2: PackedConv
+    proj_out: PackedConv
+    kv_index: int              # slot in the per-prompt cross-attention K / V^T cache
+
+
+class NetWeights:
+    """Device-resident, kernel-layout weights of one UNet-shaped network (UNet or ControlNet encoder)."""
+
+    def __init__(self, ops, cfg: UNetConfig, w: Dict[str, torch.Tensor], is_controlnet=False,
+                 cn_cfg: Optional[ControlNetConfig] = None):
+        self.ops, self.cfg, self.is_cn = ops, cfg, is_controlnet
+        self._w = w
+        self._temb_w, self._temb_b = [], []
+        self._temb_cols = 0
+        self.transformers: List[TransformerW] = []
+        dev = ops.to_device
+        ch = cfg.block_out_channels
+        self.conv_in = self._conv("conv_in", cin_pad=8)
+        self.time_l1 = self._lin("time_embedding.linear_1")
+        self.time_l2 = self._lin("time_embedding.linear_2")
+        self.cond_proj = self._lin("time_embedding.cond_proj") if cfg.cond_proj_dim else None
+        self.down: List[List[Tuple[ResnetW, Optional[TransformerW]]]] = []
+        self.downsamplers: List[Optional[PackedConv]] = []
+        cin = ch[0]
+        for i, cout in enumerate(ch):
+            blk = []
+            for j in range(cfg.layers_per_block):
+                r = self._resnet(f"down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+                t = self._transformer(f"down_blocks.{i}.attentions.{j}", cout) if cfg.down_attn[i] else None
+                blk.append((r, t))
+            self.down.append(blk)
+            self.downsamplers.append(self._conv(f"down_blocks.{i}.downsamplers.0.conv") if i < len(ch) - 1 else None)
+            cin = cout
+        self.mid = (self._resnet("mid_block.resnets.0", ch[-1], ch[-1]),
+                    self._transformer("mid_block.attentions.0", ch[-1]),
+                    self._resnet("mid_block.resnets.1", ch[-1], ch[-1]))
+        if not is_controlnet:
+            skips = skip_channels(cfg)
+            rev = list(reversed(ch))
+            self.up: List[List[Tuple[ResnetW, Optional[TransformerW]]]] = []
+            self.upsamplers: List[Optional[PackedConv]] = []
+            prev = ch[-1]
+            for i, cout in enumerate(rev):
+                blk = []
+                for j in range(cfg.layers_per_block + 1):
+                    sc = skips.pop()
+                    r = self._resnet(f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else cout) + sc, cout)
+                    t = self._transformer(f"up_blocks.{i}.attentions.{j}", cout) if cfg.up_attn[i] else None
+                    blk.append((r, t))
+                self.up.append(blk)
+                self.upsamplers.append(self._conv(f"up_blocks.{i}.upsamplers.0.conv") if i < len(rev) - 1 else None)
+                prev = cout
+            self.norm_out = self._norm("conv_norm_out")
+            self.conv_out = self._conv("conv_out")
+        else:
+            cc = cn_cfg.cond_channels
+            p = "controlnet_cond_embedding"
+            self.cond_convs = [(self._conv(f"{p}.conv_in", cin_pad=8), 1)]
+            k = 0
+            for i in range(len(cc) - 1):
+                self.cond_convs.append((self._conv(f"{p}.blocks.{k}"), 1))
+                self.cond_convs.append((self._conv(f"{p}.blocks.{k + 1}"), 2))
+                k += 2
+            self.cond_out = self._conv(f"{p}.conv_out")
+            self.zero_convs = [self._conv(f"controlnet_down_blocks.{i}") for i in range(len(skip_channels(cfg)))]
+            self.zero_mid = self._conv("controlnet_mid_block")
+        # all per-ResnetBlock time projections as ONE linear layer: [sum Cout][temb_dim]
+        tw = pack_linear_cat(self._temb_w, self._temb_b)
+        self.temb_proj = self._to_dev(tw)
+        self._w = None
+        self._temb_w = self._temb_b = None
+
+    # --- helpers
+    def _to_dev(self, p: PackedConv) -> PackedConv:
+        p.weight = self.ops.to_device(p.weight)
+        if p.bias is not None:
+            p.bias = self.ops.to_device(p.bias)
+        return p
+
+    def _conv(self, name, cin_pad=None, with_bias=True) -> PackedConv:
+        b = self._w.get(name + ".bias") if with_bias else None
+        return self._to_dev(pack_conv(self._w[name + ".weight"], b, cin_pad=cin_pad))
+
+    def _lin(self, name) -> PackedConv:
+        return self._to_dev(pack_linear(self._w[name + ".weight"], self._w.get(name + ".bias")))
+
+    def _norm(self, name):
+        return (self.ops.to_device(self._w[name + ".weight"].half().contiguous()),
+                self.ops.to_device(self._w[name + ".bias"].half().contiguous()))
+
+    def _resnet(self, p, cin, cout) -> ResnetW:
+        off = self._temb_cols
+        self._temb_w.append(self._w[p + ".time_emb_proj.weight"])
+        # conv1's bias is folded into the time projection's bias: both are per-channel constants added
+        # to conv1's output before norm2 (ResnetBlock2D.forward).
+        self._temb_b.append((self._w[p + ".time_emb_proj.bias"].float() + self._w[p + ".conv1.bias"].float()))
+        self._temb_cols += cout
+        sc = self._conv(p + ".conv_shortcut") if (p + ".conv_shortcut.weight") in self._w else None
+        return ResnetW(cin, cout, self._norm(p + ".norm1"), self._conv(p + ".conv1", with_bias=False),
+                       self._norm(p + ".norm2"), self._conv(p + ".conv2"), sc, off)
+
+    def _transformer(self, p, c) -> TransformerW:
+        w = self._w
+        b = p + ".transformer_blocks.0"
+        qkv = self._to_dev(pack_linear_cat([w[f"{b}.attn1.to_q.weight"], w[f"{b}.attn1.to_k.weight"],
+                                            w[f"{b}.attn1.to_v.weight"]]))
+        kv2 = self._to_dev(pack_linear_cat([w[f"{b}.attn2.to_k.weight"], w[f"{b}.attn2.to_v.weight"]]))
+        t = TransformerW(c, self._norm(p + ".norm"), self._conv(p + ".proj_in"), self._norm(b + ".norm1"), qkv,
+                         self._lin(b + ".attn1.to_out.0"), self._norm(b + ".norm2"), self._lin(b + ".attn2.to_q"), kv2,
+                         self._lin(b + ".attn2.to_out.0"), self._norm(b + ".norm3"),
+                         self._to_dev(pack_geglu(w[f"{b}.ff.net.0.proj.weight"], w[f"{b}.ff.net.0.proj.bias"])),
+                         self._lin(b + ".ff.net.2"), self._conv(p + ".proj_out"), len(self.transformers))
+        self.transformers.append(t)
+        return t
+
+
+class TAESDWeights:
+    def __init__(self, ops, w: Dict[str, torch.Tensor]):
+        self.ops = ops
+
+        def cv(name, cin_pad=None):
+            p = pack_conv(w[name + ".weight"], w.get(name + ".bias"), cin_pad=cin_pad)
+            p.weight = ops.to_device(p.weight)
+            if p.bias is not None:
+                p.bias = ops.to_device(p.bias)
+            return p
+
+        def blk(p):
+            return [cv(f"{p}.conv.{k}") for k in (0, 2, 4)]
+
+        e = "encoder.layers"
+        self.enc_in = cv(f"{e}.0", cin_pad=8)
+        self.enc_blocks0 = [blk(f"{e}.1")]
+        self.enc_stages = []
+        n = 2
+        for _ in range(3):
+            down = cv(f"{e}.{n}")
+            n += 1
+            bs = []
+            for _ in range(3):
+                bs.append(blk(f"{e}.{n}"))
+                n += 1
+            self.enc_stages.append((down, bs))
+        self.enc_out = cv(f"{e}.{n}")
+        d = "decoder.layers"
+        self.dec_in = cv(f"{d}.0", cin_pad=8)
+        self.dec_stages = []
+        n = 2
+        for nb in (3, 3, 3):
+            bs = []
+            for _ in range(nb):
+                bs.append(blk(f"{d}.{n}"))
+                n += 1
+            n += 1
+            up = cv(f"{d}.{n}")
+            n += 1
+            self.dec_stages.append((bs, up))
+        self.dec_last_block = blk(f"{d}.{n}")
+        n += 1
+        self.dec_out = cv(f"{d}.{n}")
+
+
+# ------------------------------------------------------------------------------------------ the engine
+class Engine:
+    """One engine = one GPU, one weight replica (reference: one Ray actor, videopipeline.py:11-32)."""
+
+    def __init__(self, ops, unet_cfg: UNetConfig, cn_cfg: ControlNetConfig, vae_cfg: TAESDConfig,
+                 w_unet: Dict[str, torch.Tensor], w_cn: Optional[Dict[str, torch.Tensor]], w_vae: Dict[str, torch.Tensor],
+                 guidance_scale: float = 7.5):
+        self.ops = ops
+        self.ucfg, self.ccfg, self.vcfg = unet_cfg, cn_cfg, vae_cfg
+        self.unet = NetWeights(ops, unet_cfg, w_unet)
+        self.cn = NetWeights(ops, cn_cfg.unet, w_cn, True, cn_cfg) if w_cn is not None else None
+        self.vae = TAESDWeights(ops, w_vae)
+        self.guidance_scale = guidance_scale  # never forwarded by the reference (videopipeline.py:114-124): 7.5
+        self.text = None
+        self.plan = None
+        self.graph = None
+        self.use_graph = True
+
+    # ---------------------------------------------------------------- prompt-dependent constants
+    def set_text_embeds(self, embeds: torch.Tensor):
+        """embeds: [77, cross_dim] (or [1,77,cross_dim]) -> cross-attention K and V^T of every layer.
+        Replaces the to_k / to_v projections diffusers recomputes every step (attn2 of each block)."""
+        ops = self.ops
+        e = embeds.reshape(-1, embeds.shape[-1]).to(torch.float16).contiguous()
+        self.text = ops.to_device(e)
+        tl = self.text.shape[0]
+        ldt = _ru(tl, 64)
+        for net in [self.unet] + ([self.cn] if self.cn else []):
+            first = not hasattr(net, "kv_cache")
+            if first:
+                net.kv_cache = []
+            for i, t in enumerate(net.transformers):
+                if first:
+                    net.kv_cache.append((ops.zeros(tl, t.c), ops.zeros(t.c, ldt)))
+                k, vt = net.kv_cache[i]
+                ops.conv(self.text, None, Geom.linear(tl), t.kv2, k, ldo=t.c, out_t=vt, ldt=ldt, t_col0=t.c)
+        ops.synchronize()
+
+    # ---------------------------------------------------------------- schedule-dependent constants
+    def _time_embeddings(self, net: NetWeights, sched: LCMSchedule, out: torch.Tensor):
+        """out[i] = concat over ResnetBlocks of time_emb_proj(SiLU(time_embedding(t_i))) + conv1.bias.
+        Replaces Timesteps/TimestepEmbedding + every ResnetBlock2D.time_emb_proj (K9 in SURVEY.md)."""
+        ops, cfg = self.ops, net.cfg
+        n = len(sched)
+        c0 = cfg.block_out_channels[0]
+        t_emb = ops.to_device(timestep_sinusoid(sched.timesteps, c0).half())
+        x = t_emb
+        if net.cond_proj is not None:
+            wemb = ops.to_device(w_embedding(self.guidance_scale, cfg.cond_proj_dim).half().expand(n, -1).contiguous())
+            x = ops.empty(n, c0)
+            ops.conv(wemb, None, Geom.linear(n), net.cond_proj, x, residual=t_emb)
+        h1 = ops.empty(n, cfg.temb_dim)
+        ops.conv(x, None, Geom.linear(n), net.time_l1, h1, act=L.ACT_SILU)
+        h2 = ops.empty(n, cfg.temb_dim)
+        ops.conv(h1, None, Geom.linear(n), net.time_l2, h2, act=L.ACT_SILU)  # SiLU(temb): all consumers apply it
+        ops.conv(h2, None, Geom.linear(n), net.temb_proj, out[:n])
+        ops.synchronize()
+
+    # ---------------------------------------------------------------- network builders (record ops)
+    def _resnet(self, r, rw: ResnetW, net, step, x, x2, c0, c1, hw, geom, out=None, out2=None, add2=None, residual2=None):
+        """x (and optional concat partner x2) -> ResnetBlock2D output [hw][cout]."""
+        a, cfg = self.arena, net.cfg
+        cin = c0 + c1
+        t1 = a.alloc(hw, cin)
+        r.groupnorm(x, x2, c0, c1, hw, cfg.groups, 1e-5, rw.n1[0], rw.n1[1], True, t1)
+        h = a.alloc(hw, rw.cout)
+        tv = net.temb_all[step, rw.temb_off:rw.temb_off + rw.cout]
+        r.conv(t1, None, geom, rw.conv1, h, rowvec=tv)
+        t2 = a.alloc(hw, rw.cout)
+        r.groupnorm(h, None, rw.cout, 0, hw, cfg.groups, 1e-5, rw.n2[0], rw.n2[1], True, t2)
+        if rw.shortcut is not None:
+            sc = a.alloc(hw, rw.cout)
+            r.conv(x, x2, Geom.linear(hw), rw.shortcut, sc, c0=c0, c1=c1)
+        else:
+            sc = x
+        out = out if out is not None else a.alloc(hw, rw.cout)
+        r.conv(t2, None, geom, rw.conv2, out, residual=sc, residual2=residual2, out2=out2, add2=add2)
+        return out
+
+    def _transformer(self, r, tw: TransformerW, net, x, hw, out2=None, add2=None):
+        a, cfg = self.arena, net.cfg
+        c, heads = tw.c, cfg.heads
+        d = c // heads
+        lin = Geom.linear(hw)
+        t = a.alloc(hw, c)
+        r.groupnorm(x, None, c, 0, hw, cfg.groups, 1e-6, tw.norm[0], tw.norm[1], False, t)
+        h = a.alloc(hw, c)
+        r.conv(t, None, lin, tw.proj_in, h)
+        # self-attention
+        n = a.alloc(hw, c)
+        r.layernorm(h, hw, c, tw.ln1[0], tw.ln1[1], 1e-5, n)
+        qk = a.alloc(hw, 2 * c)
+        ldvt = _ru(hw, 64)
+        vt = self._vt_buffer(c, ldvt)
+        r.conv(n, None, lin, tw.qkv, qk, ldo=2 * c, out_t=vt, ldt=ldvt, t_col0=2 * c)
+        att = a.alloc(hw, c)
+        r.attention(qk, 2 * c, qk[:, c:], 2 * c, vt, ldvt, att, c, hw, hw, heads, d, d ** -0.5)
+        h1 = a.alloc(hw, c)
+        r.conv(att, None, lin, tw.out1, h1, residual=h)
+        # cross-attention over the cached text K / V^T
+        r.layernorm(h1, hw, c, tw.ln2[0], tw.ln2[1], 1e-5, n)
+        q = a.alloc(hw, c)
+        r.conv(n, None, lin, tw.q2, q)
+        kt, vtt = net.kv_cache[tw.kv_index]
+        r.attention(q, c, kt, c, vtt, vtt.shape[1], att, c, hw, kt.shape[0], heads, d, d ** -0.5)
+        h2 = a.alloc(hw, c)
+        r.conv(att, None, lin, tw.out2, h2, residual=h1)
+        # GEGLU feed-forward
+        r.layernorm(h2, hw, c, tw.ln3[0], tw.ln3[1], 1e-5, n)
+        f = a.alloc(hw, 4 * c)
+        r.conv(n, None, lin, tw.ff1, f)
+        h3 = a.alloc(hw, c)
+        r.conv(f, None, lin, tw.ff2, h3, residual=h2)
+        out = a.alloc(hw, c)
+        r.conv(h3, None, lin, tw.proj_out, out, residual=x, out2=out2, add2=add2)
+        return out
+
+    def _vt_buffer(self, c, ldvt):
+        # V^T buffers live outside the rewound arena: their key-padding columns must stay zero forever
+        key = (c, ldvt, self._vt_count)
+        self._vt_count += 1
+        buf = self._vt_pool.get(key)
+        if buf is None:
+            buf = self.ops.zeros(c, ldvt)
+            self._vt_pool[key] = buf
+        return buf
+
+    def _down_mid(self, r, net: NetWeights, step, h, sizes, cn_res=None, cn_mid=None):
+        """conv_in output h -> (mid output, skip list).  With cn_res (UNet + ControlNet) every skip is
+        produced together with skip + residual through the producing conv's second output."""
+        a = self.arena
+        ch = net.cfg.block_out_channels
+        skips = []
+        k = 1  # skip 0 is conv_in's output (handled by the caller)
+        for i, c in enumerate(ch):
+            hh, ww = sizes[i]
+            hw = hh * ww
+            g3 = Geom.conv(hh, ww)
+            for j, (rw, tw) in enumerate(net.down[i]):
+                cin = rw.cin
+                want2 = cn_res is not None
+                if tw is None:
+                    o2 = a.alloc(hw, c) if want2 else None
+                    h = self._resnet(r, rw, net, step, h, None, cin, 0, hw, g3, out2=o2, add2=cn_res[k] if want2 else None)
+                else:
+                    h = self._resnet(r, rw, net, step, h, None, cin, 0, hw, g3)
+                    o2 = a.alloc(hw, c) if want2 else None
+                    h = self._transformer(r, tw, net, h, hw, out2=o2, add2=cn_res[k] if want2 else None)
+                skips.append((o2 if want2 else h, c, i))
+                k += 1
+            ds = net.downsamplers[i]
+            if ds is not None:
+                h2, w2 = sizes[i + 1]
+                o = a.alloc(h2 * w2, c)
+                o2 = a.alloc(h2 * w2, c) if cn_res is not None else None
+                r.conv(h, None, Geom.conv(hh, ww, stride=2), ds, o, out2=o2, add2=cn_res[k] if cn_res is not None else None)
+                h = o
+                skips.append((o2 if cn_res is not None else o, c, i + 1))
+                k += 1
+        hh, ww = sizes[-1]
+        hw = hh * ww
+        g3 = Geom.conv(hh, ww)
+        c = ch[-1]
+        h = self._resnet(r, net.mid[0], net, step, h, None, c, 0, hw, g3)
+        h = self._transformer(r, net.mid[1], net, h, hw)
+        h = self._resnet(r, net.mid[2], net, step, h, None, c, 0, hw, g3, residual2=cn_mid)
+        return h, skips
+
+    def _unet(self, r, step, lat, sizes, cn_res, cn_mid, eps_out):
+        a, net = self.arena, self.unet
+        ch = net.cfg.block_out_channels
+        h0, w0 = sizes[0]
+        hw0 = h0 * w0
+        x = a.alloc(hw0, ch[0])
+        x2 = a.alloc(hw0, ch[0]) if cn_res is not None else None
+        r.conv(lat, None, Geom.conv(h0, w0), net.conv_in, x, out2=x2, add2=cn_res[0] if cn_res is not None else None)
+        h, skips = self._down_mid(r, net, step, x, sizes, cn_res, cn_mid)
+        skips = [(x2 if cn_res is not None else x, ch[0], 0)] + skips
+        nlev = len(ch)
+        cprev = ch[-1]
+        for i in range(nlev):
+            lvl = nlev - 1 - i
+            hh, ww = sizes[lvl]
+            hw = hh * ww
+            g3 = Geom.conv(hh, ww)
+            for j, (rw, tw) in enumerate(net.up[i]):
+                s, sc, slvl = skips.pop()
+                assert slvl == lvl and rw.cin == cprev + sc, (slvl, lvl, rw.cin, cprev, sc)
+                h = self._resnet(r, rw, net, step, h, s, cprev, sc, hw, g3)
+                cprev = rw.cout
+                if tw is not None:
+                    h = self._transformer(r, tw, net, h, hw)
+            up = net.upsamplers[i]
+            if up is not None:
+                h2, w2 = sizes[lvl - 1]
+                o = a.alloc(h2 * w2, cprev)
+                # nearest resize to the next skip's size folded into the conv's gather (Upsample2D)
+                r.conv(h, None, Geom.conv(hh, ww, up_to=(h2, w2)), up, o)
+                h = o
+        t = a.alloc(hw0, ch[0])
+        r.groupnorm(h, None, ch[0], 0, hw0, net.cfg.groups, 1e-5, net.norm_out[0], net.norm_out[1], True, t)
+        r.conv(t, None, Geom.conv(h0, w0), net.conv_out, eps_out, ldo=8)
+
+    def _controlnet(self, r, step, lat, sizes, cond_emb, scale):
+        a, net = self.arena, self.cn
+        ch = net.cfg.block_out_channels
+        h0, w0 = sizes[0]
+        hw0 = h0 * w0
+        x = a.alloc(hw0, ch[0])
+        r.conv(lat, None, Geom.conv(h0, w0), net.conv_in, x, residual=cond_emb)
+        h, skips = self._down_mid(r, net, step, x, sizes)
+        skips = [(x, ch[0], 0)] + skips
+        nres = len(skips) + 1
+        scales = torch.logspace(-1, 0, nres) * scale  # guess_mode (always on in the reference, lcm_controlnet.py:399,447)
+        res = []
+        for i, (s, c, lvl) in enumerate(skips):
+            hh, ww = sizes[lvl]
+            o = a.alloc(hh * ww, c)
+            r.conv(s, None, Geom.linear(hh * ww), net.zero_convs[i], o, out_scale=float(scales[i]))
+            res.append(o)
+        hh, ww = sizes[-1]
+        mid = a.alloc(hh * ww, ch[-1])
+        r.conv(h, None, Geom.linear(hh * ww), net.zero_mid, mid, out_scale=float(scales[-1]))
+        return res, mid
+
+    def _cond_embedding(self, r, ctrl, H, W):
+        a, net = self.arena, self.cn
+        h, hh, ww = ctrl, H, W
+        for pw, stride in net.cond_convs:
+            g = Geom.conv(hh, ww, stride=stride)
+            o = a.alloc(g.m, pw.n)
+            r.conv(h, None, g, pw, o, act=L.ACT_SILU)
+            h, hh, ww = o, g.ho, g.wo
+        o = a.alloc(hh * ww, net.cond_out.n)
+        r.conv(h, None, Geom.conv(hh, ww), net.cond_out, o)
+        return o
+
+    def _taesd_block(self, r, blk, x, hh, ww):
+        a = self.arena
+        g = Geom.conv(hh, ww)
+        c = blk[0].n
+        t1 = a.alloc(g.m, c)
+        r.conv(x, None, g, blk[0], t1, act=L.ACT_RELU)
+        t2 = a.alloc(g.m, c)
+        r.conv(t1, None, g, blk[1], t2, act=L.ACT_RELU)
+        o = a.alloc(g.m, c)
+        r.conv(t2, None, g, blk[2], o, residual=x, act=L.ACT_RELU | L.ACT_POST)
+        return o
+
+    def _encode(self, r, img8, H, W, out):
+        a, v = self.arena, self.vae
+        c = v.enc_in.n
+        h = a.alloc(H * W, c)
+        r.conv(img8, None, Geom.conv(H, W), v.enc_in, h)
+        for b in v.enc_blocks0:
+            h = self._taesd_block(r, b, h, H, W)
+        hh, ww = H, W
+        for down, bs in v.enc_stages:
+            g = Geom.conv(hh, ww, stride=2)
+            o = a.alloc(g.m, c)
+            r.conv(h, None, g, down, o)
+            h, hh, ww = o, g.ho, g.wo
+            for b in bs:
+                h = self._taesd_block(r, b, h, hh, ww)
+        r.conv(h, None, Geom.conv(hh, ww), v.enc_out, out, ldo=8)
+
+    def _decode(self, r, z8, hh, ww, out):
+        a, v = self.arena, self.vae
+        c = v.dec_in.n
+        h = a.alloc(hh * ww, c)
+        r.conv(z8, None, Geom.conv(hh, ww), v.dec_in, h, act=L.ACT_RELU)
+        for bs, up in v.dec_stages:
+            for b in bs:
+                h = self._taesd_block(r, b, h, hh, ww)
+            g = Geom.conv(hh, ww, up_to=(2 * hh, 2 * ww))  # nn.Upsample(scale_factor=2) folded into the conv
+            o = a.alloc(g.m, c)
+            r.conv(h, None, g, up, o)
+            h, hh, ww = o, g.ho, g.wo
+        h = self._taesd_block(r, v.dec_last_block, h, hh, ww)
+        r.conv(h, None, Geom.conv(hh, ww), v.dec_out, out, ldo=8)
+
+    # ---------------------------------------------------------------- prepare: build + capture
+    def prepare(self, H: int, W: int, steps: int, strength: float, controlnet_scale: float = 1.0,
+                use_controlnet: bool = True, use_graph: Optional[bool] = None):
+        """Fix the frame geometry and schedule; build the static program and capture it into a hipGraph
+        (the reference's intent at videopipeline.py:35-47, `compile_model`)."""
+        if H % 8 or W % 8:
+            raise ValueError("height and width must be multiples of 8 (TAESD / latent stride)")
+        if self.text is None:
+            raise RuntimeError("set_text_embeds must be called before prepare")
+        if use_controlnet and self.cn is None:
+            raise RuntimeError("no ControlNet weights loaded")
+        if use_graph is not None:
+            self.use_graph = use_graph
+        ops = self.ops
+        sched = LCMSchedule(strength, steps)
+        n = len(sched)
+        h0, w0 = H // 8, W // 8
+        sizes = [(h0, w0)]
+        for _ in range(len(self.ucfg.block_out_channels) - 1):
+            ph, pw_ = sizes[-1]
+            sizes.append(((ph + 1) // 2, (pw_ + 1) // 2))
+        hw0 = h0 * w0
+        if self.graph is not None:
+            ops.graph_destroy(self.graph)
+            self.graph = None
+        self.arena = Arena(ops)
+        self._vt_pool, self._vt_count = getattr(self, "_vt_pool", {}), 0
+        # persistent per-frame I/O and constants
+        self.frame_u8 = ops.zeros(H, W, 3, dtype=torch.uint8)
+        self.out_u8 = ops.zeros(H, W, 3, dtype=torch.uint8)
+        self.edge_u8 = ops.zeros(H * W, dtype=torch.uint8)
+        for net in [self.unet] + ([self.cn] if use_controlnet else []):
+            net.temb_all = ops.zeros(n, net.temb_proj.n)
+            self._time_embeddings(net, sched, net.temb_all)
+        # noise draws: the reference resets the global CPU generator to a fresh-Generator state on every
+        # frame (videopipeline.py:126), so for a fixed shape the draws are the same every frame.
+        self.noise = ops.to_device(self.host_noise(n, h0, w0))
+        a = self.arena
+        enc_in = a.alloc(H * W, 8)
+        x0 = a.alloc(hw0, 8)
+        lat = [a.alloc(hw0, 8), a.alloc(hw0, 8)]
+        eps = a.alloc(hw0, 8)
+        den = a.alloc(hw0, 8)
+        dec_in = a.alloc(hw0, 8)
+        dec_out = a.alloc(H * W, 8)
+        for t in (x0, lat[0], lat[1], eps, den, dec_in):
+            t.zero_()
+        self.buffers = {"x0": x0, "lat": lat, "eps": eps, "denoised": den, "dec_in": dec_in, "dec_out": dec_out}
+        r = Recorder(ops)
+        r.preprocess_rgb(self.frame_u8, H, W, enc_in)
+        cond_emb = None
+        if use_controlnet:
+            ctrl = a.alloc(H * W, 8)
+            r.sobel_control(self.frame_u8, H, W, 0.11, 0.8, self.edge_u8, ctrl)  # videopipeline.py:109
+            cond_emb = self._cond_embedding(r, ctrl, H, W)
+        self._encode(r, enc_in, H, W, x0)
+        sa, sb = sched.add_noise_coef()
+        r.add_noise(x0, self.noise[0], sa, sb, hw0, lat[0])
+        mark = a.mark()
+        for i in range(n):
+            a.rewind(mark)
+            self._vt_count = 0
+            cur, nxt = lat[i & 1], lat[(i + 1) & 1]
+            cn_res = cn_mid = None
+            if use_controlnet:
+                cn_res, cn_mid = self._controlnet(r, i, cur, sizes, cond_emb, controlnet_scale)
+            self._unet(r, i, cur, sizes, cn_res, cn_mid, eps)
+            nz = self.noise[i + 1] if sched.multistep else None
+            last = i == n - 1
+            r.lcm_step(eps, cur, nz, sched.step_coef(i), hw0, nxt, den, dec_in if last else None)
+        self._decode(r, dec_in, h0, w0, dec_out)
+        r.postprocess_rgb(dec_out, 8, H * W, self.out_u8)
+        self.program = r
+        self.plan = dict(H=H, W=W, steps=steps, strength=strength, cn_scale=controlnet_scale, cn=use_controlnet, n=n,
+                         sizes=sizes, timesteps=sched.timesteps, n_ops=len(r.calls), arena_bytes=a.peak)
+        # warm-up (eager), then capture
+        r.run()
+        ops.synchronize()
+        if self.use_graph:
+            ops.graph_begin()
+            r.run()
+            self.graph = ops.graph_end()
+        return self.plan
+
+    @staticmethod
+    def host_noise(n_steps: int, h: int, w: int) -> torch.Tensor:
+        """The CPU draws of one frame, in the reference's order: draw 0 = prepare_latents noise
+        (lcm_controlnet.py:331, generator not forwarded), then one torch.randn per scheduler step
+        (:1033) when the schedule has more than one step.  fp32 [(n+1), 4, h*w]."""
+        st = torch.get_rng_state()
+        try:
+            torch.manual_seed(0)
+            torch.default_generator.set_state(torch.Generator(device="cpu").get_state())
+            draws = [torch.randn(1, 4, h, w)]
+            if n_steps > 1:
+                for _ in range(n_steps):
+                    draws.append(torch.randn(1, 4, h, w))
+            else:
+                draws.append(torch.zeros(1, 4, h, w))
+        finally:
+            torch.set_rng_state(st)
+        return torch.cat(draws, dim=0).reshape(len(draws), 4, h * w).contiguous()
+
+    # ---------------------------------------------------------------- per frame
+    def launch(self):
+        """Enqueue one frame's work (frame_u8 -> out_u8) on the ops stream."""
+        if self.graph is not None:
+            self.ops.graph_launch(self.graph)
+        else:
+            self.program.run()
+
+    def infer_u8(self, frame: np.ndarray) -> np.ndarray:
+        """frame: uint8 [H][W][3] already cropped/resized by the caller -> uint8 [H][W][3]."""
+        p = self.plan
+        if frame.shape != (p["H"], p["W"], 3) or frame.dtype != np.uint8:
+            raise ValueError(f"frame must be uint8 {(p['H'], p['W'], 3)}, got {frame.dtype} {frame.shape}")
+        self.ops.upload(self.frame_u8, torch.from_numpy(np.ascontiguousarray(frame)))
+        self.launch()
+        return self.ops.download(self.out_u8).numpy()

@@ -80,6 +80,9 @@ class HipOps:
         torch.cuda.set_device(self.device)
         self.ctx = L.Context(device_id)
         self.stream = stream or torch.cuda.Stream(device=self.device)
+        # torch-side plumbing (allocation fills, H2D/D2H copies) must be ordered with the kernels: make the
+        # kernel stream this thread's current torch stream.
+        torch.cuda.set_stream(self.stream)
         self._ws = {}
         self.tile_override = {}
 
@@ -110,6 +113,15 @@ class HipOps:
 
     def synchronize(self):
         self.stream.synchronize()
+
+    def upload(self, dst: torch.Tensor, src_cpu: torch.Tensor):
+        with torch.cuda.stream(self.stream):
+            dst.copy_(src_cpu.view(dst.shape), non_blocking=True)
+
+    def download(self, src: torch.Tensor) -> torch.Tensor:
+        with torch.cuda.stream(self.stream):
+            out = src.to("cpu", non_blocking=False)
+        return out
 
     # ------------------------------------------------------------------ ops
     def conv(self, src0, src1, g: Geom, w: PackedConv, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None,
