@@ -91,7 +91,12 @@ typedef struct vsd_conv_desc {
   int32_t tile;           /* vsd_tile */
   int32_t split_k;        /* >= 1; > 1 needs workspace of split_k * M * n floats */
   void* workspace;
+  void* counters;         /* optional: VSD_SPLITK_MAX_TILES int32, all zero.  When given, a split-K launch reduces
+                             inside the kernel (the last workgroup to arrive at a tile sums the slabs in a fixed
+                             order and runs the epilogue, leaving its counter at zero); when NULL a second
+                             kernel (splitk_reduce) does it.  Results are bit-identical either way. */
 } vsd_conv_desc;
+#define VSD_SPLITK_MAX_TILES 16384
 
 int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream);
 

@@ -1,0 +1,54 @@
+"""Attribute rocprofv3 kernel-trace durations of the LAST eager frame to the engine's ops.
+usage: analyze_trace.py <kernel_trace.csv> <ops.json>"""
+import collections, csv, json, sys
+
+trace, opsf = sys.argv[1], sys.argv[2]
+ops = json.load(open(opsf))
+ours = ("conv_gemm_kernel", "splitk_reduce", "gn_stats", "gn_apply", "layernorm_kernel", "attention_kernel",
+        "preprocess_rgb", "sobel_max", "sobel_apply", "add_noise", "lcm_step", "postprocess")
+rows = [r for r in csv.DictReader(open(trace)) if any(o in r["Kernel_Name"] for o in ours)]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+expect = []
+for i, m in enumerate(ops):
+    # split > 1: two-kernel reduction; split < -1: in-kernel reduction (one launch)
+    n = {"conv": 1 + (1 if m.get("split", 1) > 1 else 0), "groupnorm": 2, "sobel_control": 2}.get(m["op"], 1)
+    expect.append(n)
+total = sum(expect)
+last = rows[-total:]
+assert "preprocess" in last[0]["Kernel_Name"], last[0]["Kernel_Name"][:80]
+pos = 0
+agg = collections.OrderedDict()
+frame_ns = int(last[-1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])
+busy = 0
+for m, n in zip(ops, expect):
+    ks = last[pos:pos + n]
+    pos += n
+    dur = [int(k["End_Timestamp"]) - int(k["Start_Timestamp"]) for k in ks]
+    busy += sum(dur)
+    if m["op"] == "conv":
+        key = ("conv", m["M"], m["N"], m["K"], m["ks"], m["tile"], m["split"])
+        assert "conv_gemm" in ks[0]["Kernel_Name"]
+    elif m["op"] == "groupnorm":
+        key = ("gn", m["hw"], m["C"])
+    elif m["op"] == "layernorm":
+        key = ("ln", m["rows"], m["C"])
+    elif m["op"] == "attention":
+        key = ("attn", m["sq"], m["sk"], m["d"])
+    else:
+        key = (m["op"],)
+    a = agg.setdefault(key, dict(count=0, ns=0, ns2=0, flops=0.0, wbytes=0))
+    a["count"] += 1
+    a["ns"] += dur[0]
+    a["ns2"] += sum(dur[1:])
+    a["flops"] += m.get("flops", 0.0)
+    a["wbytes"] += m.get("wbytes", 0)
+print(f"frame span {frame_ns/1e6:.2f} ms, kernel busy {busy/1e6:.2f} ms, {total} kernels")
+fam = collections.Counter()
+for k, a in agg.items():
+    fam[k[0]] += a["ns"] + a["ns2"]
+print({k: round(v / 1e6, 2) for k, v in fam.items()})
+print(f"{'op':48s} {'cnt':>4s} {'tot ms':>8s} {'avg us':>8s} {'2nd us':>7s} {'TF/s':>7s} {'wGB/s':>7s}")
+for k, a in sorted(agg.items(), key=lambda kv: -(kv[1]["ns"] + kv[1]["ns2"])):
+    t = a["ns"]
+    print(f"{str(k):48s} {a['count']:4d} {(t + a['ns2'])/1e6:8.3f} {t/a['count']/1e3:8.1f} {a['ns2']/a['count']/1e3:7.1f} "
+          f"{a['flops']/max(t,1)/1e3:7.1f} {a['wbytes']/max(t,1):7.1f}")

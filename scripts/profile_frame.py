@@ -1,0 +1,55 @@
+"""Run under rocprofv3 --kernel-trace: executes eager frames of the 512x512 4-step program and writes the op
+list (shapes, tile, split) to gpurun_out/ops_<tag>.json so that scripts/analyze_trace.py can attribute
+kernel durations to layers."""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from videosd_amd import config as C, weights as W, lib as L
+from videosd_amd.engine import Engine
+from videosd_amd.ops import HipOps, choose_tile
+
+cn = "--no-cn" not in sys.argv
+size = 512
+for a in sys.argv[1:]:
+    if a.startswith("--size="): size = int(a.split("=")[1])
+tag = sys.argv[-1] if not sys.argv[-1].startswith("--") and len(sys.argv) > 1 else "r1"
+ops = HipOps(0)
+wu = W.synthesize(W.unet_spec(C.SD15_UNET), "unet.", device="cuda")
+wc = W.synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", device="cuda")
+wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda")
+eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
+eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half())
+eng.prepare(size, size, 4, 0.6, use_controlnet=cn, use_graph=False)
+meta = []
+for fn, a, k in eng.program.calls:
+    name = fn.__name__
+    m = {"op": name}
+    if name == "conv":
+        g, w = a[2], a[3]
+        tile, split = k.get("tile"), k.get("split_k")
+        if tile is None:
+            tile, sk = choose_tile(g.m, w.n, w.kp, w.geglu, k.get("t_col0", 0) if k.get("out_t") is not None else 0)
+            split = sk if split is None else split
+        key = ops.conv_key(g, w, k.get("t_col0", 0))
+        ink = True
+        if k.get("tile") is None and key in ops.tile_override:
+            tile, split, ink = ops.tile_override[key]
+        split = split or 1
+        kt = w.kp // 64
+        split = min(split, kt); per = -(-kt // split); split = -(-kt // per)
+        m.update(M=g.m, N=w.n, K=w.k, ks=g.ksize, stride=g.stride, resize=(g.hi != g.hs), tile=tile, split=split if not ink else -split,
+                 flops=2.0 * g.m * w.n * w.k, wbytes=2 * w.n * w.kp, geglu=w.geglu)
+    elif name == "groupnorm":
+        m.update(C=a[2] + a[3], hw=a[4])
+    elif name == "layernorm":
+        m.update(rows=a[1], C=a[2])
+    elif name == "attention":
+        m.update(sq=a[8], sk=a[9], heads=a[10], d=a[11], flops=4.0 * a[8] * a[9] * a[10] * a[11])
+    meta.append(m)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(meta, open(f"gpurun_out/ops_{tag}.json", "w"))
+f = np.random.default_rng(0).integers(0, 256, (size, size, 3), dtype=np.uint8)
+for _ in range(4):
+    eng.infer_u8(f)
+ops.synchronize()
+print("ops", len(meta))

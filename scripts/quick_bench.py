@@ -21,6 +21,8 @@ for cn in (False, True):
     for _ in range(N): eng.launch()
     ops.synchronize(); dt=(time.time()-t)/N
     print(f"cn={cn}: {dt*1e3:.2f} ms/frame  {1/dt:.1f} fps")
+    if cn:
+        for k, v in sorted(ops.tile_override.items()): print("   tuned", k, v)
     eng.prepare(512, 512, 4, 0.6, use_controlnet=cn, use_graph=False)
     ops.profile_begin(); eng.launch(); ops.synchronize(); st = ops.profile_end()
     for k,v in st.items(): print(f"   {k:14s} {v['ms']:8.3f} ms  {v['launches']:5d} launches  {v['flops']/1e12:.3f} TFLOP  -> {v['flops']/1e9/max(v['ms'],1e-9):.1f} TFLOP/s" )

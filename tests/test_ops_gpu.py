@@ -107,6 +107,23 @@ def test_conv3x3_all_tiles_splitk(ops, tile, split_k):
     check(got, ref, f"conv3x3 tile={tile} split={split_k}")
 
 
+def test_splitk_inkernel_reduction_is_bit_identical_to_reduce_kernel(ops):
+    h, w, cin, cout = 16, 16, 640, 320
+    x = rnd(1, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
+    b = rnd(cout, seed=3, scale=0.1)
+    res = rnd(h * w, cout, seed=5)
+    outs = []
+    for inkernel in (True, False, True):
+        ops.inkernel_splitk = inkernel
+        got, ref = run_conv(ops, [x], h, w, wt, b, ksize=3, tile=2, split_k=6, residual=res, act=2)
+        check(got, ref, f"split-K inkernel={inkernel}")
+        outs.append(got)
+    ops.inkernel_splitk = True
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert int(ops._counters.abs().sum()) == 0  # every tile's arrival counter is back at zero
+
+
 def test_conv3x3_sd_width_deep_k(ops):
     h, w, cin, cout = 8, 8, 2560, 1280  # the deepest K of the UNet (23040), small M -> split-K heuristic path
     x = rnd(1, cin, h, w, seed=1)

@@ -45,6 +45,7 @@ struct ConvParams {
   int ldt, t_col0;
   int split_k, kt_per_split;
   float* ws_partial;
+  int* counters;  // per-tile arrival tickets for the in-kernel split-K reduction (all zero between launches)
   int tiles_m, tiles_n;
 };
 
@@ -131,6 +132,43 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
       if (post) x = apply_act(x);
       p.out[(size_t)m * p.ldo + n + i] = (half_t)x;
       if (p.out2) p.out2[(size_t)m * p.ldo + n + i] = (half_t)(x + (float)p.add2[(size_t)m * p.ldo + n + i]);
+    }
+  }
+}
+
+// 8 consecutive fp32 outputs of row r / column c8 of this tile: from the LDS-staged accumulators, or (last
+// arriver of a split-K tile) the sum of all slabs in the fixed order 0..split_k-1 (deterministic).
+__device__ __forceinline__ void load_chunk8(const ConvParams& p, const float* Cs, int pitch, bool from_slabs, int r, int c8,
+                                            int m, int n, float (&v)[8]) {
+  if (!from_slabs) {
+    f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * pitch + c8);
+    f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * pitch + c8 + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = lo[i];
+      v[4 + i] = hi[i];
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  const size_t slab = (size_t)p.M * p.N;
+  const float* s = p.ws_partial + (size_t)m * p.N + n;
+  if (n + 8 <= p.N) {
+    for (int k = 0; k < p.split_k; ++k) {
+      f32x4 lo = *reinterpret_cast<const f32x4*>(s + k * slab);
+      f32x4 hi = *reinterpret_cast<const f32x4*>(s + k * slab + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] += lo[i];
+        v[4 + i] += hi[i];
+      }
+    }
+  } else {
+    for (int k = 0; k < p.split_k; ++k) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (n + i < p.N) v[i] += s[k * slab + i];
     }
   }
 }
@@ -302,9 +340,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }
   __syncthreads();
 
+  bool from_slabs = false;
   if (p.split_k > 1) {
     constexpr int CH = BN / 8;
     float* slab = p.ws_partial + (size_t)split * p.M * p.N;
+    // With the in-kernel reduction the slabs are stored WRITE-THROUGH (sc1): they are then visible to the
+    // reducing workgroup on any XCD without an L2 write-back fence on every producer (cdna guide, G16 R1).
+    const bool wt = p.counters != nullptr;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        slab, 0, (int)min((size_t)p.M * p.N * sizeof(float), (size_t)0x7fffffff), 0x00020000);
     for (int q = tid; q < BM * CH; q += 256) {
       int r = q / CH, c8 = (q - r * CH) * 8;
       int m = m0 + r, n = n0 + c8;
@@ -312,15 +356,45 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       const float* s = Cs + r * BNP + c8;
       float* d = slab + (size_t)m * p.N + n;
       if (n + 8 <= p.N) {
-        *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(s);
-        *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(s + 4);
+        if (wt) {
+          int off = (int)(((size_t)m * p.N + n) * sizeof(float));
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(s), rsrc, off, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(s + 4), rsrc, off + 16, 0, 16);
+        } else {
+          *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(s);
+          *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(s + 4);
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          if (n + i < p.N) d[i] = s[i];
+          if (n + i < p.N) {
+            if (wt) __hip_atomic_store(d + i, s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else d[i] = s[i];
+          }
       }
     }
-    return;
+    if (!p.counters) return;  // two-kernel form: splitk_reduce_kernel finishes the job
+    // In-launch reduction: the LAST workgroup to arrive at this tile sums the slabs and runs the epilogue.
+    // Write-through slab stores, every wave drains them (vmcnt(0)), barrier, one relaxed agent-scope ticket;
+    // agent-scope acquire on the reducer
+    // (cdna guide, "In-launch split-K reduction").  Placement independent; the counter is left at zero.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* lastflag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      int* cnt = p.counters + tile_n * p.tiles_m + tile_m;
+      int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int last = ticket == p.split_k - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *lastflag = last;
+    }
+    __syncthreads();
+    if (!*lastflag) return;
+    from_slabs = true;
   }
 
   if ((p.act & 0xff) == VSD_ACT_GEGLU) {
@@ -355,8 +429,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       int m = m0 + r, n = n0 + c8;
       if (m >= p.M || n >= p.N) continue;
       float v[8];
+      if (from_slabs) {
+        load_chunk8(p, Cs, BNP, true, r, c8, m, n, v);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = Cs[r * BNP + c8 + i];
+        for (int i = 0; i < 8; ++i) v[i] = Cs[r * BNP + c8 + i];
+      }
       epilogue_store8(p, m, n, v);
     }
   } else {
@@ -366,13 +444,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       int m = m0 + r, n = n0 + c8;
       if (m >= p.M || n >= p.N) continue;
       float v[8];
-      f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8);
-      f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8 + 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        v[i] = lo[i];
-        v[4 + i] = hi[i];
-      }
+      load_chunk8(p, Cs, BNP, from_slabs, r, c8, m, n, v);
       epilogue_store8(p, m, n, v);
     }
   }
@@ -445,6 +517,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.out_t = (half_t*)d->out_t; p.ldt = d->ldt; p.t_col0 = d->t_col0;
   p.split_k = d->split_k < 1 ? 1 : d->split_k;
   p.ws_partial = (float*)d->workspace;
+  p.counters = (int*)d->counters;
 
   if (!p.src0 || !p.w || !p.out) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: null src/weight/out");
   if (p.M <= 0 || p.N <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: empty problem M=%d N=%d", p.M, p.N);
@@ -475,6 +548,9 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   if (p.split_k > KT) p.split_k = KT;
   p.kt_per_split = cdiv(KT, p.split_k);
   p.split_k = cdiv(KT, p.kt_per_split);
+  if (p.split_k == 1) p.counters = nullptr;
+  if (p.counters && p.tiles_m * p.tiles_n > VSD_SPLITK_MAX_TILES)
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: %d tiles exceed the split-K counter buffer", p.tiles_m * p.tiles_n);
   const int grid = p.tiles_m * p.tiles_n * p.split_k;
   {
     LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
@@ -485,7 +561,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     int rc = ls.finish();
     if (rc) return rc;
   }
-  if (p.split_k > 1) {
+  if (p.split_k > 1 && !p.counters) {
     LaunchScope ls(ctx, s, VSD_FAM_SPLITK_REDUCE, 0.0);
     size_t total = (size_t)p.M * ((p.N + 7) / 8);
     int g = (int)((total + 255) / 256);

@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int GN_MAX_PART = 64;
+constexpr int GN_MAX_PART = 32;
 
 struct GnParams {
   const half_t* src0;
@@ -79,17 +79,33 @@ __global__ void gn_stats_kernel(const GnParams p) {
 __global__ void gn_apply_kernel(const GnParams p) {
   extern __shared__ float sm[];  // [groups][2] -> mean, rstd
   const int t = threadIdx.x;
-  if (t < p.groups) {
-    float s = 0.f, q = 0.f;
-    for (int b = 0; b < p.nblk; ++b) {
-      s += p.part[((size_t)b * p.groups + t) * 2];
-      q += p.part[((size_t)b * p.groups + t) * 2 + 1];
+  // fold the stats partials in a fixed order: one thread per (group, sum|sumsq), loads independent of each other
+  for (int i = t; i < p.groups * 2; i += blockDim.x) {
+    float acc = 0.f;
+    const float* src = p.part + i;
+    const int stride = p.groups * 2;
+    int b = 0;
+    for (; b + 4 <= p.nblk; b += 4) {
+      float v0 = src[(size_t)(b + 0) * stride], v1 = src[(size_t)(b + 1) * stride];
+      float v2 = src[(size_t)(b + 2) * stride], v3 = src[(size_t)(b + 3) * stride];
+      acc += v0; acc += v1; acc += v2; acc += v3;
     }
+    for (; b < p.nblk; ++b) acc += src[(size_t)b * stride];
+    sm[i] = acc;
+  }
+  __syncthreads();
+  float mean_r = 0.f, rstd_r = 0.f;
+  if (t < p.groups) {
     float n = (float)p.hw * (float)p.cpg;
-    float mean = s / n;
-    float var = fmaxf(q / n - mean * mean, 0.f);
-    sm[t * 2] = mean;
-    sm[t * 2 + 1] = rsqrtf(var + p.eps);
+    float mean = sm[t * 2] / n;
+    float var = fmaxf(sm[t * 2 + 1] / n - mean * mean, 0.f);
+    mean_r = mean;
+    rstd_r = rsqrtf(var + p.eps);
+  }
+  __syncthreads();
+  if (t < p.groups) {
+    sm[t * 2] = mean_r;
+    sm[t * 2 + 1] = rstd_r;
   }
   __syncthreads();
   const int ch8 = t % p.c8;
@@ -202,7 +218,7 @@ extern "C" int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, i
   p.out = (half_t*)out; p.part = (float*)workspace;
   p.rpp = p.c8 >= 256 ? 1 : 256 / p.c8;
   const int threads = p.c8 * p.rpp;
-  int nblk = cdiv(hw, 4 * p.rpp);
+  int nblk = cdiv(hw, 8 * p.rpp);
   if (nblk > GN_MAX_PART) nblk = GN_MAX_PART;
   if (nblk < 1) nblk = 1;
   p.nblk = nblk;
@@ -216,8 +232,8 @@ extern "C" int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, i
     if (rc) return rc;
   }
   {
-    int ablk = cdiv(hw, 2 * p.rpp);
-    if (ablk > 512) ablk = 512;
+    int ablk = cdiv(hw, 4 * p.rpp);
+    if (ablk > 256) ablk = 256;
     LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk), dim3(threads), smem, s, p);
     return ls.finish();

@@ -558,8 +558,27 @@ class Engine:
         r.conv(h, None, Geom.conv(hh, ww), v.dec_out, out, ldo=8)
 
     # ---------------------------------------------------------------- prepare: build + capture
+    def autotune(self, verbose: bool = False):
+        """Pick (tile, split-K, reduction form) per distinct conv shape of the recorded program by timing the
+        candidates on the GPU (the hipBLASLt/MIOpen "find" step, done on our own kernel)."""
+        ops = self.ops
+        if not hasattr(ops, "tune_conv"):
+            return {}
+        seen = {}
+        for fn, a, k in self.program.calls:
+            if fn.__name__ != "conv":
+                continue
+            key = ops.conv_key(a[2], a[3], k.get("t_col0", 0))
+            if key in seen or key in ops.tile_override or k.get("tile") is not None:
+                continue
+            best, table = ops.tune_conv(a, k)
+            seen[key] = best
+            if verbose:
+                print("tune", key, "->", best, flush=True)
+        return seen
+
     def prepare(self, H: int, W: int, steps: int, strength: float, controlnet_scale: float = 1.0,
-                use_controlnet: bool = True, use_graph: Optional[bool] = None):
+                use_controlnet: bool = True, use_graph: Optional[bool] = None, autotune: bool = True):
         """Fix the frame geometry and schedule; build the static program and capture it into a hipGraph
         (the reference's intent at videopipeline.py:35-47, `compile_model`)."""
         if H % 8 or W % 8:
@@ -632,7 +651,9 @@ class Engine:
         self.program = r
         self.plan = dict(H=H, W=W, steps=steps, strength=strength, cn_scale=controlnet_scale, cn=use_controlnet, n=n,
                          sizes=sizes, timesteps=sched.timesteps, n_ops=len(r.calls), arena_bytes=a.peak)
-        # warm-up (eager), then capture
+        # per-shape kernel configuration (timed once per shape, cached in ops.tile_override), warm-up, capture
+        if autotune:
+            self.autotune()
         r.run()
         ops.synchronize()
         if self.use_graph:

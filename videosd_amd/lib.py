@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(HERE, "libvsd.so")
 
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_QUICKGELU = range(5)
 ACT_POST = 256
+SPLITK_MAX_TILES = 16384
 TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128 = range(4)
 TILE_DIMS = {TILE_128x128: (128, 128), TILE_128x64: (128, 64), TILE_64x64: (64, 64), TILE_64x128: (64, 128)}
 FAMILIES = ["conv_gemm", "splitk_reduce", "groupnorm", "layernorm", "attention", "elementwise"]
@@ -32,6 +33,7 @@ class ConvDesc(C.Structure):
         ("out_t", C.c_void_p), ("ldt", C.c_int32), ("t_col0", C.c_int32),
         ("tile", C.c_int32), ("split_k", C.c_int32),
         ("workspace", C.c_void_p),
+        ("counters", C.c_void_p),
     ]
 
 

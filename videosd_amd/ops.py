@@ -85,6 +85,8 @@ class HipOps:
         torch.cuda.set_stream(self.stream)
         self._ws = {}
         self.tile_override = {}
+        self.inkernel_splitk = True
+        self._counters = torch.zeros(L.SPLITK_MAX_TILES, dtype=torch.int32, device=self.device)
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -131,10 +133,11 @@ class HipOps:
         c0 = c0 if c0 is not None else (w.cin - c1)
         if w.geglu:
             act = L.ACT_GEGLU
-        key = (m, w.n, w.kp, w.geglu, t_col0)
+        key = self.conv_key(g, w, t_col0)
+        inkernel = self.inkernel_splitk
         if tile is None:
             if key in self.tile_override:
-                tile, split_k = self.tile_override[key]
+                tile, split_k, inkernel = self.tile_override[key]
             else:
                 tile, sk = choose_tile(m, w.n, w.kp, w.geglu, t_col0 if out_t is not None else 0)
                 split_k = sk if split_k is None else split_k
@@ -160,7 +163,58 @@ class HipOps:
         if split_k > 1:
             ws = workspace if workspace is not None else self.workspace("splitk", split_k * m * w.n * 4)
             d.workspace = self._p(ws)
+            if inkernel:
+                d.counters = self._p(self._counters)
         self.ctx.call("vsd_conv_gemm", C.byref(d), self.s)
+
+    @staticmethod
+    def conv_key(g: Geom, w: PackedConv, t_col0: int = 0):
+        return (g.m, w.n, w.kp, g.ksize, g.stride, g.hi != g.hs or g.wi != g.ws, w.geglu, t_col0)
+
+    def tune_conv(self, args, kwargs, reps: int = 8):
+        """Time every (tile, split_k, reduction form) candidate for one recorded conv call on the GPU and
+        remember the fastest in tile_override.  Returns (best, table)."""
+        g, w = args[2], args[3]
+        t_col0 = kwargs.get("t_col0", 0)
+        key = self.conv_key(g, w, t_col0)
+        kt = w.kp // 64
+        tiles = [L.TILE_128x128, L.TILE_64x128] if w.geglu else [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64]
+        cands = []
+        for t in tiles:
+            bm, bn = L.TILE_DIMS[t]
+            if kwargs.get("out_t") is not None and t_col0 % bn:
+                continue
+            blocks = -(-g.m // bm) * -(-w.n // bn)
+            cands.append((t, 1, False))
+            if w.geglu or blocks >= 384:
+                continue
+            for sp in (2, 3, 4, 6, 8, 12, 16, 24):
+                if sp > kt // 2 or blocks * sp > 1536:
+                    break
+                cands.append((t, sp, False))
+                cands.append((t, sp, True))
+        kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k")}
+        table = []
+        saved = self.tile_override.pop(key, None)
+        for (t, sp, ink) in cands:
+            self.inkernel_splitk = ink
+            try:
+                for _ in range(2):
+                    self.conv(*args, tile=t, split_k=sp, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
+                for _ in range(reps):
+                    self.conv(*args, tile=t, split_k=sp, **kw)
+                e1.record(self.stream)
+                e1.synchronize()
+                table.append((e0.elapsed_time(e1) / reps * 1e3, t, sp, ink))
+            except RuntimeError:
+                continue
+        self.inkernel_splitk = True
+        table.sort()
+        best = table[0]
+        self.tile_override[key] = (best[1], best[2], best[3])
+        return best, table
 
     def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out):
         ws = self.workspace("gn", int(self.ctx.lib.vsd_groupnorm_workspace_bytes(hw, c0 + c1, groups)))
