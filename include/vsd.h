@@ -91,6 +91,8 @@ typedef struct vsd_conv_desc {
   int32_t tile;           /* vsd_tile */
   int32_t split_k;        /* >= 1; > 1 needs workspace of split_k * M * n floats */
   void* workspace;
+  int32_t pipeline;       /* main-loop form: 0 = register-staged double buffer; 3 or 4 = direct-to-LDS ring with
+                             that many stages (global_load_lds, counted vmcnt) */
   void* counters;         /* optional: VSD_SPLITK_MAX_TILES int32, all zero.  When given, a split-K launch reduces
                              inside the kernel (the last workgroup to arrive at a tile sums the slabs in a fixed
                              order and runs the epilogue, leaving its counter at zero); when NULL a second

@@ -33,7 +33,7 @@ for fn, a, k in eng.program.calls:
         key = ops.conv_key(g, w, k.get("t_col0", 0))
         ink = True
         if k.get("tile") is None and key in ops.tile_override:
-            tile, split, ink = ops.tile_override[key]
+            tile, split, ink, _pl = ops.tile_override[key]
         split = split or 1
         kt = w.kp // 64
         split = min(split, kt); per = -(-kt // split); split = -(-kt // per)

@@ -42,7 +42,7 @@ def check(got, ref, what="", atol_scale=2.0 ** -8, rel=2e-3):
 
 
 def run_conv(ops, x_list, h, w, weight, bias, *, ksize, stride=1, up_to=None, tile=None, split_k=None, act=0,
-             rowvec=None, residual=None, residual2=None, out_scale=1.0, cin_pad=None):
+             rowvec=None, residual=None, residual2=None, out_scale=1.0, cin_pad=None, pipeline=None):
     """x_list: NCHW fp16 CPU tensors (concat sources). Returns (got [M,N] fp16 on cpu, ref NCHW fp32)."""
     from videosd_amd.ops import Geom
     from videosd_amd.packing import pack_conv
@@ -71,7 +71,7 @@ def run_conv(ops, x_list, h, w, weight, bias, *, ksize, stride=1, up_to=None, ti
     c0 = srcs[0].shape[1]
     c1 = srcs[1].shape[1] if len(srcs) > 1 else 0
     ops.conv(srcs[0], srcs[1] if len(srcs) > 1 else None, g, pw, out, ldo=ldo, c0=c0, c1=c1, act=act, out_scale=out_scale,
-             tile=tile, split_k=split_k, **kw)
+             tile=tile, split_k=split_k, pipeline=pipeline, **kw)
     ops.synchronize()
     # reference
     xin = torch.cat([x.float() for x in x_list], dim=1)
@@ -96,15 +96,30 @@ def run_conv(ops, x_list, h, w, weight, bias, *, ksize, stride=1, up_to=None, ti
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3])
 @pytest.mark.parametrize("split_k", [1, 3])
-def test_conv3x3_all_tiles_splitk(ops, tile, split_k):
+@pytest.mark.parametrize("pipeline", [0, 3, 4])
+def test_conv3x3_all_tiles_splitk(ops, tile, split_k, pipeline):
     h, w, cin, cout = 18, 14, 128, 192  # M=252: ragged in M for every tile
     x = rnd(1, cin, h, w, seed=1)
     wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
     b = rnd(cout, seed=3, scale=0.1)
     rv = rnd(cout, seed=4, scale=0.1)
     res = rnd(h * w, cout, seed=5)
-    got, ref = run_conv(ops, [x], h, w, wt, b, ksize=3, tile=tile, split_k=split_k, rowvec=rv, residual=res)
-    check(got, ref, f"conv3x3 tile={tile} split={split_k}")
+    got, ref = run_conv(ops, [x], h, w, wt, b, ksize=3, tile=tile, split_k=split_k, rowvec=rv, residual=res,
+                        pipeline=pipeline)
+    check(got, ref, f"conv3x3 tile={tile} split={split_k} pipeline={pipeline}")
+
+
+@pytest.mark.parametrize("pipeline", [0, 3, 4])
+def test_pipelines_are_bit_identical_and_handle_short_k(ops, pipeline):
+    # K = 1..5 tiles (shorter than the ring), ragged M and N
+    for cin in (64, 128, 320):
+        h, w, cout = 9, 11, 72
+        x = rnd(1, cin, h, w, seed=1)
+        wt = rnd(cout, cin, 1, 1, seed=2, scale=cin ** -0.5)
+        got, ref = run_conv(ops, [x], h, w, wt, rnd(cout, seed=3, scale=0.1), ksize=1, tile=2, pipeline=pipeline)
+        base, _ = run_conv(ops, [x], h, w, wt, rnd(cout, seed=3, scale=0.1), ksize=1, tile=2, pipeline=0)
+        check(got, ref, f"short-K cin={cin} pipeline={pipeline}")
+        assert torch.equal(got, base)
 
 
 def test_splitk_inkernel_reduction_is_bit_identical_to_reduce_kernel(ops):
@@ -167,8 +182,9 @@ def test_conv_small_channels_generic_path(ops, cin, cout, pad):
     h, w = 20, 12
     x = rnd(1, cin, h, w, seed=1)
     wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
-    got, ref = run_conv(ops, [x], h, w, wt, rnd(cout, seed=3, scale=0.1), ksize=3, cin_pad=pad, act=2)
-    check(got, ref, f"generic conv {cin}->{cout}")
+    for pl in (0, 3):
+        got, ref = run_conv(ops, [x], h, w, wt, rnd(cout, seed=3, scale=0.1), ksize=3, cin_pad=pad, act=2, pipeline=pl)
+        check(got, ref, f"generic conv {cin}->{cout} pipeline={pl}")
 
 
 @pytest.mark.parametrize("act", [0, 1, 2, 4])

@@ -11,6 +11,10 @@ extern "C" vsd_ctx* vsd_create(int device_id) {
   if (hipSetDevice(device_id) != hipSuccess) return nullptr;
   vsd_ctx* c = new vsd_ctx();
   c->device = device_id;
+  if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
   for (int i = 0; i < VSD_FAM_COUNT; ++i) {
     c->fam_flops[i] = 0;
     c->fam_launch[i] = 0;
@@ -29,6 +33,7 @@ static void drop_events(vsd_ctx* ctx) {
 extern "C" void vsd_destroy(vsd_ctx* ctx) {
   if (!ctx) return;
   drop_events(ctx);
+  if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   delete ctx;
 }
 

@@ -28,6 +28,7 @@ struct vsd_ctx {
   bool profiling = false;
   bool capturing = false;
   std::vector<ProfEvent> events;
+  void* zero_page = nullptr;  // 4 KiB of zeros in HBM (out-of-bounds source for LDS-DMA loads)
   double fam_flops[VSD_FAM_COUNT];
   int64_t fam_launch[VSD_FAM_COUNT];
 };

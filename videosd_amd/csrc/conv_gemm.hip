@@ -45,6 +45,7 @@ struct ConvParams {
   int ldt, t_col0;
   int split_k, kt_per_split;
   float* ws_partial;
+  const half_t* zeros;  // >= 16 zero bytes: source of out-of-bounds chunks for the direct-to-LDS loader
   int* counters;  // per-tile arrival tickets for the in-kernel split-K reduction (all zero between launches)
   int tiles_m, tiles_n;
 };
@@ -174,19 +175,25 @@ __device__ __forceinline__ void load_chunk8(const ConvParams& p, const float* Cs
 }
 
 // ---------------------------------------------------------------- main kernel
-template <int BM, int BN, bool GENERIC>
+// STAGES == 0: register-staged double buffer (global -> VGPR -> LDS), one tile of prefetch.
+// STAGES >= 3: direct-to-LDS ring (global_load_lds, 16 B per lane) with STAGES-1 tiles in flight behind counted
+//              vmcnt waits and raw barriers; the XOR swizzle is applied on the per-lane SOURCE address because a
+//              wave's LDS-DMA destination is lane-linear; out-of-bounds chunks read a zero page.
+template <int BM, int BN, bool GENERIC, int STAGES>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   constexpr int WM = 2, WN = 2;             // 2x2 waves
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   constexpr int FM = TM / 16, FN = TN / 16;  // 16x16 fragments per wave
   constexpr int AR = BM / 32, BR = BN / 32;  // 16-byte chunks per thread per K tile
   constexpr int BNP = BN + 4;                // fp32 epilogue row pitch
-  constexpr int STAGE_BYTES = 2 * (BM + BN) * BK * 2;
+  constexpr int NBUF = STAGES == 0 ? 2 : STAGES;
+  constexpr int STAGE_HALFS = (BM + BN) * BK;
+  constexpr int STAGE_BYTES = NBUF * STAGE_HALFS * 2;
   constexpr int EPI_BYTES = BM * BNP * 4;
   constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-  half_t* As = reinterpret_cast<half_t*>(smem);                // [2][BM][64]
-  half_t* Bs = reinterpret_cast<half_t*>(smem) + 2 * BM * BK;  // [2][BN][64]
+  half_t* As = reinterpret_cast<half_t*>(smem);                                        // register path: [2][BM][64]
+  half_t* Bs = reinterpret_cast<half_t*>(smem) + 2 * BM * BK;                          //                [2][BN][64]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -293,38 +300,127 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   const int fr = lane & 15;  // fragment row (A) / column (B)
   const int fq = lane >> 4;  // k-chunk quarter
 
-  if (kt_begin < kt_end) {
-    VSD_LOAD_TILE(kt_begin)
-    VSD_STORE_TILE(0)
-  }
-  __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    const bool more = kt + 1 < kt_end;
-    if (more) VSD_LOAD_TILE(kt + 1)
-    const half_t* a = As + buf * BM * BK;
-    const half_t* b = Bs + buf * BN * BK;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8 af[FM], bf[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        int r = wm * TM + i * 16 + fr;
-        af[i] = *reinterpret_cast<const half8*>(a + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
-      }
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        int r = wn * TN + j * 16 + fr;
-        bf[j] = *reinterpret_cast<const half8*>(b + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
-      }
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+  if constexpr (STAGES == 0) {
+    if (kt_begin < kt_end) {
+      VSD_LOAD_TILE(kt_begin)
+      VSD_STORE_TILE(0)
     }
-    if (more) VSD_STORE_TILE(buf ^ 1)
     __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int buf = (kt - kt_begin) & 1;
+      const bool more = kt + 1 < kt_end;
+      if (more) VSD_LOAD_TILE(kt + 1)
+      const half_t* a = As + buf * BM * BK;
+      const half_t* b = Bs + buf * BN * BK;
+  #pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        half8 af[FM], bf[FN];
+  #pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          int r = wm * TM + i * 16 + fr;
+          af[i] = *reinterpret_cast<const half8*>(a + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+        }
+  #pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          int r = wn * TN + j * 16 + fr;
+          bf[j] = *reinterpret_cast<const half8*>(b + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+        }
+  #pragma unroll
+        for (int i = 0; i < FM; ++i)
+  #pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) VSD_STORE_TILE(buf ^ 1)
+      __syncthreads();
+    }
+  } else {
+    // ------------------------------------------------------------ direct-to-LDS ring
+    constexpr int LPT = AR + BR;            // LDS-DMA instructions per thread per tile
+    const int lc = cc ^ (lr & 7);           // logical 16-byte chunk this lane fetches; it lands in slot cc of its row
+    const int nt = kt_end - kt_begin;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+#define VSD_ISSUE_TILE(KT_, SLOT_)                                                                    \
+  {                                                                                                   \
+    const int kt_ = (KT_);                                                                            \
+    half_t* a_ = reinterpret_cast<half_t*>(smem) + (SLOT_) * STAGE_HALFS;                             \
+    half_t* b_ = a_ + BM * BK;                                                                        \
+    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                  \
+      const half_t* g_ = nvalid[i] ? (wrow[i] - cc * 8 + lc * 8 + (size_t)kt_ * BK) : p.zeros;        \
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(b_ + (8 * wave + 32 * i) * BK), 16, 0, 0); \
+    }                                                                                                 \
+    int k_, cs_;                                                                                      \
+    const half_t* src_;                                                                               \
+    bool kok_ = true;                                                                                 \
+    if (!GENERIC) {                                                                                   \
+      k_ = kt_ * BK;                                                                                  \
+    } else {                                                                                          \
+      k_ = kt_ * BK + lc * 8;                                                                         \
+      kok_ = k_ < p.K;                                                                                \
+    }                                                                                                 \
+    const int tap_ = k_ / p.cin;                                                                      \
+    int c_ = k_ - tap_ * p.cin;                                                                       \
+    const int ky_ = tap_ / p.ksize, kx_ = tap_ - ky_ * p.ksize;                                       \
+    if (!GENERIC && c_ >= p.c0) {                                                                     \
+      src_ = p.src1; cs_ = p.c1; c_ -= p.c0;                                                          \
+    } else {                                                                                          \
+      src_ = p.src0; cs_ = p.c0;                                                                      \
+    }                                                                                                 \
+    if (!GENERIC) c_ += lc * 8;                                                                       \
+    _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                  \
+      int iy = iy0[i] + ky_, ix = ix0[i] + kx_;                                                       \
+      bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi;  \
+      int sy = iy, sx = ix;                                                                           \
+      if (p.resize) {                                                                                 \
+        sy = (iy * p.hs) / p.hi;                                                                      \
+        sx = (ix * p.ws) / p.wi;                                                                      \
+      }                                                                                               \
+      const half_t* g_ = ok ? src_ + ((size_t)(sy * p.ws + sx)) * cs_ + c_ : p.zeros;                 \
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(a_ + (8 * wave + 32 * i) * BK), 16, 0, 0); \
+    }                                                                                                 \
+  }
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+      if (st < nt) VSD_ISSUE_TILE(kt_begin + st, st)
+    int slot = 0;
+    for (int t = 0; t < nt; ++t) {
+      // tile t has landed once all but the younger tiles' loads are done; then everyone's has (barrier)
+      const int rem = min(STAGES - 2, nt - 1 - t);
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + STAGES - 1 < nt) {
+        int ns = slot + STAGES - 1;
+        if (ns >= STAGES) ns -= STAGES;
+        VSD_ISSUE_TILE(kt_begin + t + STAGES - 1, ns)
+      }
+      const half_t* a = reinterpret_cast<const half_t*>(smem) + slot * STAGE_HALFS;
+      const half_t* b = a + BM * BK;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        half8 af[FM], bf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          int r = wm * TM + i * 16 + fr;
+          af[i] = *reinterpret_cast<const half8*>(a + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          int r = wn * TN + j * 16 + fr;
+          bf[j] = *reinterpret_cast<const half8*>(b + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      if (++slot == STAGES) slot = 0;
+    }
+    __syncthreads();  // every wave is done reading the ring before the epilogue reuses the LDS
+#undef VSD_ISSUE_TILE
   }
 
   // ---- epilogue: accumulators -> LDS (fp32) -> row-contiguous 8-wide chunks
@@ -481,10 +577,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
   }
 }
 
+template <int BM, int BN, int STAGES>
+void launch2(const ConvParams& p, int grid, hipStream_t s) {
+  if (p.generic) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, STAGES>), dim3(grid), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, STAGES>), dim3(grid), dim3(256), 0, s, p);
+}
 template <int BM, int BN>
-void launch(const ConvParams& p, int grid, hipStream_t s) {
-  if (p.generic) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true>), dim3(grid), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false>), dim3(grid), dim3(256), 0, s, p);
+void launch(const ConvParams& p, int grid, int stages, hipStream_t s) {
+  if (stages == 0) launch2<BM, BN, 0>(p, grid, s);
+  else if (stages == 3) launch2<BM, BN, 3>(p, grid, s);
+  else launch2<BM, BN, 4>(p, grid, s);
 }
 
 }  // namespace
@@ -518,6 +620,9 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.split_k = d->split_k < 1 ? 1 : d->split_k;
   p.ws_partial = (float*)d->workspace;
   p.counters = (int*)d->counters;
+  p.zeros = (const half_t*)ctx->zero_page;
+  const int stages = d->pipeline;
+  if (stages != 0 && stages != 3 && stages != 4) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3 or 4)", stages);
 
   if (!p.src0 || !p.w || !p.out) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: null src/weight/out");
   if (p.M <= 0 || p.N <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: empty problem M=%d N=%d", p.M, p.N);
@@ -554,10 +659,10 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   const int grid = p.tiles_m * p.tiles_n * p.split_k;
   {
     LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
-    if (BM == 128 && BN == 128) launch<128, 128>(p, grid, s);
-    else if (BM == 128 && BN == 64) launch<128, 64>(p, grid, s);
-    else if (BM == 64 && BN == 64) launch<64, 64>(p, grid, s);
-    else launch<64, 128>(p, grid, s);
+    if (BM == 128 && BN == 128) launch<128, 128>(p, grid, stages, s);
+    else if (BM == 128 && BN == 64) launch<128, 64>(p, grid, stages, s);
+    else if (BM == 64 && BN == 64) launch<64, 64>(p, grid, stages, s);
+    else launch<64, 128>(p, grid, stages, s);
     int rc = ls.finish();
     if (rc) return rc;
   }

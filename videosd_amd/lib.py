@@ -33,6 +33,7 @@ class ConvDesc(C.Structure):
         ("out_t", C.c_void_p), ("ldt", C.c_int32), ("t_col0", C.c_int32),
         ("tile", C.c_int32), ("split_k", C.c_int32),
         ("workspace", C.c_void_p),
+        ("pipeline", C.c_int32),
         ("counters", C.c_void_p),
     ]
 

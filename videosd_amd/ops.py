@@ -86,6 +86,7 @@ class HipOps:
         self._ws = {}
         self.tile_override = {}
         self.inkernel_splitk = True
+        self.default_pipeline = 3
         self._counters = torch.zeros(L.SPLITK_MAX_TILES, dtype=torch.int32, device=self.device)
 
     # ------------------------------------------------------------------ helpers
@@ -128,7 +129,7 @@ class HipOps:
     # ------------------------------------------------------------------ ops
     def conv(self, src0, src1, g: Geom, w: PackedConv, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None,
              residual2=None, ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0,
-             t_col0=0, tile=None, split_k=None, workspace=None):
+             t_col0=0, tile=None, split_k=None, workspace=None, pipeline=None):
         m = g.m
         c0 = c0 if c0 is not None else (w.cin - c1)
         if w.geglu:
@@ -137,7 +138,7 @@ class HipOps:
         inkernel = self.inkernel_splitk
         if tile is None:
             if key in self.tile_override:
-                tile, split_k, inkernel = self.tile_override[key]
+                tile, split_k, inkernel, pipeline = self.tile_override[key]
             else:
                 tile, sk = choose_tile(m, w.n, w.kp, w.geglu, t_col0 if out_t is not None else 0)
                 split_k = sk if split_k is None else split_k
@@ -160,6 +161,7 @@ class HipOps:
         d.out2, d.add2 = self._p(out2), self._p(add2)
         d.out_t, d.ldt, d.t_col0 = self._p(out_t), ldt, t_col0
         d.tile, d.split_k = tile, split_k
+        d.pipeline = self.default_pipeline if pipeline is None else pipeline
         if split_k > 1:
             ws = workspace if workspace is not None else self.workspace("splitk", split_k * m * w.n * 4)
             d.workspace = self._p(ws)
@@ -185,35 +187,37 @@ class HipOps:
             if kwargs.get("out_t") is not None and t_col0 % bn:
                 continue
             blocks = -(-g.m // bm) * -(-w.n // bn)
-            cands.append((t, 1, False))
+            for pl in (0, 3, 4):
+                cands.append((t, 1, False, pl))
             if w.geglu or blocks >= 384:
                 continue
             for sp in (2, 3, 4, 6, 8, 12, 16, 24):
                 if sp > kt // 2 or blocks * sp > 1536:
                     break
-                cands.append((t, sp, False))
-                cands.append((t, sp, True))
-        kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k")}
+                for pl in (0, 3):
+                    cands.append((t, sp, False, pl))
+                    cands.append((t, sp, True, pl))
+        kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline")}
         table = []
         saved = self.tile_override.pop(key, None)
-        for (t, sp, ink) in cands:
+        for (t, sp, ink, pl) in cands:
             self.inkernel_splitk = ink
             try:
                 for _ in range(2):
-                    self.conv(*args, tile=t, split_k=sp, **kw)
+                    self.conv(*args, tile=t, split_k=sp, pipeline=pl, **kw)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(self.stream)
                 for _ in range(reps):
-                    self.conv(*args, tile=t, split_k=sp, **kw)
+                    self.conv(*args, tile=t, split_k=sp, pipeline=pl, **kw)
                 e1.record(self.stream)
                 e1.synchronize()
-                table.append((e0.elapsed_time(e1) / reps * 1e3, t, sp, ink))
+                table.append((e0.elapsed_time(e1) / reps * 1e3, t, sp, ink, pl))
             except RuntimeError:
                 continue
         self.inkernel_splitk = True
         table.sort()
         best = table[0]
-        self.tile_override[key] = (best[1], best[2], best[3])
+        self.tile_override[key] = (best[1], best[2], best[3], best[4])
         return best, table
 
     def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out):
