@@ -11,6 +11,7 @@
 // head_dim d (multiple of 8, <= 160) is zero-padded to NQK*16 for QK^T and NPV*32 for PV.
 // Algorithmic FLOPs per launch: 4*sq*sk*heads*d.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -29,13 +30,18 @@ struct AttnParams {
 
 constexpr float NEG_BIG = -1.0e30f;
 
-template <int NQK, int NPV>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+template <int NQK, int NPV, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_kernel(const AttnParams p) {
+  constexpr int NT = 64 * NW;        // threads
   constexpr int KS = NQK * 16 + 8;   // K tile row pitch (halfs): odd number of 16-byte slots
   constexpr int VS = 64 + 4;         // V^T tile row pitch (halfs): 136 bytes
   constexpr int DV = NPV * 32;
-  __shared__ __attribute__((aligned(16))) half_t Ks[64 * KS];
-  __shared__ __attribute__((aligned(16))) half_t Vs[DV * VS];
+  constexpr int KTILE = 64 * KS, VTILE = DV * VS;
+  constexpr int KCH = (64 * NQK * 2 + NT - 1) / NT;  // 16-byte chunks per thread per K tile (upper bound)
+  constexpr int VCH = (DV * 8 + NT - 1) / NT;        // ... per V^T tile
+  __shared__ __attribute__((aligned(16))) half_t smem[2 * (KTILE + VTILE)];  // double buffered
+  half_t* Ks = smem;
+  half_t* Vs = smem + 2 * KTILE;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -43,13 +49,59 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
   const int lr = lane & 31;
   const int lh = lane >> 5;
   const int head = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
   const int d = p.d;
   const int dch = d >> 3;  // 16-byte chunks per row
 
-  // zero the LDS tiles once (padding columns / rows stay zero for the whole kernel)
-  for (int i = tid; i < 64 * KS / 8; i += 256) reinterpret_cast<u32x4*>(Ks)[i] = (u32x4){0u, 0u, 0u, 0u};
-  for (int i = tid; i < DV * VS / 4; i += 256) reinterpret_cast<u32x2*>(Vs)[i] = (u32x2){0u, 0u};
+  // zero both LDS buffers once (padding columns / rows stay zero for the whole kernel)
+  for (int i = tid; i < 2 * (KTILE + VTILE) / 8; i += NT) reinterpret_cast<u32x4*>(smem)[i] = (u32x4){0u, 0u, 0u, 0u};
+
+  // ---- per-thread staging coordinates (fixed for the whole kernel)
+  int kg[KCH], kl[KCH], krow[KCH];
+#pragma unroll
+  for (int i = 0; i < KCH; ++i) {
+    int c = tid + i * NT;
+    bool ok = c < 64 * dch;
+    int kr = ok ? c / dch : 0, kc = ok ? c - kr * dch : 0;
+    krow[i] = ok ? kr : 1 << 28;  // never < sk
+    kg[i] = kr * p.ldk + head * d + kc * 8;
+    kl[i] = kr * KS + kc * 8;
+  }
+  int vg[VCH], vl[VCH];
+  bool vok[VCH];
+#pragma unroll
+  for (int i = 0; i < VCH; ++i) {
+    int c = tid + i * NT;
+    vok[i] = c < d * 8;
+    int vr = vok[i] ? c >> 3 : 0, vc = c & 7;
+    vg[i] = (head * d + vr) * p.ldvt + vc * 8;
+    vl[i] = vr * VS + vc * 8;
+  }
+  u32x4 kreg[KCH], vreg[VCH];
+  const u32x4 zero4 = (u32x4){0u, 0u, 0u, 0u};
+#define ATT_LOAD(KEY0_)                                                                             \
+  {                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < KCH; ++i) {                                               \
+      bool ok = (KEY0_) + krow[i] < p.sk;                                                           \
+      u32x4 v = *reinterpret_cast<const u32x4*>(p.k + (ok ? (size_t)(KEY0_) * p.ldk + kg[i] : 0));  \
+      kreg[i] = ok ? v : zero4;                                                                     \
+    }                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < VCH; ++i) {                                               \
+      u32x4 v = *reinterpret_cast<const u32x4*>(p.vt + (vok[i] ? (size_t)vg[i] + (KEY0_) : 0));     \
+      vreg[i] = v;                                                                                  \
+    }                                                                                               \
+  }
+#define ATT_STORE(BUF_)                                                                             \
+  {                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < KCH; ++i)                                                 \
+      if (krow[i] < 64) *reinterpret_cast<u32x4*>(Ks + (BUF_) * KTILE + kl[i]) = kreg[i];           \
+    _Pragma("unroll") for (int i = 0; i < VCH; ++i)                                                 \
+      if (vok[i]) {                                                                                 \
+        u32x2* dst = reinterpret_cast<u32x2*>(Vs + (BUF_) * VTILE + vl[i]);                         \
+        dst[0] = (u32x2){vreg[i][0], vreg[i][1]};                                                   \
+        dst[1] = (u32x2){vreg[i][2], vreg[i][3]};                                                   \
+      }                                                                                             \
+  }
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0+lr][ks*16 + lh*8 .. +8], pre-scaled
   half8 qf[NQK];
@@ -75,29 +127,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
   float m_run = NEG_BIG, l_run = 0.f;
 
   int sk_end = p.sk;
-  if (p.causal) sk_end = min(p.sk, blockIdx.x * 128 + 128);  // keys beyond the block's last query are never visible
+  if (p.causal) sk_end = min(p.sk, (int)blockIdx.x * (32 * NW) + 32 * NW);  // later keys are never visible
   const int ntiles = (sk_end + 63) / 64;
+
+  ATT_LOAD(0)
+  __syncthreads();  // zero fill complete before the first tile lands on top of it
+  ATT_STORE(0)
+  __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
     const int key0 = t * 64;
-    __syncthreads();  // previous tile fully consumed (also orders the zero fill before the first stores)
-    // ---- stage K tile: 64 keys x d halfs
-    for (int c = tid; c < 64 * dch; c += 256) {
-      int kr = c / dch, kc = c - kr * dch;
-      int key = key0 + kr;
-      u32x4 v = *reinterpret_cast<const u32x4*>(p.k + (size_t)(key < p.sk ? key : 0) * p.ldk + head * d + kc * 8);
-      if (key >= p.sk) v = (u32x4){0u, 0u, 0u, 0u};
-      *reinterpret_cast<u32x4*>(Ks + kr * KS + kc * 8) = v;
-    }
-    // ---- stage V^T tile: d rows x 64 keys (global rows are zero-padded to a multiple of 64 keys)
-    for (int c = tid; c < d * 8; c += 256) {
-      int vr = c >> 3, vc = c & 7;
-      u32x4 v = *reinterpret_cast<const u32x4*>(p.vt + (size_t)(head * d + vr) * p.ldvt + key0 + vc * 8);
-      u32x2* dst = reinterpret_cast<u32x2*>(Vs + vr * VS + vc * 8);
-      dst[0] = (u32x2){v[0], v[1]};
-      dst[1] = (u32x2){v[2], v[3]};
-    }
-    __syncthreads();
+    const int buf = t & 1;
+    const bool more = t + 1 < ntiles;
+    if (more) ATT_LOAD(key0 + 64)  // next tile's global loads fly during this tile's MFMAs
+    const half_t* Kb = Ks + buf * KTILE;
+    const half_t* Vb = Vs + buf * VTILE;
 
     // ---- S^T = K Q^T for two 32-key chains
     f32x16 s[2];
@@ -107,7 +151,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < NQK; ++ks) {
-        half8 kf = *reinterpret_cast<const half8*>(Ks + (kb * 32 + lr) * KS + ks * 16 + lh * 8);
+        half8 kf = *reinterpret_cast<const half8*>(Kb + (kb * 32 + lr) * KS + ks * 16 + lh * 8);
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
       }
     }
@@ -158,7 +202,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         for (int j = 0; j < 8; ++j) pf[j] = (half_t)s[kb][8 * st + j];
 #pragma unroll
         for (int db = 0; db < NPV; ++db) {
-          const half_t* vrow = Vs + (db * 32 + lr) * VS + kb * 32 + 16 * st + 4 * lh;
+          const half_t* vrow = Vb + (db * 32 + lr) * VS + kb * 32 + 16 * st + 4 * lh;
           half4 lo = *reinterpret_cast<const half4*>(vrow);
           half4 hi = *reinterpret_cast<const half4*>(vrow + 8);
           half8 vf = (half8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -166,7 +210,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         }
       }
     }
+    if (more) ATT_STORE(buf ^ 1)
+    __syncthreads();
   }
+#undef ATT_LOAD
+#undef ATT_STORE
 
   // ---- epilogue: normalise and write O[q][head*d + dd]
   const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -189,9 +237,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 }
 
 template <int NQK, int NPV>
-void launch_attn(const AttnParams& p, hipStream_t s) {
-  dim3 grid((p.sq + 127) / 128, p.heads);
-  hipLaunchKernelGGL((attention_kernel<NQK, NPV>), grid, dim3(256), 0, s, p);
+void launch_attn(const AttnParams& p, int nw, hipStream_t s) {
+  if (nw == 2) {
+    dim3 grid((p.sq + 63) / 64, p.heads);
+    hipLaunchKernelGGL((attention_kernel<NQK, NPV, 2>), grid, dim3(128), 0, s, p);
+  } else {
+    dim3 grid((p.sq + 127) / 128, p.heads);
+    hipLaunchKernelGGL((attention_kernel<NQK, NPV, 4>), grid, dim3(256), 0, s, p);
+  }
 }
 
 }  // namespace
@@ -214,14 +267,17 @@ extern "C" int vsd_attention(vsd_ctx* ctx, const void* q, int ldq, const void* k
   hipStream_t s = (hipStream_t)stream;
   LaunchScope ls(ctx, s, VSD_FAM_ATTENTION, 4.0 * sq * (double)sk * heads * d);
   const int nqk = (d + 15) / 16, npv = (d + 31) / 32;
-  if (nqk <= 1) launch_attn<1, 1>(p, s);
-  else if (nqk == 2) launch_attn<2, 1>(p, s);
-  else if (nqk == 3) launch_attn<3, 2>(p, s);
-  else if (nqk == 4) launch_attn<4, 2>(p, s);
-  else if (nqk == 5) launch_attn<5, 3>(p, s);
-  else if (nqk == 6) launch_attn<6, 3>(p, s);
-  else if (nqk <= 8) launch_attn<8, 4>(p, s);
-  else launch_attn<10, 5>(p, s);
+  // 64-query workgroups (2 waves) when 128-query ones would leave the 256 CUs with < 2 workgroups each
+  int nw = (((sq + 127) / 128) * heads < 64) ? 2 : 4;
+  if (const char* e = getenv("VSD_ATTN_NW")) nw = atoi(e) == 2 ? 2 : 4;
+  if (nqk <= 1) launch_attn<1, 1>(p, nw, s);
+  else if (nqk == 2) launch_attn<2, 1>(p, nw, s);
+  else if (nqk == 3) launch_attn<3, 2>(p, nw, s);
+  else if (nqk == 4) launch_attn<4, 2>(p, nw, s);
+  else if (nqk == 5) launch_attn<5, 3>(p, nw, s);
+  else if (nqk == 6) launch_attn<6, 3>(p, nw, s);
+  else if (nqk <= 8) launch_attn<8, 4>(p, nw, s);
+  else launch_attn<10, 5>(p, nw, s);
   (void)npv;
   return ls.finish();
 }
