@@ -93,6 +93,16 @@ typedef struct vsd_conv_desc {
   void* workspace;
   int32_t pipeline;       /* main-loop form: 0 = register-staged double buffer; 3 or 4 = direct-to-LDS ring with
                              that many stages (global_load_lds, counted vmcnt) */
+  void* rowstat_out;      /* optional fp32 [M][n/64][2]: per output row, (sum, sum of squares) of the fp16 outputs over
+                             each 64-column group -- the LayerNorm statistics of the NEXT layer, for free */
+  const void* ln_part;    /* optional: fused LayerNorm of the A operand.  Row partials as written by the producer's
+                             rowstat_out, fp32 [M][ln_groups][2]; the weights must hold W*gamma, ln_s[n] = sum_k of
+                             those fp16 weights, ln_t[n] = sum_k beta[k] W[n][k] + bias[n] (fp32 [n], packed like the
+                             weights); then out = rstd*(acc - mean*ln_s) + ln_t replaces acc + bias.  1x1 layers only. */
+  int32_t ln_groups;
+  float ln_eps;
+  const void* ln_s;
+  const void* ln_t;
   void* counters;         /* optional: VSD_SPLITK_MAX_TILES int32, all zero.  When given, a split-K launch reduces
                              inside the kernel (the last workgroup to arrive at a tile sums the slabs in a fixed
                              order and runs the epilogue, leaving its counter at zero); when NULL a second

@@ -42,7 +42,7 @@ class FakeOps:
 
     def conv(self, src0, src1, g, w, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None, residual2=None,
              ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0, t_col0=0, tile=None,
-             split_k=None, workspace=None):
+             split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None, ln_eps=1e-5):
         c0 = c0 if c0 is not None else (w.cin - c1)
         x = self._nhwc(src0, g.hs, g.ws, c0)
         if src1 is not None and c1:
@@ -52,17 +52,27 @@ class FakeOps:
             x = F.interpolate(x, size=(g.hi, g.wi), mode="nearest")
         wt = w.weight[:, :w.k].float()
         bias = None if w.bias is None else w.bias.float()
+        ln_s, ln_t = w.ln_s, w.ln_t
+
+        def untile(v):  # GEGLU tile packing -> [hidden rows | gate rows]
+            f = w.n // 2
+            vv = v.reshape(f // 64, 2, 64, *v.shape[1:])
+            return torch.cat([vv[:, 0].reshape(f, *v.shape[1:]), vv[:, 1].reshape(f, *v.shape[1:])], dim=0)
+
         if w.geglu:
-            n = w.n
-            f = n // 2
-            wt = wt.reshape(f // 64, 2, 64, w.k)
-            wt = torch.cat([wt[:, 0].reshape(f, w.k), wt[:, 1].reshape(f, w.k)], dim=0)
-            bb = bias.reshape(f // 64, 2, 64)
-            bias = torch.cat([bb[:, 0].reshape(f), bb[:, 1].reshape(f)], dim=0)
+            wt = untile(wt)
+            bias = None if bias is None else untile(bias)
+            if ln_s is not None:
+                ln_s, ln_t = untile(ln_s), untile(ln_t)
         wt = wt.reshape(w.n, w.ksize, w.ksize, w.cin).permute(0, 3, 1, 2)
         y = F.conv2d(x, wt, bias, stride=g.stride, padding=g.pad)
         assert y.shape[2:] == (g.ho, g.wo), (y.shape, g)
         y = y[0].permute(1, 2, 0).reshape(g.m, w.n)
+        if ln_part is not None:
+            tot = ln_part.float().sum(dim=1)  # [M, 2]
+            mean = tot[:, 0] / w.k
+            rstd = torch.rsqrt((tot[:, 1] / w.k - mean * mean).clamp_min(0) + ln_eps)
+            y = rstd[:, None] * (y - mean[:, None] * ln_s.float()[None, :]) + ln_t.float()[None, :]
         if rowvec is not None:
             y = y + rowvec.float()[None, :]
         post = bool(act & L.ACT_POST)
@@ -97,6 +107,10 @@ class FakeOps:
         if post:
             y = fa(y)
         out[:, :nout] = y.half()
+        if rowstat_out is not None:
+            o = out[:, :nout].float().reshape(g.m, nout // 64, 64)
+            rowstat_out[:, :, 0] = o.sum(dim=2)
+            rowstat_out[:, :, 1] = (o * o).sum(dim=2)
         if out2 is not None:
             out2[:, :nout] = (y + add2[:, :nout].float()).half()
 

@@ -217,6 +217,53 @@ def test_geglu_fused(ops, tile):
     check(out, hid * F.gelu(gate), "geglu")
 
 
+@pytest.mark.parametrize("m,c", [(300, 320), (64, 1280), (1000, 128)])
+def test_fused_layernorm_producer_rowstats_and_consumer(ops, m, c):
+    """out1 GEMM leaves per-row (sum, sumsq); the next GEMM (QKV with V^T, GEGLU) applies LayerNorm from them."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_geglu_ln, pack_linear, pack_linear_ln
+
+    x = rnd(m, c, seed=1)
+    res = (rnd(m, c, seed=2).float() * 3 + 1.5).half()
+    w0, b0 = rnd(c, c, seed=3, scale=c ** -0.5), rnd(c, seed=4, scale=0.1)
+    p0 = ops.to_device_pack(pack_linear(w0, b0))
+    h = torch.zeros(m, c, dtype=torch.float16, device="cuda")
+    rs = torch.zeros(m, c // 64, 2, dtype=torch.float32, device="cuda")
+    for split in (1, 2):
+        ops.conv(x.cuda(), None, Geom.linear(m), p0, h, residual=res.cuda(), rowstat_out=rs, split_k=split, tile=2)
+        ops.synchronize()
+        href = F.linear(x.float(), w0.float(), b0.float()) + res.float()
+        check(h, href, "producer out")
+        hq = h.float().cpu()
+        tot = rs.sum(dim=1).cpu()
+        assert torch.allclose(tot[:, 0], hq.sum(dim=1), rtol=1e-4, atol=1e-2)
+        assert torch.allclose(tot[:, 1], (hq * hq).sum(dim=1), rtol=1e-4, atol=1e-2)
+    gamma, beta = (1 + 0.1 * rnd(c, seed=5).float()).half(), rnd(c, seed=6, scale=0.1)
+    ln = F.layer_norm(hq, (c,), gamma.float(), beta.float(), 1e-5)
+    # consumer 1: fused QKV with transposed V
+    wq, wk, wv = (rnd(c, c, seed=i, scale=c ** -0.5) for i in (7, 8, 9))
+    pq = ops.to_device_pack(pack_linear_ln([wq, wk, wv], None, gamma, beta))
+    ldt = (m + 63) // 64 * 64
+    qk = torch.zeros(m, 2 * c, dtype=torch.float16, device="cuda")
+    vt = torch.zeros(c, ldt, dtype=torch.float16, device="cuda")
+    for split, ink in ((1, True), (2, True), (2, False)):
+        ops.inkernel_splitk = ink
+        ops.conv(h, None, Geom.linear(m), pq, qk, ldo=2 * c, out_t=vt, ldt=ldt, t_col0=2 * c, ln_part=rs, split_k=split, tile=2)
+        ops.synchronize()
+        check(qk[:, :c], F.linear(ln, wq.float()), f"ln->q split={split}", rel=3e-3)
+        check(qk[:, c:], F.linear(ln, wk.float()), f"ln->k split={split}", rel=3e-3)
+        check(vt[:, :m], F.linear(ln, wv.float()).t(), f"ln->v^T split={split}", rel=3e-3)
+    ops.inkernel_splitk = True
+    # consumer 2: GEGLU
+    wf, bf = rnd(8 * c, c, seed=10, scale=c ** -0.5), rnd(8 * c, seed=11, scale=0.1)
+    pf = ops.to_device_pack(pack_geglu_ln(wf, bf, gamma, beta))
+    f = torch.zeros(m, 4 * c, dtype=torch.float16, device="cuda")
+    ops.conv(h, None, Geom.linear(m), pf, f, ln_part=rs)
+    ops.synchronize()
+    hid, gate = F.linear(ln, wf.float(), bf.float()).chunk(2, dim=-1)
+    check(f, hid * F.gelu(gate), "ln->geglu", rel=3e-3)
+
+
 def test_qkv_transposed_output_and_dual_output(ops):
     from videosd_amd.ops import Geom
     from videosd_amd.packing import pack_linear_cat

@@ -45,13 +45,19 @@ struct ConvParams {
   int ldt, t_col0;
   int split_k, kt_per_split;
   float* ws_partial;
+  float* rowstat_out;    // [M][N/64][2]: per-row (sum, sumsq) of the fp16 outputs over each 64-column group
+  const float* ln_part;  // fused input LayerNorm: row partials of the A operand, [M][ln_groups][2]
+  int ln_groups;
+  float ln_eps;
+  const float* ln_s;     // [N] sum_k W'[n][k]  (W' = W * gamma)
+  const float* ln_t;     // [N] sum_k beta[k] W[n][k] + bias[n]
   const half_t* zeros;  // >= 16 zero bytes: source of out-of-bounds chunks for the direct-to-LDS loader
   int* counters;  // per-tile arrival tickets for the in-kernel split-K reduction (all zero between launches)
   int tiles_m, tiles_n;
 };
 
 // ---------------------------------------------------------------- epilogue (shared with the reducer)
-__device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int n, float (&v)[8]) {
+__device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int n, float (&v)[8], float& rsum, float& rsq) {
   // n is a multiple of 8; handles n + 8 > N by scalar fallback
   const bool full = (n + 8 <= p.N);
   if (p.bias) {
@@ -115,7 +121,12 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
     }
     half8 o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (half_t)v[i];
+    for (int i = 0; i < 8; ++i) {
+      o[i] = (half_t)v[i];
+      float f = (float)o[i];
+      rsum += f;
+      rsq += f * f;
+    }
     *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
     if (p.out2) {
       half8 a = *reinterpret_cast<const half8*>(p.add2 + (size_t)m * p.ldo + n);
@@ -134,6 +145,46 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
       p.out[(size_t)m * p.ldo + n + i] = (half_t)x;
       if (p.out2) p.out2[(size_t)m * p.ldo + n + i] = (half_t)(x + (float)p.add2[(size_t)m * p.ldo + n + i]);
     }
+  }
+}
+
+// Fused input LayerNorm: the GEMM ran on the raw rows x with W' = W*gamma, so
+//   LN(x) W^T + b = rstd * (x W'^T - mean * s) + t,   s[n] = sum_k W'[n][k],  t[n] = sum_k beta[k] W[n][k] + b[n].
+// Row mean / rstd come from the (sum, sumsq) partials the producing kernel's epilogue left per 64-column group.
+__device__ __forceinline__ void ln_row_stats(const ConvParams& p, int m, float& mean, float& rstd) {
+  // partials of one row are contiguous: [M][ln_groups][2]; ln_groups is a multiple of... anything >= 1
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2* src = reinterpret_cast<const f32x2*>(p.ln_part) + (size_t)m * p.ln_groups;
+  float S = 0.f, Q = 0.f;
+  int g = 0;
+  for (; g + 4 <= p.ln_groups; g += 4) {  // four independent loads in flight
+    f32x2 a = src[g], b = src[g + 1], c = src[g + 2], d = src[g + 3];
+    S += a[0]; Q += a[1];
+    S += b[0]; Q += b[1];
+    S += c[0]; Q += c[1];
+    S += d[0]; Q += d[1];
+  }
+  for (; g < p.ln_groups; ++g) {
+    f32x2 a = src[g];
+    S += a[0]; Q += a[1];
+  }
+  const float inv = 1.0f / (float)p.K;
+  mean = S * inv;
+  rstd = rsqrtf(fmaxf(Q * inv - mean * mean, 0.f) + p.ln_eps);
+}
+__device__ __forceinline__ void ln_transform8(const ConvParams& p, int n, float mean, float rstd, float (&v)[8]) {
+  if (n + 8 <= p.N) {
+    f32x4 s0 = *reinterpret_cast<const f32x4*>(p.ln_s + n), s1 = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4);
+    f32x4 t0 = *reinterpret_cast<const f32x4*>(p.ln_t + n), t1 = *reinterpret_cast<const f32x4*>(p.ln_t + n + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = rstd * (v[i] - mean * s0[i]) + t0[i];
+      v[4 + i] = rstd * (v[4 + i] - mean * s1[i]) + t1[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (n + i < p.N) v[i] = rstd * (v[i] - mean * p.ln_s[n + i]) + p.ln_t[n + i];
   }
 }
 
@@ -191,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   constexpr int STAGE_BYTES = NBUF * STAGE_HALFS * 2;
   constexpr int EPI_BYTES = BM * BNP * 4;
   constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + BM * 8];  // + per-row (mean, rstd) of a fused LN
   half_t* As = reinterpret_cast<half_t*>(smem);                                        // register path: [2][BM][64]
   half_t* Bs = reinterpret_cast<half_t*>(smem) + 2 * BM * BK;                          //                [2][BN][64]
 
@@ -297,13 +348,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  float* rowms = reinterpret_cast<float*>(smem + LDS_BYTES);  // per-row (mean, rstd) of a fused input LayerNorm
+// issued right after the prologue tile loads so that its memory latency overlaps theirs
+#define VSD_LN_ROWSTATS()                                              \
+  if (p.ln_part && tid < BM) {                                         \
+    float mean = 0.f, rstd = 0.f;                                      \
+    if (m0 + tid < p.M) ln_row_stats(p, m0 + tid, mean, rstd);         \
+    rowms[2 * tid] = mean;                                             \
+    rowms[2 * tid + 1] = rstd;                                         \
+  }
   const int fr = lane & 15;  // fragment row (A) / column (B)
   const int fq = lane >> 4;  // k-chunk quarter
 
   if constexpr (STAGES == 0) {
     if (kt_begin < kt_end) {
       VSD_LOAD_TILE(kt_begin)
+      VSD_LN_ROWSTATS()
       VSD_STORE_TILE(0)
+    } else {
+      VSD_LN_ROWSTATS()
     }
     __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -383,6 +446,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int st = 0; st < STAGES - 1; ++st)
       if (st < nt) VSD_ISSUE_TILE(kt_begin + st, st)
+    VSD_LN_ROWSTATS()
     int slot = 0;
     for (int t = 0; t < nt; ++t) {
       // tile t has landed once all but the younger tiles' loads are done; then everyone's has (barrier)
@@ -425,6 +489,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 
   // ---- epilogue: accumulators -> LDS (fp32) -> row-contiguous 8-wide chunks
   float* Cs = reinterpret_cast<float*>(smem);
+
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -501,14 +566,29 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       int m = m0 + r;
       if (m >= p.M) continue;
       const float* s = Cs + r * BNP + c8;
-      half8 bh = *reinterpret_cast<const half8*>(p.bias + n0 + c8);
-      half8 bg = *reinterpret_cast<const half8*>(p.bias + n0 + BN / 2 + c8);
       half8 o;
+      if (p.ln_part) {
+        const float mean = rowms[2 * r], rstd = rowms[2 * r + 1];
+        const int nh = n0 + c8, ng = n0 + BN / 2 + c8;
+        float hv[8], gv[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float h = s[i] + (float)bh[i];
-        float g = s[BN / 2 + i] + (float)bg[i];
-        o[i] = (half_t)(h * gelu_erf_f(g));
+        for (int i = 0; i < 8; ++i) {
+          hv[i] = s[i];
+          gv[i] = s[BN / 2 + i];
+        }
+        ln_transform8(p, nh, mean, rstd, hv);
+        ln_transform8(p, ng, mean, rstd, gv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (half_t)(hv[i] * gelu_erf_f(gv[i]));
+      } else {
+        half8 bh = *reinterpret_cast<const half8*>(p.bias + n0 + c8);
+        half8 bg = *reinterpret_cast<const half8*>(p.bias + n0 + BN / 2 + c8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float h = s[i] + (float)bh[i];
+          float g = s[BN / 2 + i] + (float)bg[i];
+          o[i] = (half_t)(h * gelu_erf_f(g));
+        }
       }
       int n = (n0 >> 1) + c8;
       if (n < no) *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
@@ -531,17 +611,36 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = Cs[r * BNP + c8 + i];
       }
-      epilogue_store8(p, m, n, v);
+      if (p.ln_part) ln_transform8(p, n, rowms[2 * r], rowms[2 * r + 1], v);
+      float rs = 0.f, rq = 0.f;
+      epilogue_store8(p, m, n, v, rs, rq);
     }
   } else {
     constexpr int CH = BN / 8;
-    for (int q = tid; q < BM * CH; q += 256) {
+    for (int q = tid; q < BM * CH; q += 256) {  // BM*CH is a multiple of 256: every lane runs every iteration
       int r = q / CH, c8 = (q - r * CH) * 8;
       int m = m0 + r, n = n0 + c8;
-      if (m >= p.M || n >= p.N) continue;
-      float v[8];
-      load_chunk8(p, Cs, BNP, from_slabs, r, c8, m, n, v);
-      epilogue_store8(p, m, n, v);
+      const bool valid = m < p.M && n < p.N;
+      float rs = 0.f, rq = 0.f;
+      if (valid) {
+        float v[8];
+        load_chunk8(p, Cs, BNP, from_slabs, r, c8, m, n, v);
+        if (p.ln_part) ln_transform8(p, n, rowms[2 * r], rowms[2 * r + 1], v);
+        epilogue_store8(p, m, n, v, rs, rq);
+      }
+      if (p.rowstat_out) {
+        // the 8 lanes of one (row, 64-column group) are consecutive: fold their sums and let the first write
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+          rs += __shfl_xor(rs, o);
+          rq += __shfl_xor(rq, o);
+        }
+        if ((tid & 7) == 0 && valid) {
+          float* dst = p.rowstat_out + ((size_t)m * (p.N >> 6) + (n >> 6)) * 2;
+          dst[0] = rs;
+          dst[1] = rq;
+        }
+      }
     }
   }
 }
@@ -573,7 +672,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
           if (n + i < p.N) v[i] += s[k * slab + i];
       }
     }
-    epilogue_store8(p, m, n, v);
+    if (p.ln_part) {
+      float mean, rstd;
+      ln_row_stats(p, m, mean, rstd);
+      ln_transform8(p, n, mean, rstd, v);
+    }
+    float rs = 0.f, rq = 0.f;
+    epilogue_store8(p, m, n, v, rs, rq);
   }
 }
 
@@ -621,6 +726,12 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.ws_partial = (float*)d->workspace;
   p.counters = (int*)d->counters;
   p.zeros = (const half_t*)ctx->zero_page;
+  p.rowstat_out = (float*)d->rowstat_out;
+  p.ln_part = (const float*)d->ln_part;
+  p.ln_groups = d->ln_groups;
+  p.ln_eps = d->ln_eps;
+  p.ln_s = (const float*)d->ln_s;
+  p.ln_t = (const float*)d->ln_t;
   const int stages = d->pipeline;
   if (stages != 0 && stages != 3 && stages != 4) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3 or 4)", stages);
 
@@ -633,6 +744,10 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   if (p.ksize != 1 && p.ksize != 3) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: ksize %d", p.ksize);
   if (p.ldo % 8 || (p.residual && p.ldr % 8)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: ld must be a multiple of 8");
   if (p.out2 && !p.add2) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: out2 without add2");
+  if (p.rowstat_out && (p.N % 64 || p.out_t || (p.split_k > 1 && !d->counters)))
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: rowstat_out needs N %% 64 == 0, no transposed output and the in-kernel split-K form");
+  if (p.ln_part && (p.ksize != 1 || !p.ln_s || !p.ln_t || p.ln_groups <= 0 || p.bias))
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: fused LayerNorm needs a 1x1 layer, ln_s/ln_t and no separate bias");
   if (p.split_k > 1 && !p.ws_partial) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: split_k needs a workspace");
   int BM, BN;
   switch (d->tile) {
@@ -643,7 +758,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     default: return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: tile %d", d->tile);
   }
   if ((p.act & 0xff) == VSD_ACT_GEGLU) {
-    if (BN != 128 || p.N % 128 || p.split_k != 1 || !p.bias || p.out_t)
+    if (BN != 128 || p.N % 128 || p.split_k != 1 || (!p.bias && !p.ln_part) || p.out_t)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: GEGLU needs BN=128, N %% 128 == 0, bias, no split-K");
   }
   if (p.out_t && (p.t_col0 % BN)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: t_col0 must be a multiple of BN");

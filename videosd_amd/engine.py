@@ -25,7 +25,7 @@ from . import lib as L
 from .config import ControlNetConfig, TAESDConfig, UNetConfig
 from .lcm import LCMSchedule, timestep_sinusoid, w_embedding
 from .ops import Geom
-from .packing import PackedConv, pack_conv, pack_geglu, pack_linear, pack_linear_cat
+from .packing import PackedConv, pack_conv, pack_geglu_ln, pack_linear, pack_linear_cat, pack_linear_ln
 from .weights import skip_channels
 
 
@@ -105,15 +105,12 @@ class TransformerW:
     c: int
     norm: Tuple[torch.Tensor, torch.Tensor]
     proj_in: PackedConv
-    ln1: Tuple[torch.Tensor, torch.Tensor]
-    qkv: PackedConv
+    qkv: PackedConv            # LayerNorm norm1 folded in (pack_linear_ln)
     out1: PackedConv
-    ln2: Tuple[torch.Tensor, torch.Tensor]
-    q2: PackedConv
+    q2: PackedConv             # norm2 folded in
     kv2: PackedConv
     out2: PackedConv
-    ln3: Tuple[torch.Tensor, torch.Tensor]
-    ff1: PackedConv
+    ff1: PackedConv            # norm3 folded in, GEGLU tile-packed
     ff2: PackedConv
     proj_out: PackedConv
     kv_index: int              # slot in the per-prompt cross-attention K / V^T cache
@@ -188,9 +185,10 @@ class NetWeights:
 
     # --- helpers
     def _to_dev(self, p: PackedConv) -> PackedConv:
-        p.weight = self.ops.to_device(p.weight)
-        if p.bias is not None:
-            p.bias = self.ops.to_device(p.bias)
+        for f in ("weight", "bias", "ln_s", "ln_t"):
+            v = getattr(p, f)
+            if v is not None:
+                setattr(p, f, self.ops.to_device(v.contiguous()))
         return p
 
     def _conv(self, name, cin_pad=None, with_bias=True) -> PackedConv:
@@ -218,14 +216,15 @@ class NetWeights:
     def _transformer(self, p, c) -> TransformerW:
         w = self._w
         b = p + ".transformer_blocks.0"
-        qkv = self._to_dev(pack_linear_cat([w[f"{b}.attn1.to_q.weight"], w[f"{b}.attn1.to_k.weight"],
-                                            w[f"{b}.attn1.to_v.weight"]]))
+        ln = lambda n: (w[f"{b}.{n}.weight"], w[f"{b}.{n}.bias"])  # noqa: E731
+        qkv = self._to_dev(pack_linear_ln([w[f"{b}.attn1.to_q.weight"], w[f"{b}.attn1.to_k.weight"],
+                                           w[f"{b}.attn1.to_v.weight"]], None, *ln("norm1")))
+        q2 = self._to_dev(pack_linear_ln([w[f"{b}.attn2.to_q.weight"]], None, *ln("norm2")))
         kv2 = self._to_dev(pack_linear_cat([w[f"{b}.attn2.to_k.weight"], w[f"{b}.attn2.to_v.weight"]]))
-        t = TransformerW(c, self._norm(p + ".norm"), self._conv(p + ".proj_in"), self._norm(b + ".norm1"), qkv,
-                         self._lin(b + ".attn1.to_out.0"), self._norm(b + ".norm2"), self._lin(b + ".attn2.to_q"), kv2,
-                         self._lin(b + ".attn2.to_out.0"), self._norm(b + ".norm3"),
-                         self._to_dev(pack_geglu(w[f"{b}.ff.net.0.proj.weight"], w[f"{b}.ff.net.0.proj.bias"])),
-                         self._lin(b + ".ff.net.2"), self._conv(p + ".proj_out"), len(self.transformers))
+        ff1 = self._to_dev(pack_geglu_ln(w[f"{b}.ff.net.0.proj.weight"], w[f"{b}.ff.net.0.proj.bias"], *ln("norm3")))
+        t = TransformerW(c, self._norm(p + ".norm"), self._conv(p + ".proj_in"), qkv, self._lin(b + ".attn1.to_out.0"),
+                         q2, kv2, self._lin(b + ".attn2.to_out.0"), ff1, self._lin(b + ".ff.net.2"),
+                         self._conv(p + ".proj_out"), len(self.transformers))
         self.transformers.append(t)
         return t
 
@@ -362,31 +361,33 @@ class Engine:
         lin = Geom.linear(hw)
         t = a.alloc(hw, c)
         r.groupnorm(x, None, c, 0, hw, cfg.groups, 1e-6, tw.norm[0], tw.norm[1], False, t)
+        # The three LayerNorms are never materialised: every producer of the token stream leaves per-row
+        # (sum, sumsq) partials (rowstat_out) and the consuming GEMM applies the norm in its epilogue (ln_part).
+        ng = c // 64
         h = a.alloc(hw, c)
-        r.conv(t, None, lin, tw.proj_in, h)
+        rs = a.alloc(hw, ng * 2, dtype=torch.float32).view(hw, ng, 2)
+        r.conv(t, None, lin, tw.proj_in, h, rowstat_out=rs)
         # self-attention
-        n = a.alloc(hw, c)
-        r.layernorm(h, hw, c, tw.ln1[0], tw.ln1[1], 1e-5, n)
         qk = a.alloc(hw, 2 * c)
         ldvt = _ru(hw, 64)
         vt = self._vt_buffer(c, ldvt)
-        r.conv(n, None, lin, tw.qkv, qk, ldo=2 * c, out_t=vt, ldt=ldvt, t_col0=2 * c)
+        r.conv(h, None, lin, tw.qkv, qk, ldo=2 * c, out_t=vt, ldt=ldvt, t_col0=2 * c, ln_part=rs)
         att = a.alloc(hw, c)
         r.attention(qk, 2 * c, qk[:, c:], 2 * c, vt, ldvt, att, c, hw, hw, heads, d, d ** -0.5)
         h1 = a.alloc(hw, c)
-        r.conv(att, None, lin, tw.out1, h1, residual=h)
+        rs1 = a.alloc(hw, ng * 2, dtype=torch.float32).view(hw, ng, 2)
+        r.conv(att, None, lin, tw.out1, h1, residual=h, rowstat_out=rs1)
         # cross-attention over the cached text K / V^T
-        r.layernorm(h1, hw, c, tw.ln2[0], tw.ln2[1], 1e-5, n)
         q = a.alloc(hw, c)
-        r.conv(n, None, lin, tw.q2, q)
+        r.conv(h1, None, lin, tw.q2, q, ln_part=rs1)
         kt, vtt = net.kv_cache[tw.kv_index]
         r.attention(q, c, kt, c, vtt, vtt.shape[1], att, c, hw, kt.shape[0], heads, d, d ** -0.5)
         h2 = a.alloc(hw, c)
-        r.conv(att, None, lin, tw.out2, h2, residual=h1)
+        rs2 = a.alloc(hw, ng * 2, dtype=torch.float32).view(hw, ng, 2)
+        r.conv(att, None, lin, tw.out2, h2, residual=h1, rowstat_out=rs2)
         # GEGLU feed-forward
-        r.layernorm(h2, hw, c, tw.ln3[0], tw.ln3[1], 1e-5, n)
         f = a.alloc(hw, 4 * c)
-        r.conv(n, None, lin, tw.ff1, f)
+        r.conv(h2, None, lin, tw.ff1, f, ln_part=rs2)
         h3 = a.alloc(hw, c)
         r.conv(f, None, lin, tw.ff2, h3, residual=h2)
         out = a.alloc(hw, c)
@@ -568,7 +569,7 @@ class Engine:
         for fn, a, k in self.program.calls:
             if fn.__name__ != "conv":
                 continue
-            key = ops.conv_key(a[2], a[3], k.get("t_col0", 0))
+            key = ops.conv_key(a[2], a[3], k.get("t_col0", 0), k.get("rowstat_out") is not None)
             if key in seen or key in ops.tile_override or k.get("tile") is not None:
                 continue
             best, table = ops.tune_conv(a, k)

@@ -34,6 +34,8 @@ class ConvDesc(C.Structure):
         ("tile", C.c_int32), ("split_k", C.c_int32),
         ("workspace", C.c_void_p),
         ("pipeline", C.c_int32),
+        ("rowstat_out", C.c_void_p), ("ln_part", C.c_void_p), ("ln_groups", C.c_int32), ("ln_eps", C.c_float),
+        ("ln_s", C.c_void_p), ("ln_t", C.c_void_p),
         ("counters", C.c_void_p),
     ]
 

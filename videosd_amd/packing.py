@@ -19,6 +19,8 @@ class PackedConv:
     cin: int                        # (padded) input channels per tap
     ksize: int
     geglu: bool = False
+    ln_s: Optional[torch.Tensor] = None   # fp32 [n]: sum_k (W*gamma)[n][k]   (fused input LayerNorm, include/vsd.h)
+    ln_t: Optional[torch.Tensor] = None   # fp32 [n]: sum_k beta[k] W[n][k] + bias[n]
 
     @property
     def n_out(self) -> int:
@@ -73,3 +75,45 @@ def pack_geglu(weight: torch.Tensor, bias: torch.Tensor) -> PackedConv:
     w = torch.stack([wh, wg], dim=1).reshape(n, k)
     b = torch.stack([bias[:f].reshape(f // 64, 64), bias[f:].reshape(f // 64, 64)], dim=1).reshape(n)
     return _finish(w, b, k, 1, geglu=True)
+
+
+def _fold_ln(weight: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.Tensor):
+    """LN(x) W^T + b == rstd * (x (W*gamma)^T - mean * s) + t  with s, t as below.  s is summed over the SAME
+    fp16-rounded values the GEMM multiplies with, so that a constant row (x = mean) cancels exactly."""
+    w32, g, b = weight.float(), gamma.float(), beta.float()
+    wp = (w32 * g[None, :]).to(torch.float16)
+    s = wp.float().sum(dim=1)
+    t = (w32 * b[None, :]).sum(dim=1)
+    if bias is not None:
+        t = t + bias.float()
+    return wp, s, t
+
+
+def pack_linear_ln(weights, biases, gamma, beta) -> PackedConv:
+    """Row-concatenated linears that consume LayerNorm(x): the norm is folded into weights + epilogue vectors."""
+    w = torch.cat(list(weights), dim=0)
+    b = None
+    if biases is not None:
+        b = torch.cat([bi if bi is not None else torch.zeros(wi.shape[0], dtype=wi.dtype, device=wi.device)
+                       for wi, bi in zip(weights, biases)], dim=0)
+    wp, s, t = _fold_ln(w, b, gamma, beta)
+    p = _finish(wp, None, w.shape[1], 1)
+    p.ln_s, p.ln_t = s.contiguous(), t.contiguous()
+    return p
+
+
+def pack_geglu_ln(weight: torch.Tensor, bias: torch.Tensor, gamma, beta) -> PackedConv:
+    n, k = weight.shape
+    f = n // 2
+    assert f % 64 == 0
+    wp, s, t = _fold_ln(weight, bias, gamma, beta)
+
+    def tile(x):  # [n, ...] -> 64 hidden rows then their 64 gate rows per 128-row tile
+        tail = x.shape[1:]
+        h = x[:f].reshape(f // 64, 64, *tail)
+        g = x[f:].reshape(f // 64, 64, *tail)
+        return torch.stack([h, g], dim=1).reshape(n, *tail)
+
+    p = _finish(tile(wp), None, k, 1, geglu=True)
+    p.ln_s, p.ln_t = tile(s).contiguous(), tile(t).contiguous()
+    return p
