@@ -1,0 +1,32 @@
+"""TEST-ONLY pipeline stand-ins used to exercise videosd_amd.dispatch without a GPU."""
+import time
+
+import numpy as np
+from PIL import Image
+
+
+class FakePipeline:
+    """Same `infer` surface as VideoSDPipeline; 'diffusion' = invert the image after an optional delay."""
+
+    def __init__(self, **config):
+        if "model" not in config or "controlnet" not in config:
+            raise KeyError("model")
+        self.device = config.get("device", 0)
+        self.delay = float(config.get("delay", 0.0))
+        self.prompt = None
+
+    def infer(self, img, prompt=["pixar, cg"], height=360, width=640, strength=0.4, steps=20, guidance_scale=7.5, ref=False,
+              style_fidelity=0.0, controlnet=False, seed=42, controlnet_scale=1):
+        if strength < 0:
+            raise ValueError("negative strength")
+        time.sleep(self.delay)
+        a = 255 - np.asarray(img.convert("RGB").resize((width, height)))
+        a[0, 0, 0] = self.device  # tag the worker that produced the frame
+        return Image.fromarray(a.astype(np.uint8), "RGB")
+
+    def compile_model(self):
+        return Image.new("RGB", (8, 8))
+
+    def set_prompt_embeds(self, embeds, key=None):
+        self.prompt = float(embeds.float().sum())
+        return self.prompt

@@ -1,0 +1,46 @@
+"""The C-ABI library loads (no GPU needed) and exports every function include/vsd.h declares; the ctypes
+struct mirrors the C struct field for field."""
+import ctypes
+import os
+import re
+
+from videosd_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header():
+    return open(os.path.join(ROOT, "include", "vsd.h")).read()
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    if not os.path.exists(L.LIB_PATH):
+        from videosd_amd import build
+
+        build.build(verbose=False)
+    lib = L.load()
+    declared = set(re.findall(r"\b(vsd_[a-z0-9_]+)\s*\(", _header()))
+    assert len(declared) >= 20
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vsd_version() == 1
+    assert lib.vsd_create(10_000) is None  # no such device -> NULL, never aborts
+
+
+def test_conv_desc_struct_matches_header_field_order():
+    body = re.search(r"typedef struct vsd_conv_desc \{(.*?)\} vsd_conv_desc;", _header(), re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.replace("*", " ").split()
+        typ_is_ptr = "*" in decl
+        for n in decl.split(",") if "," in decl else [decl]:
+            nm = n.replace("*", " ").split()[-1]
+            fields.append((nm, typ_is_ptr))
+    got = [(n, issubclass(t, ctypes.c_void_p) or t is ctypes.c_void_p) for n, t in L.ConvDesc._fields_]
+    assert [f[0] for f in fields] == [g[0] for g in got]
+    assert fields == got

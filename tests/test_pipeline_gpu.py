@@ -116,3 +116,22 @@ def test_sd15_width_pipeline_matches_oracle():
     assert np.array_equal(a, eng.infer_u8(f))
     assert torch.isfinite(eng.buffers["denoised"].float()).all()
     assert a.std() > 1.0
+
+
+@pytest.mark.parametrize("cfg_name", ["MINI_CLIP", "CLIP_L"])
+def test_clip_text_encoder_matches_oracle(cfg_name):
+    """CLIP text encoder on the HIP kernels vs the oracle restatement (itself pinned against transformers)."""
+    from oracle import nets
+    from videosd_amd import config as C
+    from videosd_amd import weights as W
+    from videosd_amd.clip import ClipTextEncoder
+    from videosd_amd.ops import HipOps
+
+    cfg = getattr(C, cfg_name)
+    w = W.synthesize(W.clip_spec(cfg), "clip.", device="cuda")
+    enc = ClipTextEncoder(HipOps(0), cfg, w)
+    ids = torch.randint(0, cfg.vocab, (cfg.max_len,), generator=torch.Generator().manual_seed(3))
+    got = enc.encode_ids(ids).float().cpu()
+    ref = nets.clip_text_forward({k: v.cpu() for k, v in w.items()}, cfg, ids[None])[0]
+    rel = float((got - ref).norm() / ref.norm())
+    assert torch.isfinite(got).all() and rel <= 1e-2, rel

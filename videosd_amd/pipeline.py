@@ -1,0 +1,150 @@
+"""VideoSDPipeline — the reference's per-GPU worker class, re-hosted on the MI355X engine.
+
+Mirrors /root/reference/diffusert/videopipeline.py:11-128: same constructor kwargs (`model`, `controlnet`
+required, `device` optional, extras such as `gpus` / `compile` ignored), same `infer` signature and
+defaults, same `load_model` / `compile_model` methods, so diffusert/server.py:104-117,317-321 can drive it
+unchanged (`VideoSDPipeline.remote(**config)` and `await pipelines[gpu].infer.remote(img, **options)` are
+provided by videosd_amd/dispatch.py without Ray).
+
+What differs underneath: no diffusers / TensorRT / torch.compile; the frame goes through
+videosd_amd.engine.Engine (libvsd.so HIP kernels replayed as one hipGraph).
+"""
+import os
+import zlib
+from typing import Dict, List, Optional, Union
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import config as C
+from . import weights as W
+
+
+def center_crop_resize(img: Image.Image, width: int, height: int) -> Image.Image:
+    """Center crop to the target aspect ratio (float box) and LANCZOS-resize: videopipeline.py:92-107."""
+    if img.width / img.height > width / height:
+        new_width = img.height * (width / height)
+        box = ((img.width - new_width) / 2, 0, (img.width + new_width) / 2, img.height)
+    else:
+        new_height = img.width * (height / width)
+        box = (0, (img.height - new_height) / 2, img.width, (img.height + new_height) / 2)
+    return img.crop(box).resize((width, height), resample=Image.Resampling.LANCZOS)
+
+
+def _weights_dir() -> Optional[str]:
+    d = os.environ.get("VSD_WEIGHTS")
+    return d if d and os.path.isdir(d) else None
+
+
+def load_or_synthesize(spec, prefix: str, filename: str, device) -> Dict[str, torch.Tensor]:
+    """Real safetensors (diffusers key names) from $VSD_WEIGHTS/<filename> when present, else seeded synthetic."""
+    d = _weights_dir()
+    if d and os.path.exists(os.path.join(d, filename)):
+        w = W.load_safetensors(os.path.join(d, filename), device=device)
+        missing = [n for n, _, _ in spec if n not in w]
+        if missing:
+            raise KeyError(f"{filename}: missing tensors {missing[:4]}...")
+        return w
+    return W.synthesize(spec, prefix, device=device)
+
+
+class VideoSDPipeline:
+    """One instance = one GPU = one full weight replica (the reference's Ray actor with num_gpus=1)."""
+
+    def __init__(self, *args, **kwargs):
+        self.device = kwargs.get("device", 0)
+        self.honor_controlnet_flag = bool(kwargs.get("honor_controlnet_flag", False))  # extension, off by default
+        try:
+            self.load_model(kwargs["model"], kwargs["controlnet"])
+        except KeyError:
+            print("Model name and controlnet model must be specified")  # videopipeline.py:24-26
+            raise
+        self._prompt_key = None
+        self._plan_key = None
+
+    # ------------------------------------------------------------------ model loading
+    def load_model(self, model_name, controlnet_model="lllyasviel/control_v11p_sd15_canny"):
+        """videopipeline.py:49-72.  Like the reference, `model_name` is accepted but the UNet is always the
+        LCM-distilled SD1.5 UNet (the reference hard-codes SimianLuo/LCM_Dreamshaper_v7), the VAE is TAESD and
+        the ControlNet is SD1.5-canny."""
+        from .engine import Engine
+        from .ops import HipOps  # raises without a ROCm GPU / libvsd.so: there is no CPU path
+
+        ops = HipOps(int(self.device))
+        dev = ops.device
+        wu = load_or_synthesize(W.unet_spec(C.SD15_UNET), "unet.", "unet.safetensors", dev)
+        wc = load_or_synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", "controlnet.safetensors", dev)
+        wv = load_or_synthesize(W.taesd_spec(C.TAESD), "vae.", "taesd.safetensors", dev)
+        self.model = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
+        self.text_encoder = None
+        d = _weights_dir()
+        if d and os.path.exists(os.path.join(d, "text_encoder.safetensors")):
+            from .clip import ClipTextEncoder
+
+            self.text_encoder = ClipTextEncoder(ops, C.CLIP_L, W.load_safetensors(os.path.join(d, "text_encoder.safetensors"),
+                                                                               device=dev))
+        return self.model
+
+    def compile_model(self):
+        """videopipeline.py:35-47: build the replayable graph and run the 768x768 warm-up frame."""
+        return self.infer(Image.new("RGB", (768, 768)), prompt="warmup", height=768, width=768, strength=0.8, steps=4)
+
+    # ------------------------------------------------------------------ prompt
+    def encode_prompt(self, prompt: Union[str, List[str]]) -> torch.Tensor:
+        """[77, 768] fp16 embeddings.  With CLIP weights + tokenizer files under $VSD_WEIGHTS the HIP CLIP encoder
+        runs; otherwise (no vocabulary offline) a deterministic stand-in seeded by the prompt text is used."""
+        text = prompt if isinstance(prompt, str) else " ".join(prompt)
+        if self.text_encoder is not None and self.text_encoder.has_tokenizer:
+            return self.text_encoder.encode(text)
+        g = torch.Generator().manual_seed(zlib.crc32(text.encode()))
+        return (torch.randn(77, C.SD15_UNET.cross_dim, generator=g) * 0.5).half()
+
+    def set_prompt_embeds(self, embeds: torch.Tensor, key=None):
+        """Install embeddings produced elsewhere (rank 0 broadcasts them over RCCL, dispatch.py)."""
+        self.model.set_text_embeds(embeds)
+        self._prompt_key = key
+
+    # ------------------------------------------------------------------ per frame
+    def infer(
+        self,
+        img,
+        prompt=["pixar, cg"],
+        height=360,
+        width=640,
+        strength=0.4,
+        steps=20,
+        guidance_scale=7.5,
+        ref=False,
+        style_fidelity=0.0,
+        controlnet=False,
+        seed=42,
+        controlnet_scale=1,
+    ):
+        """Same contract as videopipeline.py:75-128.  `guidance_scale`, `ref`, `style_fidelity` and
+        `controlnet` are accepted and ignored exactly like the reference (ControlNet always runs; 7.5 is baked
+        in); `seed` does not change the result because the reference resets the CPU generator state per frame."""
+        img = center_crop_resize(img, width, height)
+        pkey = prompt if isinstance(prompt, str) else tuple(prompt)
+        if pkey != self._prompt_key:
+            self.model.set_text_embeds(self.encode_prompt(prompt))
+            self._prompt_key = pkey
+        use_cn = bool(controlnet) if self.honor_controlnet_flag else True
+        plan_key = (height, width, int(steps), float(strength), float(controlnet_scale), use_cn)
+        if plan_key != self._plan_key:
+            self.model.prepare(height, width, int(steps), float(strength), controlnet_scale=float(controlnet_scale),
+                               use_controlnet=use_cn)
+            self._plan_key = plan_key
+        np.random.seed(seed)  # kept for parity with videopipeline.py:112 (nothing downstream consumes it)
+        out = self.model.infer_u8(np.asarray(img.convert("RGB"), dtype=np.uint8))
+        return Image.fromarray(out, mode="RGB")
+
+    # `VideoSDPipeline.remote(**config)` -> awaitable handle (replaces the Ray actor API, server.py:320-321)
+    @classmethod
+    def remote(cls, **config):
+        from .dispatch import RemotePipeline
+
+        return RemotePipeline(**config)
+
+
+VideoPipeline = VideoSDPipeline  # BASELINE.json's north_star calls the class by this name
