@@ -29,6 +29,15 @@ class FakeOps:
     def synchronize(self):
         pass
 
+    def use_stream(self, idx):
+        pass
+
+    def fork(self):
+        pass
+
+    def join(self):
+        pass
+
     def upload(self, dst, src):
         dst.copy_(src.view(dst.shape))
 

@@ -136,7 +136,7 @@ def test_splitk_inkernel_reduction_is_bit_identical_to_reduce_kernel(ops):
         outs.append(got)
     ops.inkernel_splitk = True
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    assert int(ops._counters.abs().sum()) == 0  # every tile's arrival counter is back at zero
+    assert int(ops._counters[0].abs().sum()) == 0  # every tile's arrival counter is back at zero
 
 
 def test_conv3x3_sd_width_deep_k(ops):

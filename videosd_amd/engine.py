@@ -404,57 +404,51 @@ class Engine:
             self._vt_pool[key] = buf
         return buf
 
-    def _down_mid(self, r, net: NetWeights, step, h, sizes, cn_res=None, cn_mid=None):
-        """conv_in output h -> (mid output, skip list).  With cn_res (UNet + ControlNet) every skip is
-        produced together with skip + residual through the producing conv's second output."""
+    def _down_mid(self, r, net: NetWeights, step, h, sizes):
+        """conv_in output h -> (mid block output, skip list [(tensor, channels, level)])."""
         a = self.arena
         ch = net.cfg.block_out_channels
         skips = []
-        k = 1  # skip 0 is conv_in's output (handled by the caller)
         for i, c in enumerate(ch):
             hh, ww = sizes[i]
             hw = hh * ww
             g3 = Geom.conv(hh, ww)
             for j, (rw, tw) in enumerate(net.down[i]):
-                cin = rw.cin
-                want2 = cn_res is not None
-                if tw is None:
-                    o2 = a.alloc(hw, c) if want2 else None
-                    h = self._resnet(r, rw, net, step, h, None, cin, 0, hw, g3, out2=o2, add2=cn_res[k] if want2 else None)
-                else:
-                    h = self._resnet(r, rw, net, step, h, None, cin, 0, hw, g3)
-                    o2 = a.alloc(hw, c) if want2 else None
-                    h = self._transformer(r, tw, net, h, hw, out2=o2, add2=cn_res[k] if want2 else None)
-                skips.append((o2 if want2 else h, c, i))
-                k += 1
+                h = self._resnet(r, rw, net, step, h, None, rw.cin, 0, hw, g3)
+                if tw is not None:
+                    h = self._transformer(r, tw, net, h, hw)
+                skips.append((h, c, i))
             ds = net.downsamplers[i]
             if ds is not None:
                 h2, w2 = sizes[i + 1]
                 o = a.alloc(h2 * w2, c)
-                o2 = a.alloc(h2 * w2, c) if cn_res is not None else None
-                r.conv(h, None, Geom.conv(hh, ww, stride=2), ds, o, out2=o2, add2=cn_res[k] if cn_res is not None else None)
+                r.conv(h, None, Geom.conv(hh, ww, stride=2), ds, o)
                 h = o
-                skips.append((o2 if cn_res is not None else o, c, i + 1))
-                k += 1
+                skips.append((o, c, i + 1))
         hh, ww = sizes[-1]
         hw = hh * ww
         g3 = Geom.conv(hh, ww)
         c = ch[-1]
         h = self._resnet(r, net.mid[0], net, step, h, None, c, 0, hw, g3)
         h = self._transformer(r, net.mid[1], net, h, hw)
-        h = self._resnet(r, net.mid[2], net, step, h, None, c, 0, hw, g3, residual2=cn_mid)
+        h = self._resnet(r, net.mid[2], net, step, h, None, c, 0, hw, g3)
         return h, skips
 
-    def _unet(self, r, step, lat, sizes, cn_res, cn_mid, eps_out):
+    def _unet_encoder(self, r, step, lat, sizes):
+        a, net = self.arena, self.unet
+        ch = net.cfg.block_out_channels
+        h0, w0 = sizes[0]
+        x = a.alloc(h0 * w0, ch[0])
+        r.conv(lat, None, Geom.conv(h0, w0), net.conv_in, x)
+        h, skips = self._down_mid(r, net, step, x, sizes)
+        return h, [(x, ch[0], 0)] + skips
+
+    def _unet_decoder(self, r, step, h, skips, sizes, eps_out):
         a, net = self.arena, self.unet
         ch = net.cfg.block_out_channels
         h0, w0 = sizes[0]
         hw0 = h0 * w0
-        x = a.alloc(hw0, ch[0])
-        x2 = a.alloc(hw0, ch[0]) if cn_res is not None else None
-        r.conv(lat, None, Geom.conv(h0, w0), net.conv_in, x, out2=x2, add2=cn_res[0] if cn_res is not None else None)
-        h, skips = self._down_mid(r, net, step, x, sizes, cn_res, cn_mid)
-        skips = [(x2 if cn_res is not None else x, ch[0], 0)] + skips
+        skips = list(skips)
         nlev = len(ch)
         cprev = ch[-1]
         for i in range(nlev):
@@ -480,27 +474,34 @@ class Engine:
         r.groupnorm(h, None, ch[0], 0, hw0, net.cfg.groups, 1e-5, net.norm_out[0], net.norm_out[1], True, t)
         r.conv(t, None, Geom.conv(h0, w0), net.conv_out, eps_out, ldo=8)
 
-    def _controlnet(self, r, step, lat, sizes, cond_emb, scale):
+    def _controlnet_encoder(self, r, step, lat, sizes, cond_emb):
         a, net = self.arena, self.cn
         ch = net.cfg.block_out_channels
         h0, w0 = sizes[0]
-        hw0 = h0 * w0
-        x = a.alloc(hw0, ch[0])
+        x = a.alloc(h0 * w0, ch[0])
         r.conv(lat, None, Geom.conv(h0, w0), net.conv_in, x, residual=cond_emb)
         h, skips = self._down_mid(r, net, step, x, sizes)
-        skips = [(x, ch[0], 0)] + skips
-        nres = len(skips) + 1
-        scales = torch.logspace(-1, 0, nres) * scale  # guess_mode (always on in the reference, lcm_controlnet.py:399,447)
-        res = []
-        for i, (s, c, lvl) in enumerate(skips):
+        return h, [(x, ch[0], 0)] + skips
+
+    def _controlnet_merge(self, r, cn_mid, cn_skips, u_mid, u_skips, sizes, scale):
+        """The 13 zero-convs, each writing UNet tensor + scale_i * (conv + bias) in one epilogue
+        (ControlNetModel's guess-mode scaling, always on in the reference: lcm_controlnet.py:399,447, and the
+        `down_block_additional_residuals` / `mid_block_additional_residual` adds of UNet2DConditionModel)."""
+        a, net = self.arena, self.cn
+        nres = len(cn_skips) + 1
+        scales = torch.logspace(-1, 0, nres) * scale
+        merged = []
+        for i, ((s, c, lvl), (us, uc, ulvl)) in enumerate(zip(cn_skips, u_skips)):
+            assert (c, lvl) == (uc, ulvl)
             hh, ww = sizes[lvl]
             o = a.alloc(hh * ww, c)
-            r.conv(s, None, Geom.linear(hh * ww), net.zero_convs[i], o, out_scale=float(scales[i]))
-            res.append(o)
+            r.conv(s, None, Geom.linear(hh * ww), net.zero_convs[i], o, out_scale=float(scales[i]), residual=us)
+            merged.append((o, c, lvl))
         hh, ww = sizes[-1]
-        mid = a.alloc(hh * ww, ch[-1])
-        r.conv(h, None, Geom.linear(hh * ww), net.zero_mid, mid, out_scale=float(scales[-1]))
-        return res, mid
+        c = net.cfg.block_out_channels[-1]
+        mid = a.alloc(hh * ww, c)
+        r.conv(cn_mid, None, Geom.linear(hh * ww), net.zero_mid, mid, out_scale=float(scales[-1]), residual=u_mid)
+        return mid, merged
 
     def _cond_embedding(self, r, ctrl, H, W):
         a, net = self.arena, self.cn
@@ -640,10 +641,19 @@ class Engine:
             a.rewind(mark)
             self._vt_count = 0
             cur, nxt = lat[i & 1], lat[(i + 1) & 1]
-            cn_res = cn_mid = None
             if use_controlnet:
-                cn_res, cn_mid = self._controlnet(r, i, cur, sizes, cond_emb, controlnet_scale)
-            self._unet(r, i, cur, sizes, cn_res, cn_mid, eps)
+                # the ControlNet encoder and the UNet encoder both depend only on the current latents: run them
+                # on two streams (two parallel branches of the captured graph), join before the zero-convs
+                r.fork()
+                r.use_stream(1)
+                cn_mid, cn_skips = self._controlnet_encoder(r, i, cur, sizes, cond_emb)
+                r.use_stream(0)
+                u_mid, u_skips = self._unet_encoder(r, i, cur, sizes)
+                r.join()
+                u_mid, u_skips = self._controlnet_merge(r, cn_mid, cn_skips, u_mid, u_skips, sizes, controlnet_scale)
+            else:
+                u_mid, u_skips = self._unet_encoder(r, i, cur, sizes)
+            self._unet_decoder(r, i, u_mid, u_skips, sizes, eps)
             nz = self.noise[i + 1] if sched.multistep else None
             last = i == n - 1
             r.lcm_step(eps, cur, nz, sched.step_coef(i), hw0, nxt, den, dec_in if last else None)

@@ -83,16 +83,32 @@ class HipOps:
         # torch-side plumbing (allocation fills, H2D/D2H copies) must be ordered with the kernels: make the
         # kernel stream this thread's current torch stream.
         torch.cuda.set_stream(self.stream)
+        self.streams = [self.stream, torch.cuda.Stream(device=self.device)]
+        self._sidx = 0
         self._ws = {}
         self.tile_override = {}
         self.inkernel_splitk = True
         self.default_pipeline = 3
-        self._counters = torch.zeros(L.SPLITK_MAX_TILES, dtype=torch.int32, device=self.device)
+        self._counters = [torch.zeros(L.SPLITK_MAX_TILES, dtype=torch.int32, device=self.device) for _ in range(2)]
 
     # ------------------------------------------------------------------ helpers
     @property
     def s(self):
-        return C.c_void_p(self.stream.cuda_stream)
+        return C.c_void_p(self.streams[self._sidx].cuda_stream)
+
+    # ---- two-stream fork/join (become parallel branches of a captured hipGraph)
+    def use_stream(self, idx: int):
+        self._sidx = idx
+
+    def fork(self):
+        e = torch.cuda.Event()
+        e.record(self.streams[0])
+        self.streams[1].wait_event(e)
+
+    def join(self):
+        e = torch.cuda.Event()
+        e.record(self.streams[1])
+        self.streams[0].wait_event(e)
 
     @staticmethod
     def _p(t):
@@ -115,6 +131,7 @@ class HipOps:
         return p
 
     def workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        key = (key, self._sidx)  # kernels on different streams may run concurrently: separate scratch
         cur = self._ws.get(key)
         if cur is None or cur.numel() < nbytes:
             cur = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
@@ -122,6 +139,7 @@ class HipOps:
         return cur
 
     def synchronize(self):
+        self.streams[1].synchronize()
         self.stream.synchronize()
 
     def upload(self, dst: torch.Tensor, src_cpu: torch.Tensor):
@@ -180,7 +198,7 @@ class HipOps:
             ws = workspace if workspace is not None else self.workspace("splitk", split_k * m * w.n * 4)
             d.workspace = self._p(ws)
             if inkernel:
-                d.counters = self._p(self._counters)
+                d.counters = self._p(self._counters[self._sidx])
         self.ctx.call("vsd_conv_gemm", C.byref(d), self.s)
 
     @staticmethod
