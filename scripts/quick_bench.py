@@ -21,6 +21,16 @@ for cn in (False, True):
     for _ in range(N): eng.launch()
     ops.synchronize(); dt=(time.time()-t)/N
     print(f"cn={cn}: {dt*1e3:.2f} ms/frame  {1/dt:.1f} fps")
+    slots=[eng]
+    for S in (2,3):
+        sl = eng.make_slot(); sl.prepare(512, 512, 4, 0.6, use_controlnet=cn); slots.append(sl)
+        for e in slots: e.ops.upload(e.frame_u8, torch.from_numpy(f)); e.launch()
+        for e in slots: e.ops.synchronize()
+        t=time.time()
+        for i in range(N*S): slots[i%S].launch()
+        for e in slots: e.ops.synchronize()
+        dt=(time.time()-t)/(N*S)
+        print(f"   slots={S}: {dt*1e3:.2f} ms/frame  {1/dt:.1f} fps")
     if cn:
         for k, v in sorted(ops.tile_override.items()): print("   tuned", k, v)
     eng.prepare(512, 512, 4, 0.6, use_controlnet=cn, use_graph=False)

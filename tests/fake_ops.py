@@ -29,6 +29,15 @@ class FakeOps:
     def synchronize(self):
         pass
 
+    def zero_(self, t):
+        t.zero_()
+
+    def copy_(self, dst, src):
+        dst.copy_(src)
+
+    def clone(self):
+        return FakeOps()
+
     def use_stream(self, idx):
         pass
 

@@ -93,6 +93,27 @@ def test_graph_replay_is_deterministic_and_equals_eager(mini_setup):
     assert np.array_equal(a, eng.infer_u8(f))
 
 
+def test_two_frames_in_flight_equal_sequential_results(mini_setup):
+    """Slots share weights/constants but nothing mutable: concurrent frames are bit-identical to sequential ones."""
+    eng, orc, text = mini_setup
+    eng.prepare(128, 128, 4, 0.6, controlnet_scale=1.0, use_controlnet=True)
+    frames = [_frame(128, 128, seed=s) for s in (11, 12, 13, 14)]
+    seq = [eng.infer_u8(f).copy() for f in frames]
+    slot = eng.make_slot()
+    slot.prepare(128, 128, 4, 0.6, controlnet_scale=1.0, use_controlnet=True)
+    engines = [eng, slot]
+    for rep in range(3):
+        outs = []
+        for pair in ((0, 1), (2, 3)):
+            for e, k in zip(engines, pair):
+                e.ops.upload(e.frame_u8, torch.from_numpy(frames[k]))
+                e.launch()  # both graphs are now in flight on different streams
+            for e in engines:
+                outs.append(e.ops.download(e.out_u8).numpy().copy())
+        for got, ref in zip(outs, seq):
+            assert np.array_equal(got, ref)
+
+
 def test_sd15_width_pipeline_matches_oracle():
     """Full SD1.5 channel widths / head dims (40, 80, 160) and the real ControlNet tower, small frame."""
     from oracle.pipeline import OraclePipeline

@@ -292,6 +292,21 @@ class Engine:
         self.plan = None
         self.graph = None
         self.use_graph = True
+        self.is_slot = False
+
+    def make_slot(self) -> "Engine":
+        """A further frame in flight on the same GPU: shares the weights and the prompt / schedule constants of
+        this engine, owns its streams, arena, I/O buffers and graph.  Call `prepare` on the parent first, then on
+        the slot with the same arguments.  (The reference keeps one frame in flight per Ray actor; frames are
+        independent, so a second one fills the gaps the first leaves between its small dependent kernels.)"""
+        e = Engine.__new__(Engine)
+        e.__dict__.update(self.__dict__)
+        e.ops = self.ops.clone()
+        e._vt_pool = {}
+        e.graph = None
+        e.plan = None
+        e.is_slot = True
+        return e
 
     # ---------------------------------------------------------------- prompt-dependent constants
     def set_text_embeds(self, embeds: torch.Tensor):
@@ -610,6 +625,9 @@ class Engine:
         self.out_u8 = ops.zeros(H, W, 3, dtype=torch.uint8)
         self.edge_u8 = ops.zeros(H * W, dtype=torch.uint8)
         for net in [self.unet] + ([self.cn] if use_controlnet else []):
+            if self.is_slot:  # schedule constants were computed by the parent engine's prepare
+                assert net.temb_all.shape[0] == n, "prepare the parent engine with the same schedule first"
+                continue
             net.temb_all = ops.zeros(n, net.temb_proj.n)
             self._time_embeddings(net, sched, net.temb_all)
         # noise draws: the reference resets the global CPU generator to a fresh-Generator state on every
@@ -624,7 +642,7 @@ class Engine:
         dec_in = a.alloc(hw0, 8)
         dec_out = a.alloc(H * W, 8)
         for t in (x0, lat[0], lat[1], eps, den, dec_in):
-            t.zero_()
+            ops.zero_(t)
         self.buffers = {"x0": x0, "lat": lat, "eps": eps, "denoised": den, "dec_in": dec_in, "dec_out": dec_out}
         r = Recorder(ops)
         r.preprocess_rgb(self.frame_u8, H, W, enc_in)
@@ -663,7 +681,8 @@ class Engine:
         self.plan = dict(H=H, W=W, steps=steps, strength=strength, cn_scale=controlnet_scale, cn=use_controlnet, n=n,
                          sizes=sizes, timesteps=sched.timesteps, n_ops=len(r.calls), arena_bytes=a.peak)
         # per-shape kernel configuration (timed once per shape, cached in ops.tile_override), warm-up, capture
-        if autotune:
+        torch.cuda.synchronize() if torch.cuda.is_available() else None  # allocation fills vs. kernel streams
+        if autotune and not self.is_slot:
             self.autotune()
         r.run()
         ops.synchronize()

@@ -73,7 +73,8 @@ def choose_tile(m: int, n: int, kp: int, geglu: bool = False, t_col0: int = 0):
 class HipOps:
     name = "hip"
 
-    def __init__(self, device_id: int = 0, stream: Optional[torch.cuda.Stream] = None):
+    def __init__(self, device_id: int = 0, stream: Optional[torch.cuda.Stream] = None, make_current: bool = True,
+                 tile_override: Optional[dict] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("HipOps needs a ROCm GPU; there is no CPU fallback in the product path")
         self.device = torch.device("cuda", device_id)
@@ -82,14 +83,18 @@ class HipOps:
         self.stream = stream or torch.cuda.Stream(device=self.device)
         # torch-side plumbing (allocation fills, H2D/D2H copies) must be ordered with the kernels: make the
         # kernel stream this thread's current torch stream.
-        torch.cuda.set_stream(self.stream)
+        if make_current:
+            torch.cuda.set_stream(self.stream)
+        self.device_id = device_id
         self.streams = [self.stream, torch.cuda.Stream(device=self.device)]
         self._sidx = 0
         self._ws = {}
-        self.tile_override = {}
+        self.tile_override = {} if tile_override is None else tile_override
         self.inkernel_splitk = True
         self.default_pipeline = 3
-        self._counters = [torch.zeros(L.SPLITK_MAX_TILES, dtype=torch.int32, device=self.device) for _ in range(2)]
+        with torch.cuda.stream(self.stream):
+            self._counters = [torch.zeros(L.SPLITK_MAX_TILES, dtype=torch.int32, device=self.device) for _ in range(2)]
+        self.stream.synchronize()
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -114,14 +119,30 @@ class HipOps:
     def _p(t):
         return None if t is None else C.c_void_p(t.data_ptr())
 
+    def clone(self) -> "HipOps":
+        """Same GPU, own context / streams / scratch, shared tuning table: a second frame in flight."""
+        return HipOps(self.device_id, make_current=False, tile_override=self.tile_override)
+
     def empty(self, *shape, dtype=torch.float16):
-        return torch.empty(*shape, dtype=dtype, device=self.device)
+        with torch.cuda.stream(self.stream):
+            return torch.empty(*shape, dtype=dtype, device=self.device)
 
     def zeros(self, *shape, dtype=torch.float16):
-        return torch.zeros(*shape, dtype=dtype, device=self.device)
+        with torch.cuda.stream(self.stream):
+            return torch.zeros(*shape, dtype=dtype, device=self.device)
 
     def to_device(self, t: torch.Tensor):
-        return t.to(self.device)
+        with torch.cuda.stream(self.stream):
+            return t.to(self.device)
+
+    def zero_(self, t: torch.Tensor):
+        with torch.cuda.stream(self.stream):
+            t.zero_()
+
+    def copy_(self, dst: torch.Tensor, src: torch.Tensor):
+        """device-to-device copy ordered on this ops' kernel stream"""
+        with torch.cuda.stream(self.stream):
+            dst.copy_(src, non_blocking=True)
 
     def to_device_pack(self, p: PackedConv) -> PackedConv:
         for f in ("weight", "bias", "ln_s", "ln_t"):
@@ -134,7 +155,8 @@ class HipOps:
         key = (key, self._sidx)  # kernels on different streams may run concurrently: separate scratch
         cur = self._ws.get(key)
         if cur is None or cur.numel() < nbytes:
-            cur = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            with torch.cuda.stream(self.stream):
+                cur = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
             self._ws[key] = cur
         return cur
 
