@@ -251,12 +251,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // block -> (tile_m fastest, tile_n, split)
-  int bid = blockIdx.x;
-  const int tile_m = bid % p.tiles_m;
-  bid /= p.tiles_m;
-  const int tile_n = bid % p.tiles_n;
-  const int split = bid / p.tiles_n;
+  // block -> (tile_m, tile_n, split).  Workgroups b and b+8 share an XCD (round-robin dispatch), so the tiles_m
+  // workgroups that stream the SAME weight tile (same tile_n / split) are given ids b, b+8, b+16, ...: the tile is
+  // then fetched into one XCD's L2 once instead of once per XCD.  Pure speed: any placement gives the same result.
+  int tile_m, grp;
+  {
+    const int bid = blockIdx.x;
+    const int G = p.tiles_n * p.split_k;
+    const int full = (G >> 3) << 3;
+    if (bid < full * p.tiles_m) {
+      const int span = 8 * p.tiles_m;
+      const int chunk = bid / span, r = bid - chunk * span;
+      grp = chunk * 8 + (r & 7);
+      tile_m = r >> 3;
+    } else {
+      const int rem = bid - full * p.tiles_m;
+      grp = full + rem / p.tiles_m;
+      tile_m = rem % p.tiles_m;
+    }
+  }
+  const int tile_n = grp % p.tiles_n;
+  const int split = grp / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int KT = p.Kp / BK;
   const int kt_begin = split * p.kt_per_split;
