@@ -12,6 +12,8 @@ ops = HipOps(0)
 eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
 text = (torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half()
 eng.set_text_embeds(text)
+import os
+eng.overlap_controlnet = os.environ.get('OVL','1')=='1'
 for cn in (False, True):
     t=time.time(); plan = eng.prepare(512, 512, 4, 0.6, use_controlnet=cn); print("prepare", time.time()-t, {k:v for k,v in plan.items() if k!='sizes'})
     f = np.random.default_rng(0).integers(0,256,(512,512,3),dtype=np.uint8)
@@ -22,7 +24,7 @@ for cn in (False, True):
     ops.synchronize(); dt=(time.time()-t)/N
     print(f"cn={cn}: {dt*1e3:.2f} ms/frame  {1/dt:.1f} fps")
     slots=[eng]
-    for S in (2,3):
+    for S in (2,3,4):
         sl = eng.make_slot(); sl.prepare(512, 512, 4, 0.6, use_controlnet=cn); slots.append(sl)
         for e in slots: e.ops.upload(e.frame_u8, torch.from_numpy(f)); e.launch()
         for e in slots: e.ops.synchronize()

@@ -293,6 +293,7 @@ class Engine:
         self.graph = None
         self.use_graph = True
         self.is_slot = False
+        self.overlap_controlnet = True  # run the ControlNet encoder on a second stream, parallel to the UNet encoder
 
     def make_slot(self) -> "Engine":
         """A further frame in flight on the same GPU: shares the weights and the prompt / schedule constants of
@@ -662,12 +663,14 @@ class Engine:
             if use_controlnet:
                 # the ControlNet encoder and the UNet encoder both depend only on the current latents: run them
                 # on two streams (two parallel branches of the captured graph), join before the zero-convs
-                r.fork()
-                r.use_stream(1)
+                if self.overlap_controlnet:
+                    r.fork()
+                    r.use_stream(1)
                 cn_mid, cn_skips = self._controlnet_encoder(r, i, cur, sizes, cond_emb)
                 r.use_stream(0)
                 u_mid, u_skips = self._unet_encoder(r, i, cur, sizes)
-                r.join()
+                if self.overlap_controlnet:
+                    r.join()
                 u_mid, u_skips = self._controlnet_merge(r, cn_mid, cn_skips, u_mid, u_skips, sizes, controlnet_scale)
             else:
                 u_mid, u_skips = self._unet_encoder(r, i, cur, sizes)
