@@ -95,6 +95,13 @@ typedef struct vsd_conv_desc {
                              that many stages (global_load_lds, counted vmcnt) */
   void* rowstat_out;      /* optional fp32 [M][n/64][2]: per output row, (sum, sum of squares) of the fp16 outputs over
                              each 64-column group -- the LayerNorm statistics of the NEXT layer, for free */
+  void* chanstat_out;     /* optional fp32 [n][2]: per output CHANNEL, (sum, sum of squares) of the fp16 outputs over all M
+                             rows -- the GroupNorm statistics of the next layer (vsd_groupnorm's chan_stats).  Needs
+                             chanstat_part (fp32 scratch, ceil(M/BM) * n * 2 floats, BM >= 64) and chan_counters
+                             (ceil(n/64) int32, all zero; left at zero).  The last workgroup of each column block folds
+                             the per-tile partials in tile order: deterministic. */
+  void* chanstat_part;
+  void* chan_counters;
   const void* ln_part;    /* optional: fused LayerNorm of the A operand.  Row partials as written by the producer's
                              rowstat_out, fp32 [M][ln_groups][2]; the weights must hold W*gamma, ln_s[n] = sum_k of
                              those fp16 weights, ln_t[n] = sum_k beta[k] W[n][k] + bias[n] (fp32 [n], packed like the
@@ -118,6 +125,11 @@ int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream);
 int64_t vsd_groupnorm_workspace_bytes(int hw, int c, int groups);
 int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int groups, float eps,
                   const void* gamma, const void* beta, int silu, void* out, void* workspace, void* stream);
+/* Same, with the statistics pass skipped: chan0 / chan1 are the per-channel (sum, sumsq) fp32 [c][2] arrays the
+ * producing vsd_conv_gemm launches left behind (chanstat_out) for src0 / src1.  One kernel instead of two. */
+int vsd_groupnorm_prestat(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int groups, float eps,
+                          const void* gamma, const void* beta, int silu, void* out, const void* chan0, const void* chan1,
+                          void* stream);
 
 /* ---- LayerNorm over the last dimension (BasicTransformerBlock.norm1/2/3, CLIP layer norms) -------- */
 int vsd_layernorm(vsd_ctx* ctx, const void* x, int rows, int c, const void* gamma, const void* beta, float eps,

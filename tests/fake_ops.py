@@ -60,7 +60,8 @@ class FakeOps:
 
     def conv(self, src0, src1, g, w, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None, residual2=None,
              ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0, t_col0=0, tile=None,
-             split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None, ln_eps=1e-5):
+             split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None, ln_eps=1e-5,
+             chanstat_out=None):
         c0 = c0 if c0 is not None else (w.cin - c1)
         x = self._nhwc(src0, g.hs, g.ws, c0)
         if src1 is not None and c1:
@@ -129,14 +130,29 @@ class FakeOps:
             o = out[:, :nout].float().reshape(g.m, nout // 64, 64)
             rowstat_out[:, :, 0] = o.sum(dim=2)
             rowstat_out[:, :, 1] = (o * o).sum(dim=2)
+        if chanstat_out is not None:
+            o = out[:, :nout].float()
+            chanstat_out[:, 0] = o.sum(dim=0)
+            chanstat_out[:, 1] = (o * o).sum(dim=0)
         if out2 is not None:
             out2[:, :nout] = (y + add2[:, :nout].float()).half()
 
-    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out):
+    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=None):
         x = src0[:, :c0].float()
         if src1 is not None and c1:
             x = torch.cat([x, src1[:, :c1].float()], dim=1)
-        y = F.group_norm(x.t()[None], groups, gamma.float(), beta.float(), eps)[0].t()
+        if chan_stats is not None:  # normalise with the statistics the producers handed over (checks the wiring)
+            cs = chan_stats[0].float() if chan_stats[1] is None else torch.cat([chan_stats[0].float(), chan_stats[1].float()])
+            c = c0 + c1
+            g = cs.reshape(groups, c // groups, 2).sum(dim=1)
+            n = hw * (c // groups)
+            mean = g[:, 0] / n
+            rstd = torch.rsqrt((g[:, 1] / n - mean * mean).clamp_min(0) + eps)
+            mean_c = mean.repeat_interleave(c // groups)
+            rstd_c = rstd.repeat_interleave(c // groups)
+            y = (x - mean_c[None]) * rstd_c[None] * gamma.float()[None] + beta.float()[None]
+        else:
+            y = F.group_norm(x.t()[None], groups, gamma.float(), beta.float(), eps)[0].t()
         if silu:
             y = F.silu(y)
         out[:, : c0 + c1] = y.half()

@@ -316,6 +316,46 @@ def test_groupnorm(ops, c0, c1, hw, silu, eps):
     check(out, ref, f"groupnorm C={c} hw={hw}")
 
 
+@pytest.mark.parametrize("h,w,c0,c1,cout,tile,split", [(16, 16, 128, 64, 192, 2, 1), (18, 14, 64, 0, 320, 1, 3),
+                                                        (64, 64, 64, 0, 64, 0, 1), (8, 8, 640, 640, 1280, 2, 4)])
+def test_fused_groupnorm_statistics(ops, h, w, c0, c1, cout, tile, split):
+    """conv epilogue leaves per-channel (sum, sumsq); GroupNorm over [conv out | other tensor] uses them."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    hw = h * w
+    xs = [rnd(1, c0, h, w, seed=1)] + ([rnd(1, c1, h, w, seed=2)] if c1 else [])
+    cin = c0 + c1
+    wt = rnd(cout, cin, 3, 3, seed=3, scale=(cin * 9) ** -0.5)
+    b = rnd(cout, seed=4, scale=0.1)
+    pw = ops.to_device_pack(pack_conv(wt, b))
+    srcs = [to_nhwc(x).cuda() for x in xs]
+    out = torch.zeros(hw, cout, dtype=torch.float16, device="cuda")
+    cs = torch.zeros(cout, 2, dtype=torch.float32, device="cuda")
+    for rep in range(2):  # twice: the arrival counters must come back to zero
+        ops.conv(srcs[0], srcs[1] if c1 else None, Geom.conv(h, w), pw, out, c0=c0, c1=c1, tile=tile, split_k=split,
+                 chanstat_out=cs)
+        ops.synchronize()
+        o = out.float().cpu()
+        assert torch.allclose(cs[:, 0].cpu(), o.sum(dim=0), rtol=1e-4, atol=2e-2), rep
+        assert torch.allclose(cs[:, 1].cpu(), (o * o).sum(dim=0), rtol=1e-4, atol=2e-2), rep
+    assert int(ops._chan_counters[0].abs().sum()) == 0
+    # GroupNorm over the concat [out | other] with pre-computed statistics == the two-kernel GroupNorm
+    other = rnd(hw, 64, seed=7).cuda()
+    ocs = torch.stack([other.float().sum(dim=0), (other.float() ** 2).sum(dim=0)], dim=1).contiguous()
+    c = cout + 64
+    gamma, beta = (1 + 0.1 * rnd(c, seed=5).float()).half().cuda(), rnd(c, seed=6, scale=0.1).cuda()
+    y1 = torch.zeros(hw, c, dtype=torch.float16, device="cuda")
+    y2 = torch.zeros(hw, c, dtype=torch.float16, device="cuda")
+    ops.groupnorm(out, other, cout, 64, hw, 32, 1e-5, gamma, beta, True, y1)
+    ops.groupnorm(out, other, cout, 64, hw, 32, 1e-5, gamma, beta, True, y2, chan_stats=(cs, ocs))
+    ops.synchronize()
+    x = torch.cat([o, other.float().cpu()], dim=1)
+    ref = F.silu(F.group_norm(x.t()[None], 32, gamma.float().cpu(), beta.float().cpu(), 1e-5)[0].t())
+    check(y1, ref, "gn two-kernel")
+    check(y2, ref, "gn prestat")
+
+
 @pytest.mark.parametrize("rows,c", [(4096, 320), (77, 768), (5, 1280), (1000, 64), (64, 1536)])
 def test_layernorm(ops, rows, c):
     x = rnd(rows, c, seed=1) * 3 + 1

@@ -46,6 +46,9 @@ struct ConvParams {
   int split_k, kt_per_split;
   float* ws_partial;
   float* rowstat_out;    // [M][N/64][2]: per-row (sum, sumsq) of the fp16 outputs over each 64-column group
+  float* chanstat_part;  // [tiles_m][N][2] scratch: per-tile column (sum, sumsq) of the fp16 outputs
+  float* chanstat_out;   // [N][2]: per-channel (sum, sumsq) over all M rows -- the next GroupNorm's statistics
+  int* chan_counters;    // [tiles_n] arrival tickets (all zero between launches)
   const float* ln_part;  // fused input LayerNorm: row partials of the A operand, [M][ln_groups][2]
   int ln_groups;
   float ln_eps;
@@ -124,6 +127,7 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
     for (int i = 0; i < 8; ++i) {
       o[i] = (half_t)v[i];
       float f = (float)o[i];
+      v[i] = f;  // hand the rounded value back: the fused statistics are those of the stored tensor
       rsum += f;
       rsq += f * f;
     }
@@ -632,6 +636,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }
   } else {
     constexpr int CH = BN / 8;
+    float cs[8], cq[8];  // this thread's 8 columns (fixed: c8 = (tid % CH) * 8), summed over its rows
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cs[i] = cq[i] = 0.f;
     for (int q = tid; q < BM * CH; q += 256) {  // BM*CH is a multiple of 256: every lane runs every iteration
       int r = q / CH, c8 = (q - r * CH) * 8;
       int m = m0 + r, n = n0 + c8;
@@ -642,6 +649,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         load_chunk8(p, Cs, BNP, from_slabs, r, c8, m, n, v);
         if (p.ln_part) ln_transform8(p, n, rowms[2 * r], rowms[2 * r + 1], v);
         epilogue_store8(p, m, n, v, rs, rq);
+        if (p.chanstat_out) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            cs[i] += v[i];
+            cq[i] += v[i] * v[i];
+          }
+        }
       }
       if (p.rowstat_out) {
         // the 8 lanes of one (row, 64-column group) are consecutive: fold their sums and let the first write
@@ -655,6 +669,59 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
           dst[0] = rs;
           dst[1] = rq;
         }
+      }
+    }
+    if (p.chanstat_out) {
+      // ---- fused GroupNorm statistics of the tensor just written.  (1) fold this tile's rows per column in a
+      // fixed order through LDS; (2) store the tile's column partials write-through; (3) ticket: the last of the
+      // tiles_m workgroups of this column block adds the partials in tile order and publishes chan[N][2].
+      // Deterministic; placement independent (agent-scope acquire on the reducer, cdna guide G16).
+      constexpr int RG = 256 / CH;
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);  // [RG][BN][2]
+      {
+        const int rg = tid / CH, c8 = (tid - rg * CH) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          red[(rg * BN + c8 + i) * 2] = cs[i];
+          red[(rg * BN + c8 + i) * 2 + 1] = cq[i];
+        }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.N) {
+        float S = 0.f, Q = 0.f;
+        for (int g = 0; g < RG; ++g) {
+          S += red[(g * BN + tid) * 2];
+          Q += red[(g * BN + tid) * 2 + 1];
+        }
+        float* dst = p.chanstat_part + ((size_t)tile_m * p.N + n0 + tid) * 2;
+        __hip_atomic_store(dst, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, Q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* lastflag = reinterpret_cast<int*>(smem);
+      if (tid == 0) {
+        int* cnt = p.chan_counters + tile_n;
+        int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = ticket == p.tiles_m - 1;
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *lastflag = last;
+      }
+      __syncthreads();
+      if (*lastflag && tid < BN && n0 + tid < p.N) {
+        float S = 0.f, Q = 0.f;
+        const float* src = p.chanstat_part + ((size_t)(n0 + tid)) * 2;
+        for (int tm = 0; tm < p.tiles_m; ++tm) {
+          S += src[(size_t)tm * p.N * 2];
+          Q += src[(size_t)tm * p.N * 2 + 1];
+        }
+        p.chanstat_out[(n0 + tid) * 2] = S;
+        p.chanstat_out[(n0 + tid) * 2 + 1] = Q;
       }
     }
   }
@@ -742,6 +809,9 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.counters = (int*)d->counters;
   p.zeros = (const half_t*)ctx->zero_page;
   p.rowstat_out = (float*)d->rowstat_out;
+  p.chanstat_part = (float*)d->chanstat_part;
+  p.chanstat_out = (float*)d->chanstat_out;
+  p.chan_counters = (int*)d->chan_counters;
   p.ln_part = (const float*)d->ln_part;
   p.ln_groups = d->ln_groups;
   p.ln_eps = d->ln_eps;
@@ -761,6 +831,10 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   if (p.out2 && !p.add2) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: out2 without add2");
   if (p.rowstat_out && (p.N % 64 || p.out_t || (p.split_k > 1 && !d->counters)))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: rowstat_out needs N %% 64 == 0, no transposed output and the in-kernel split-K form");
+  if (p.chanstat_out && (!p.chanstat_part || !p.chan_counters || p.N % 8 || p.out_t || (p.act & 0xff) == VSD_ACT_GEGLU ||
+                         (p.split_k > 1 && !d->counters)))
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: chanstat_out needs chanstat_part + chan_counters, N %% 8 == 0, a plain (non-transposed, "
+                    "non-GEGLU) output and the in-kernel split-K form");
   if (p.ln_part && (p.ksize != 1 || !p.ln_s || !p.ln_t || p.ln_groups <= 0 || p.bias))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: fused LayerNorm needs a 1x1 layer, ln_s/ln_t and no separate bias");
   if (p.split_k > 1 && !p.ws_partial) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: split_k needs a workspace");

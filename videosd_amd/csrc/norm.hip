@@ -25,6 +25,8 @@ struct GnParams {
   int silu;
   half_t* out;
   float* part;  // [nblk][groups][2]
+  const float* chan0;  // pre-computed per-channel (sum, sumsq) of src0 / src1 (fused into the producer), or null
+  const float* chan1;
   int nblk;     // stats workgroups
   int rpp;      // rows per pass = blockDim / c8
 };
@@ -80,6 +82,17 @@ __global__ void gn_apply_kernel(const GnParams p) {
   extern __shared__ float sm[];  // [groups][2] -> mean, rstd
   const int t = threadIdx.x;
   // fold the stats partials in a fixed order: one thread per (group, sum|sumsq), loads independent of each other
+  if (p.chan0) {
+    for (int i = t; i < p.groups * 2; i += blockDim.x) {
+      const int g = i >> 1, which = i & 1;
+      float acc = 0.f;
+      for (int j = 0; j < p.cpg; ++j) {
+        int c = g * p.cpg + j;
+        acc += (c < p.c0) ? p.chan0[c * 2 + which] : p.chan1[(c - p.c0) * 2 + which];
+      }
+      sm[i] = acc;
+    }
+  } else
   for (int i = t; i < p.groups * 2; i += blockDim.x) {
     float acc = 0.f;
     const float* src = p.part + i;
@@ -216,6 +229,7 @@ extern "C" int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, i
   p.hw = hw; p.groups = groups; p.cpg = p.c / groups; p.eps = eps;
   p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.silu = silu;
   p.out = (half_t*)out; p.part = (float*)workspace;
+  p.chan0 = nullptr; p.chan1 = nullptr;
   p.rpp = p.c8 >= 256 ? 1 : 256 / p.c8;
   const int threads = p.c8 * p.rpp;
   int nblk = cdiv(hw, 8 * p.rpp);
@@ -238,6 +252,35 @@ extern "C" int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, i
     hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk), dim3(threads), smem, s, p);
     return ls.finish();
   }
+}
+
+extern "C" int vsd_groupnorm_prestat(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int groups,
+                                     float eps, const void* gamma, const void* beta, int silu, void* out, const void* chan0,
+                                     const void* chan1, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  GnParams p;
+  p.src0 = (const half_t*)src0;
+  p.src1 = (const half_t*)src1;
+  p.c0 = c0;
+  p.c1 = src1 ? c1 : 0;
+  p.c = p.c0 + p.c1;
+  if (!src0 || !out || !gamma || !beta || !chan0 || (src1 && !chan1)) return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm_prestat: null pointer");
+  if (p.c0 % 8 || p.c1 % 8 || hw <= 0 || groups <= 0 || p.c % groups || groups > 256)
+    return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm_prestat: bad shape c0=%d c1=%d hw=%d groups=%d", c0, c1, hw, groups);
+  p.c8 = p.c / 8;
+  if (p.c8 > 1024) return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm_prestat: C=%d too large", p.c);
+  p.hw = hw; p.groups = groups; p.cpg = p.c / groups; p.eps = eps;
+  p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.silu = silu;
+  p.out = (half_t*)out; p.part = nullptr; p.nblk = 0;
+  p.chan0 = (const float*)chan0; p.chan1 = (const float*)chan1;
+  p.rpp = p.c8 >= 256 ? 1 : 256 / p.c8;
+  const int threads = p.c8 * p.rpp;
+  hipStream_t s = (hipStream_t)stream;
+  int ablk = cdiv(hw, 4 * p.rpp);
+  if (ablk > 256) ablk = 256;
+  LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk), dim3(threads), (size_t)groups * 2 * sizeof(float), s, p);
+  return ls.finish();
 }
 
 extern "C" int vsd_layernorm(vsd_ctx* ctx, const void* x, int rows, int c, const void* gamma, const void* beta,

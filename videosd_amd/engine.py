@@ -293,6 +293,11 @@ class Engine:
         self.graph = None
         self.use_graph = True
         self.is_slot = False
+        # GroupNorm statistics can be produced by the convs' epilogues (chanstat_out); measured on MI355X this costs
+        # the short-lived conv workgroups more (LDS fold + arrival ticket at their tail) than the separate, overlappable
+        # statistics kernels it removes, so it is off by default.
+        self.fuse_gn_stats = False
+        self._stats = {}
         self.overlap_controlnet = True  # run the ControlNet encoder on a second stream, parallel to the UNet encoder
 
     def make_slot(self) -> "Engine":
@@ -355,19 +360,20 @@ class Engine:
         a, cfg = self.arena, net.cfg
         cin = c0 + c1
         t1 = a.alloc(hw, cin)
-        r.groupnorm(x, x2, c0, c1, hw, cfg.groups, 1e-5, rw.n1[0], rw.n1[1], True, t1)
+        self._gn(r, x, x2, c0, c1, hw, cfg.groups, 1e-5, rw.n1[0], rw.n1[1], True, t1)
         h = a.alloc(hw, rw.cout)
         tv = net.temb_all[step, rw.temb_off:rw.temb_off + rw.cout]
-        r.conv(t1, None, geom, rw.conv1, h, rowvec=tv)
+        r.conv(t1, None, geom, rw.conv1, h, rowvec=tv, chanstat_out=self._stat_buf(h, rw.cout))
         t2 = a.alloc(hw, rw.cout)
-        r.groupnorm(h, None, rw.cout, 0, hw, cfg.groups, 1e-5, rw.n2[0], rw.n2[1], True, t2)
+        self._gn(r, h, None, rw.cout, 0, hw, cfg.groups, 1e-5, rw.n2[0], rw.n2[1], True, t2)
         if rw.shortcut is not None:
             sc = a.alloc(hw, rw.cout)
             r.conv(x, x2, Geom.linear(hw), rw.shortcut, sc, c0=c0, c1=c1)
         else:
             sc = x
         out = out if out is not None else a.alloc(hw, rw.cout)
-        r.conv(t2, None, geom, rw.conv2, out, residual=sc, residual2=residual2, out2=out2, add2=add2)
+        r.conv(t2, None, geom, rw.conv2, out, residual=sc, residual2=residual2, out2=out2, add2=add2,
+               chanstat_out=self._stat_buf(out, rw.cout))
         return out
 
     def _transformer(self, r, tw: TransformerW, net, x, hw, out2=None, add2=None):
@@ -376,7 +382,7 @@ class Engine:
         d = c // heads
         lin = Geom.linear(hw)
         t = a.alloc(hw, c)
-        r.groupnorm(x, None, c, 0, hw, cfg.groups, 1e-6, tw.norm[0], tw.norm[1], False, t)
+        self._gn(r, x, None, c, 0, hw, cfg.groups, 1e-6, tw.norm[0], tw.norm[1], False, t)
         # The three LayerNorms are never materialised: every producer of the token stream leaves per-row
         # (sum, sumsq) partials (rowstat_out) and the consuming GEMM applies the norm in its epilogue (ln_part).
         ng = c // 64
@@ -407,8 +413,26 @@ class Engine:
         h3 = a.alloc(hw, c)
         r.conv(f, None, lin, tw.ff2, h3, residual=h2)
         out = a.alloc(hw, c)
-        r.conv(h3, None, lin, tw.proj_out, out, residual=x, out2=out2, add2=add2)
+        r.conv(h3, None, lin, tw.proj_out, out, residual=x, out2=out2, add2=add2, chanstat_out=self._stat_buf(out, c))
         return out
+
+    # ---- fused GroupNorm statistics: a conv that writes a tensor a GroupNorm will read also leaves the tensor's
+    #      per-channel (sum, sumsq); the GroupNorm then needs no statistics pass of its own
+    def _stat_buf(self, tensor, c):
+        if not self.fuse_gn_stats:
+            return None
+        sb = self.arena.alloc(c, 2, dtype=torch.float32)
+        self._stats[tensor.data_ptr()] = sb
+        return sb
+
+    def _gn(self, r, x, x2, c0, c1, hw, groups, eps, gamma, beta, silu, out):
+        cs = None
+        if self.fuse_gn_stats:
+            s0 = self._stats.get(x.data_ptr())
+            s1 = self._stats.get(x2.data_ptr()) if x2 is not None else None
+            if s0 is not None and (x2 is None or s1 is not None):
+                cs = (s0, s1)
+        r.groupnorm(x, x2, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=cs)
 
     def _vt_buffer(self, c, ldvt):
         # V^T buffers live outside the rewound arena: their key-padding columns must stay zero forever
@@ -438,7 +462,7 @@ class Engine:
             if ds is not None:
                 h2, w2 = sizes[i + 1]
                 o = a.alloc(h2 * w2, c)
-                r.conv(h, None, Geom.conv(hh, ww, stride=2), ds, o)
+                r.conv(h, None, Geom.conv(hh, ww, stride=2), ds, o, chanstat_out=self._stat_buf(o, c))
                 h = o
                 skips.append((o, c, i + 1))
         hh, ww = sizes[-1]
@@ -455,7 +479,7 @@ class Engine:
         ch = net.cfg.block_out_channels
         h0, w0 = sizes[0]
         x = a.alloc(h0 * w0, ch[0])
-        r.conv(lat, None, Geom.conv(h0, w0), net.conv_in, x)
+        r.conv(lat, None, Geom.conv(h0, w0), net.conv_in, x, chanstat_out=self._stat_buf(x, ch[0]))
         h, skips = self._down_mid(r, net, step, x, sizes)
         return h, [(x, ch[0], 0)] + skips
 
@@ -484,10 +508,10 @@ class Engine:
                 h2, w2 = sizes[lvl - 1]
                 o = a.alloc(h2 * w2, cprev)
                 # nearest resize to the next skip's size folded into the conv's gather (Upsample2D)
-                r.conv(h, None, Geom.conv(hh, ww, up_to=(h2, w2)), up, o)
+                r.conv(h, None, Geom.conv(hh, ww, up_to=(h2, w2)), up, o, chanstat_out=self._stat_buf(o, cprev))
                 h = o
         t = a.alloc(hw0, ch[0])
-        r.groupnorm(h, None, ch[0], 0, hw0, net.cfg.groups, 1e-5, net.norm_out[0], net.norm_out[1], True, t)
+        self._gn(r, h, None, ch[0], 0, hw0, net.cfg.groups, 1e-5, net.norm_out[0], net.norm_out[1], True, t)
         r.conv(t, None, Geom.conv(h0, w0), net.conv_out, eps_out, ldo=8)
 
     def _controlnet_encoder(self, r, step, lat, sizes, cond_emb):
@@ -495,7 +519,7 @@ class Engine:
         ch = net.cfg.block_out_channels
         h0, w0 = sizes[0]
         x = a.alloc(h0 * w0, ch[0])
-        r.conv(lat, None, Geom.conv(h0, w0), net.conv_in, x, residual=cond_emb)
+        r.conv(lat, None, Geom.conv(h0, w0), net.conv_in, x, residual=cond_emb, chanstat_out=self._stat_buf(x, ch[0]))
         h, skips = self._down_mid(r, net, step, x, sizes)
         return h, [(x, ch[0], 0)] + skips
 
@@ -511,12 +535,14 @@ class Engine:
             assert (c, lvl) == (uc, ulvl)
             hh, ww = sizes[lvl]
             o = a.alloc(hh * ww, c)
-            r.conv(s, None, Geom.linear(hh * ww), net.zero_convs[i], o, out_scale=float(scales[i]), residual=us)
+            r.conv(s, None, Geom.linear(hh * ww), net.zero_convs[i], o, out_scale=float(scales[i]), residual=us,
+                   chanstat_out=self._stat_buf(o, c))
             merged.append((o, c, lvl))
         hh, ww = sizes[-1]
         c = net.cfg.block_out_channels[-1]
         mid = a.alloc(hh * ww, c)
-        r.conv(cn_mid, None, Geom.linear(hh * ww), net.zero_mid, mid, out_scale=float(scales[-1]), residual=u_mid)
+        r.conv(cn_mid, None, Geom.linear(hh * ww), net.zero_mid, mid, out_scale=float(scales[-1]), residual=u_mid,
+               chanstat_out=self._stat_buf(mid, c))
         return mid, merged
 
     def _cond_embedding(self, r, ctrl, H, W):
@@ -586,7 +612,7 @@ class Engine:
         for fn, a, k in self.program.calls:
             if fn.__name__ != "conv":
                 continue
-            key = ops.conv_key(a[2], a[3], k.get("t_col0", 0), k.get("rowstat_out") is not None)
+            key = ops.conv_key(a[2], a[3], k.get("t_col0", 0), k.get("rowstat_out") is not None or k.get("chanstat_out") is not None)
             if key in seen or key in ops.tile_override or k.get("tile") is not None:
                 continue
             best, table = ops.tune_conv(a, k)
@@ -620,6 +646,7 @@ class Engine:
             ops.graph_destroy(self.graph)
             self.graph = None
         self.arena = Arena(ops)
+        self._stats = {}
         self._vt_pool, self._vt_count = getattr(self, "_vt_pool", {}), 0
         # persistent per-frame I/O and constants
         self.frame_u8 = ops.zeros(H, W, 3, dtype=torch.uint8)
@@ -658,6 +685,7 @@ class Engine:
         mark = a.mark()
         for i in range(n):
             a.rewind(mark)
+            self._stats = {}
             self._vt_count = 0
             cur, nxt = lat[i & 1], lat[(i + 1) & 1]
             if use_controlnet:

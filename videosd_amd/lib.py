@@ -34,7 +34,8 @@ class ConvDesc(C.Structure):
         ("tile", C.c_int32), ("split_k", C.c_int32),
         ("workspace", C.c_void_p),
         ("pipeline", C.c_int32),
-        ("rowstat_out", C.c_void_p), ("ln_part", C.c_void_p), ("ln_groups", C.c_int32), ("ln_eps", C.c_float),
+        ("rowstat_out", C.c_void_p), ("chanstat_out", C.c_void_p), ("chanstat_part", C.c_void_p),
+        ("chan_counters", C.c_void_p), ("ln_part", C.c_void_p), ("ln_groups", C.c_int32), ("ln_eps", C.c_float),
         ("ln_s", C.c_void_p), ("ln_t", C.c_void_p),
         ("counters", C.c_void_p),
     ]
@@ -50,6 +51,8 @@ SIGNATURES = {
     "vsd_groupnorm_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "vsd_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsd_groupnorm_prestat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsd_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                 C.c_void_p, C.c_void_p]),
     "vsd_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

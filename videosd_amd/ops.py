@@ -94,6 +94,8 @@ class HipOps:
         self.default_pipeline = 3
         with torch.cuda.stream(self.stream):
             self._counters = [torch.zeros(L.SPLITK_MAX_TILES, dtype=torch.int32, device=self.device) for _ in range(2)]
+        with torch.cuda.stream(self.stream):
+            self._chan_counters = [torch.zeros(4096, dtype=torch.int32, device=self.device) for _ in range(2)]
         self.stream.synchronize()
 
     # ------------------------------------------------------------------ helpers
@@ -177,12 +179,12 @@ class HipOps:
     def conv(self, src0, src1, g: Geom, w: PackedConv, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None,
              residual2=None, ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0,
              t_col0=0, tile=None, split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None,
-             ln_eps=1e-5):
+             ln_eps=1e-5, chanstat_out=None):
         m = g.m
         c0 = c0 if c0 is not None else (w.cin - c1)
         if w.geglu:
             act = L.ACT_GEGLU
-        key = self.conv_key(g, w, t_col0, rowstat_out is not None)
+        key = self.conv_key(g, w, t_col0, rowstat_out is not None or chanstat_out is not None)
         inkernel = self.inkernel_splitk
         if tile is None:
             if key in self.tile_override:
@@ -205,6 +207,10 @@ class HipOps:
             d.ln_part, d.ln_groups, d.ln_eps = self._p(ln_part), ln_part.shape[1], ln_eps
             d.ln_s, d.ln_t = self._p(w.ln_s), self._p(w.ln_t)
         d.rowstat_out = self._p(rowstat_out)
+        if chanstat_out is not None:
+            d.chanstat_out = self._p(chanstat_out)
+            d.chanstat_part = self._p(self.workspace("chanpart", (-(-m // 64)) * w.n * 8))
+            d.chan_counters = self._p(self._chan_counters[self._sidx])
         d.rowvec = self._p(rowvec)
         d.residual, d.residual2 = self._p(residual), self._p(residual2)
         d.ldr = ldr if ldr is not None else w.n_out
@@ -225,6 +231,7 @@ class HipOps:
 
     @staticmethod
     def conv_key(g: Geom, w: PackedConv, t_col0: int = 0, rowstat: bool = False):
+        # `rowstat` = any fused statistics output (restricts split-K to the in-kernel reduction)
         return (g.m, w.n, w.kp, g.ksize, g.stride, g.hi != g.hs or g.wi != g.ws, w.geglu, t_col0, rowstat)
 
     def tune_conv(self, args, kwargs, reps: int = 12):
@@ -232,7 +239,7 @@ class HipOps:
         remember the fastest in tile_override.  Returns (best, table)."""
         g, w = args[2], args[3]
         t_col0 = kwargs.get("t_col0", 0)
-        key = self.conv_key(g, w, t_col0, kwargs.get("rowstat_out") is not None)
+        key = self.conv_key(g, w, t_col0, kwargs.get("rowstat_out") is not None or kwargs.get("chanstat_out") is not None)
         kt = w.kp // 64
         tiles = [L.TILE_128x128, L.TILE_64x128] if w.geglu else [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64]
         cands = []
@@ -249,7 +256,7 @@ class HipOps:
                 if sp > kt // 2 or blocks * sp > 1536:
                     break
                 for pl in (0, 3):
-                    if kwargs.get("rowstat_out") is None:
+                    if kwargs.get("rowstat_out") is None and kwargs.get("chanstat_out") is None:
                         cands.append((t, sp, False, pl))
                     cands.append((t, sp, True, pl))
         kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline")}
@@ -278,7 +285,11 @@ class HipOps:
         self.tile_override[key] = (best[1], best[2], best[3], best[4])
         return best, table
 
-    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out):
+    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=None):
+        if chan_stats is not None:  # statistics were produced by the convs that wrote src0 / src1: one kernel
+            self.ctx.call("vsd_groupnorm_prestat", self._p(src0), self._p(src1), c0, c1, hw, groups, eps, self._p(gamma),
+                          self._p(beta), int(silu), self._p(out), self._p(chan_stats[0]), self._p(chan_stats[1]), self.s)
+            return
         ws = self.workspace("gn", int(self.ctx.lib.vsd_groupnorm_workspace_bytes(hw, c0 + c1, groups)))
         self.ctx.call("vsd_groupnorm", self._p(src0), self._p(src1), c0, c1, hw, groups, eps, self._p(gamma),
                       self._p(beta), int(silu), self._p(out), self._p(ws), self.s)
