@@ -92,7 +92,8 @@ typedef struct vsd_conv_desc {
   int32_t split_k;        /* >= 1; > 1 needs workspace of split_k * M * n floats */
   void* workspace;
   int32_t pipeline;       /* main-loop form: 0 = register-staged double buffer; 3 or 4 = direct-to-LDS ring with
-                             that many stages (global_load_lds, counted vmcnt) */
+                             that many stages (global_load_lds, counted vmcnt); 5 / 6 = the 3- / 4-stage ring with the
+                             DMA issues interleaved between the MFMAs (single-basic-block iterations) */
   void* rowstat_out;      /* optional fp32 [M][n/64][2]: per output row, (sum, sum of squares) of the fp16 outputs over
                              each 64-column group -- the LayerNorm statistics of the NEXT layer, for free */
   void* chanstat_out;     /* optional fp32 [n][2]: per output CHANNEL, (sum, sum of squares) of the fp16 outputs over all M
@@ -191,6 +192,8 @@ int vsd_graph_destroy(vsd_ctx* ctx, void* graph_exec);
 int vsd_profile_begin(vsd_ctx* ctx);
 int vsd_profile_end(vsd_ctx* ctx);
 int vsd_stage_times(vsd_ctx* ctx, float* ms, int64_t* launches, double* flops);
+/* average elapsed ms of an EMPTY event bracket on `stream` (the per-launch cost of the timing itself) */
+int vsd_profile_overhead(vsd_ctx* ctx, void* stream, int n, float* ms_out);
 
 #ifdef __cplusplus
 }

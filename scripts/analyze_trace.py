@@ -8,32 +8,34 @@ ours = ("conv_gemm_kernel", "splitk_reduce", "gn_stats", "gn_apply", "layernorm_
         "preprocess_rgb", "sobel_max", "sobel_apply", "add_noise", "lcm_step", "postprocess")
 rows = [r for r in csv.DictReader(open(trace)) if any(o in r["Kernel_Name"] for o in ours)]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-expect = []
-for i, m in enumerate(ops):
-    # split > 1: two-kernel reduction; split < -1: in-kernel reduction (one launch)
-    n = {"conv": 1 + (1 if m.get("split", 1) > 1 else 0), "groupnorm": 2, "sobel_control": 2}.get(m["op"], 1)
-    expect.append(n)
-total = sum(expect)
-last = rows[-total:]
-assert "preprocess" in last[0]["Kernel_Name"], last[0]["Kernel_Name"][:80]
+# the last eager frame = everything from the last preprocess_rgb kernel on
+start = max(i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"])
+last = rows[start:]
 pos = 0
 agg = collections.OrderedDict()
-frame_ns = int(last[-1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])
 busy = 0
-for m, n in zip(ops, expect):
+total = 0
+for m in ops:
+    n = {"groupnorm": 2, "sobel_control": 2}.get(m["op"], 1)
+    if m["op"] == "conv" and pos + 1 < len(last) and "splitk_reduce" in last[pos + 1]["Kernel_Name"]:
+        n = 2
+    if m["op"] == "groupnorm" and "gn_stats" not in last[pos]["Kernel_Name"]:
+        n = 1  # statistics fused into the producer
     ks = last[pos:pos + n]
     pos += n
+    total += n
     dur = [int(k["End_Timestamp"]) - int(k["Start_Timestamp"]) for k in ks]
     busy += sum(dur)
     if m["op"] == "conv":
         key = ("conv", m["M"], m["N"], m["K"], m["ks"], m["tile"], m["split"])
-        assert "conv_gemm" in ks[0]["Kernel_Name"]
+        assert "conv_gemm" in ks[0]["Kernel_Name"], (m, ks[0]["Kernel_Name"][:60])
     elif m["op"] == "groupnorm":
         key = ("gn", m["hw"], m["C"])
     elif m["op"] == "layernorm":
         key = ("ln", m["rows"], m["C"])
     elif m["op"] == "attention":
         key = ("attn", m["sq"], m["sk"], m["d"])
+        assert "attention" in ks[0]["Kernel_Name"], (m, ks[0]["Kernel_Name"][:60])
     else:
         key = (m["op"],)
     a = agg.setdefault(key, dict(count=0, ns=0, ns2=0, flops=0.0, wbytes=0))
@@ -42,6 +44,7 @@ for m, n in zip(ops, expect):
     a["ns2"] += sum(dur[1:])
     a["flops"] += m.get("flops", 0.0)
     a["wbytes"] += m.get("wbytes", 0)
+frame_ns = int(last[pos - 1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])
 print(f"frame span {frame_ns/1e6:.2f} ms, kernel busy {busy/1e6:.2f} ms, {total} kernels")
 fam = collections.Counter()
 for k, a in agg.items():

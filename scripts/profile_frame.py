@@ -19,10 +19,14 @@ wc = W.synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", device="cuda")
 wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda")
 eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
 eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half())
+ops.load_tuning(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tuning_mi355x.json"))
+eng.overlap_controlnet = False
 eng.prepare(size, size, 4, 0.6, use_controlnet=cn, use_graph=False)
 meta = []
 for fn, a, k in eng.program.calls:
     name = fn.__name__
+    if name in ("fork", "join", "use_stream"):
+        continue
     m = {"op": name}
     if name == "conv":
         g, w = a[2], a[3]
@@ -30,7 +34,7 @@ for fn, a, k in eng.program.calls:
         if tile is None:
             tile, sk = choose_tile(g.m, w.n, w.kp, w.geglu, k.get("t_col0", 0) if k.get("out_t") is not None else 0)
             split = sk if split is None else split
-        key = ops.conv_key(g, w, k.get("t_col0", 0))
+        key = ops.conv_key(g, w, k.get("t_col0", 0), k.get("rowstat_out") is not None or k.get("chanstat_out") is not None)
         ink = True
         if k.get("tile") is None and key in ops.tile_override:
             tile, split, ink, _pl = ops.tile_override[key]

@@ -96,7 +96,7 @@ def run_conv(ops, x_list, h, w, weight, bias, *, ksize, stride=1, up_to=None, ti
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3])
 @pytest.mark.parametrize("split_k", [1, 3])
-@pytest.mark.parametrize("pipeline", [0, 3, 4])
+@pytest.mark.parametrize("pipeline", [0, 3, 4, 5, 6])
 def test_conv3x3_all_tiles_splitk(ops, tile, split_k, pipeline):
     h, w, cin, cout = 18, 14, 128, 192  # M=252: ragged in M for every tile
     x = rnd(1, cin, h, w, seed=1)
@@ -109,7 +109,7 @@ def test_conv3x3_all_tiles_splitk(ops, tile, split_k, pipeline):
     check(got, ref, f"conv3x3 tile={tile} split={split_k} pipeline={pipeline}")
 
 
-@pytest.mark.parametrize("pipeline", [0, 3, 4])
+@pytest.mark.parametrize("pipeline", [0, 3, 4, 5, 6])
 def test_pipelines_are_bit_identical_and_handle_short_k(ops, pipeline):
     # K = 1..5 tiles (shorter than the ring), ragged M and N
     for cin in (64, 128, 320):
@@ -182,7 +182,7 @@ def test_conv_small_channels_generic_path(ops, cin, cout, pad):
     h, w = 20, 12
     x = rnd(1, cin, h, w, seed=1)
     wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
-    for pl in (0, 3):
+    for pl in (0, 3, 5):
         got, ref = run_conv(ops, [x], h, w, wt, rnd(cout, seed=3, scale=0.1), ksize=3, cin_pad=pad, act=2, pipeline=pl)
         check(got, ref, f"generic conv {cin}->{cout} pipeline={pl}")
 

@@ -107,3 +107,26 @@ extern "C" int vsd_stage_times(vsd_ctx* ctx, float* ms, int64_t* launches, doubl
   }
   return VSD_OK;
 }
+
+// Average elapsed time (ms) of an EMPTY event bracket on `stream`: what the per-launch HIP-event timing of
+// vsd_stage_times adds to every kernel it brackets (bench.py subtracts launches * this from a family's total).
+extern "C" int vsd_profile_overhead(vsd_ctx* ctx, void* stream, int n, float* ms_out) {
+  if (!ctx || !ms_out || n <= 0) return VSD_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev(2 * n);
+  for (auto& e : ev) VSD_HIP(ctx, hipEventCreate(&e));
+  for (int i = 0; i < n; ++i) {
+    VSD_HIP(ctx, hipEventRecord(ev[2 * i], s));
+    VSD_HIP(ctx, hipEventRecord(ev[2 * i + 1], s));
+  }
+  VSD_HIP(ctx, hipStreamSynchronize(s));
+  double tot = 0;
+  for (int i = 0; i < n; ++i) {
+    float t = 0.f;
+    VSD_HIP(ctx, hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+    tot += t;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *ms_out = (float)(tot / n);
+  return VSD_OK;
+}

@@ -27,6 +27,8 @@ struct ConvParams {
   int hs, ws, hi, wi, ho, wo;
   int ksize, stride, pad;
   int resize;   // hi != hs || wi != ws
+  unsigned rmul_y, rmul_x;  // resize: ceil(hs * 2^22 / hi), source row = (iy * rmul_y) >> 22; else 1 and shift 0
+  int rshift;
   int generic;  // cin % 64 != 0: per-chunk tap computation
   const half_t* w;
   int M, N, K, Kp;
@@ -234,7 +236,7 @@ __device__ __forceinline__ void load_chunk8(const ConvParams& p, const float* Cs
 // STAGES >= 3: direct-to-LDS ring (global_load_lds, 16 B per lane) with STAGES-1 tiles in flight behind counted
 //              vmcnt waits and raw barriers; the XOR swizzle is applied on the per-lane SOURCE address because a
 //              wave's LDS-DMA destination is lane-linear; out-of-bounds chunks read a zero page.
-template <int BM, int BN, bool GENERIC, int STAGES>
+template <int BM, int BN, bool GENERIC, int STAGES, bool ILV>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   constexpr int WM = 2, WN = 2;             // 2x2 waves
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
@@ -337,11 +339,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                \
       int iy = iy0[i] + ky_, ix = ix0[i] + kx_;                                                     \
       bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi; \
-      int sy = iy, sx = ix;                                                                         \
-      if (p.resize) {                                                                               \
-        sy = (iy * p.hs) / p.hi;                                                                    \
-        sx = (ix * p.ws) / p.wi;                                                                    \
-      }                                                                                             \
+      /* nearest resize as a fixed-point multiply: floor(i*hs/hi) exactly for i*hi < 2^22 (identity: 2^22) */ \
+      const int sy = (int)(((unsigned)iy * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)ix * p.rmul_x) >> p.rshift); \
       size_t off = ok ? ((size_t)(sy * p.ws + sx)) * cs_ + c_ : 0;                                  \
       u32x4 v = *reinterpret_cast<const u32x4*>(src_ + off);                                        \
       areg[i] = ok ? v : zero4;                                                                     \
@@ -453,54 +452,142 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                  \
       int iy = iy0[i] + ky_, ix = ix0[i] + kx_;                                                       \
       bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi;  \
-      int sy = iy, sx = ix;                                                                           \
-      if (p.resize) {                                                                                 \
-        sy = (iy * p.hs) / p.hi;                                                                      \
-        sx = (ix * p.ws) / p.wi;                                                                      \
-      }                                                                                               \
+      const int sy = (int)(((unsigned)iy * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)ix * p.rmul_x) >> p.rshift); \
       const half_t* g_ = ok ? src_ + ((size_t)(sy * p.ws + sx)) * cs_ + c_ : p.zeros;                 \
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(a_ + (8 * wave + 32 * i) * BK), 16, 0, 0); \
     }                                                                                                 \
   }
+    if constexpr (!ILV) {
+  #pragma unroll
+      for (int st = 0; st < STAGES - 1; ++st)
+        if (st < nt) VSD_ISSUE_TILE(kt_begin + st, st)
+      VSD_LN_ROWSTATS()
+      int slot = 0;
+      for (int t = 0; t < nt; ++t) {
+        // tile t has landed once all but the younger tiles' loads are done; then everyone's has (barrier)
+        const int rem = min(STAGES - 2, nt - 1 - t);
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + STAGES - 1 < nt) {
+          int ns = slot + STAGES - 1;
+          if (ns >= STAGES) ns -= STAGES;
+          VSD_ISSUE_TILE(kt_begin + t + STAGES - 1, ns)
+        }
+        const half_t* a = reinterpret_cast<const half_t*>(smem) + slot * STAGE_HALFS;
+        const half_t* b = a + BM * BK;
+  #pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          half8 af[FM], bf[FN];
+  #pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            int r = wm * TM + i * 16 + fr;
+            af[i] = *reinterpret_cast<const half8*>(a + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+          }
+  #pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            int r = wn * TN + j * 16 + fr;
+            bf[j] = *reinterpret_cast<const half8*>(b + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+          }
+  #pragma unroll
+          for (int i = 0; i < FM; ++i)
+  #pragma unroll
+            for (int j = 0; j < FN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (++slot == STAGES) slot = 0;
+      }
+
+    } else {
+      // Interleaved form: every iteration is ONE basic block -- the next tile's LDS-DMA issue is unconditional (tile
+      // index clamped: the last iterations re-fetch the final tile into a slot nobody reads) so the wait count is a
+      // constant and the scheduler may spread the DMA issues and LDS fragment reads between the MFMAs
+      // (sched_group_barrier), instead of running "all loads, then all reads, then all MFMAs" back to back.
+      const int kt_last = kt_end - 1;
 #pragma unroll
-    for (int st = 0; st < STAGES - 1; ++st)
-      if (st < nt) VSD_ISSUE_TILE(kt_begin + st, st)
-    VSD_LN_ROWSTATS()
-    int slot = 0;
-    for (int t = 0; t < nt; ++t) {
-      // tile t has landed once all but the younger tiles' loads are done; then everyone's has (barrier)
-      const int rem = min(STAGES - 2, nt - 1 - t);
-      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-      else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (t + STAGES - 1 < nt) {
+      for (int st = 0; st < STAGES - 1; ++st) VSD_ISSUE_TILE(min(kt_begin + st, kt_last), st)
+      VSD_LN_ROWSTATS()
+      int slot = 0;
+      constexpr int NM = FM * FN * 2;       // MFMAs per tile per wave
+      for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+        __builtin_amdgcn_s_barrier();
         int ns = slot + STAGES - 1;
         if (ns >= STAGES) ns -= STAGES;
-        VSD_ISSUE_TILE(kt_begin + t + STAGES - 1, ns)
-      }
-      const half_t* a = reinterpret_cast<const half_t*>(smem) + slot * STAGE_HALFS;
-      const half_t* b = a + BM * BK;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        half8 af[FM], bf[FN];
+        // ---- per-tile scalars of the tile to fetch (same arithmetic as VSD_ISSUE_TILE)
+        const int ktn = min(kt_begin + t + STAGES - 1, kt_last);
+        half_t* na = reinterpret_cast<half_t*>(smem) + ns * STAGE_HALFS;
+        half_t* nb = na + BM * BK;
+        int k_, cs_;
+        const half_t* src_;
+        bool kok_ = true;
+        if (!GENERIC) {
+          k_ = ktn * BK;
+        } else {
+          k_ = ktn * BK + lc * 8;
+          kok_ = k_ < p.K;
+        }
+        const int tap_ = k_ / p.cin;
+        int c_ = k_ - tap_ * p.cin;
+        const int ky_ = tap_ / p.ksize, kx_ = tap_ - ky_ * p.ksize;
+        if (!GENERIC && c_ >= p.c0) {
+          src_ = p.src1; cs_ = p.c1; c_ -= p.c0;
+        } else {
+          src_ = p.src0; cs_ = p.c0;
+        }
+        if (!GENERIC) c_ += lc * 8;
+        const half_t* a = reinterpret_cast<const half_t*>(smem) + slot * STAGE_HALFS;
+        const half_t* b = a + BM * BK;
+        half8 af[2][FM], bf[2][FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           int r = wm * TM + i * 16 + fr;
-          af[i] = *reinterpret_cast<const half8*>(a + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+          af[0][i] = *reinterpret_cast<const half8*>(a + r * BK + (((fq) ^ (r & 7)) << 3));
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           int r = wn * TN + j * 16 + fr;
-          bf[j] = *reinterpret_cast<const half8*>(b + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+          bf[0][j] = *reinterpret_cast<const half8*>(b + r * BK + (((fq) ^ (r & 7)) << 3));
         }
+        // ---- LPT pieces: one LDS-DMA issue, then MPP MFMAs; the k-step-1 fragments are read half way
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+        for (int pc = 0; pc < LPT; ++pc) {
+          if (pc < BR) {
+            const int i = pc;
+            const half_t* g_ = nvalid[i] ? (wrow[i] - cc * 8 + lc * 8 + (size_t)ktn * BK) : p.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(nb + (8 * wave + 32 * i) * BK), 16, 0, 0);
+          } else {
+            const int i = pc - BR;
+            int iy = iy0[i] + ky_, ix = ix0[i] + kx_;
+            bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi;
+            const int sy = (int)(((unsigned)iy * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)ix * p.rmul_x) >> p.rshift);
+            const half_t* g_ = ok ? src_ + ((size_t)(sy * p.ws + sx)) * cs_ + c_ : p.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(na + (8 * wave + 32 * i) * BK), 16, 0, 0);
+          }
+          if (pc == 0) {
 #pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < FM; ++i) {
+              int r = wm * TM + i * 16 + fr;
+              af[1][i] = *reinterpret_cast<const half8*>(a + r * BK + (((4 + fq) ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              int r = wn * TN + j * 16 + fr;
+              bf[1][j] = *reinterpret_cast<const half8*>(b + r * BK + (((4 + fq) ^ (r & 7)) << 3));
+            }
+          }
+#pragma unroll
+          for (int idx = pc * NM / LPT; idx < (pc + 1) * NM / LPT; ++idx) {  // this piece's share of the NM MFMAs
+            const int ks = idx / (FM * FN), ij = idx % (FM * FN);        // k-step 0 first, then k-step 1
+            const int i = ij / FN, j = ij % FN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the DMA / MFMA alternation as written
+        }
+        if (++slot == STAGES) slot = 0;
       }
-      if (++slot == STAGES) slot = 0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail fetches must land before the LDS is reused
     }
     __syncthreads();  // every wave is done reading the ring before the epilogue reuses the LDS
 #undef VSD_ISSUE_TILE
@@ -764,16 +851,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
   }
 }
 
-template <int BM, int BN, int STAGES>
+template <int BM, int BN, int STAGES, bool ILV>
 void launch2(const ConvParams& p, int grid, hipStream_t s) {
-  if (p.generic) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, STAGES>), dim3(grid), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, STAGES>), dim3(grid), dim3(256), 0, s, p);
+  if (p.generic) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, STAGES, ILV>), dim3(grid), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, STAGES, ILV>), dim3(grid), dim3(256), 0, s, p);
 }
 template <int BM, int BN>
 void launch(const ConvParams& p, int grid, int stages, hipStream_t s) {
-  if (stages == 0) launch2<BM, BN, 0>(p, grid, s);
-  else if (stages == 3) launch2<BM, BN, 3>(p, grid, s);
-  else launch2<BM, BN, 4>(p, grid, s);
+  if (stages == 0) launch2<BM, BN, 0, false>(p, grid, s);
+  else if (stages == 3) launch2<BM, BN, 3, false>(p, grid, s);
+  else if (stages == 4) launch2<BM, BN, 4, false>(p, grid, s);
+  else if (stages == 5) launch2<BM, BN, 3, true>(p, grid, s);
+  else launch2<BM, BN, 4, true>(p, grid, s);
 }
 
 }  // namespace
@@ -790,6 +879,16 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.hs = d->hs; p.ws = d->ws; p.hi = d->hi; p.wi = d->wi; p.ho = d->ho; p.wo = d->wo;
   p.ksize = d->ksize; p.stride = d->stride; p.pad = d->pad;
   p.resize = (d->hi != d->hs) || (d->wi != d->ws);
+  if (d->hi <= 0 || d->wi <= 0 || d->hs > d->hi || d->ws > d->wi || (p.resize && (d->hi > 1024 || d->wi > 1024)))
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: input size %dx%d (stored %dx%d) unsupported", d->hi, d->wi, d->hs, d->ws);
+  if (p.resize) {
+    p.rshift = 22;
+    p.rmul_y = (unsigned)((((unsigned long long)d->hs << 22) + d->hi - 1) / d->hi);
+    p.rmul_x = (unsigned)((((unsigned long long)d->ws << 22) + d->wi - 1) / d->wi);
+  } else {
+    p.rshift = 0;
+    p.rmul_y = p.rmul_x = 1;
+  }
   p.generic = (p.cin % 64) != 0;
   p.w = (const half_t*)d->weight;
   p.M = d->ho * d->wo;
@@ -818,7 +917,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.ln_s = (const float*)d->ln_s;
   p.ln_t = (const float*)d->ln_t;
   const int stages = d->pipeline;
-  if (stages != 0 && stages != 3 && stages != 4) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3 or 4)", stages);
+  if (stages != 0 && (stages < 3 || stages > 6)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3, 4, 5 or 6)", stages);
 
   if (!p.src0 || !p.w || !p.out) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: null src/weight/out");
   if (p.M <= 0 || p.N <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: empty problem M=%d N=%d", p.M, p.N);

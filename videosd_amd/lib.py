@@ -72,6 +72,7 @@ SIGNATURES = {
     "vsd_graph_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vsd_profile_begin": (C.c_int, [C.c_void_p]),
     "vsd_profile_end": (C.c_int, [C.c_void_p]),
+    "vsd_profile_overhead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "vsd_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
 }
 

@@ -248,14 +248,14 @@ class HipOps:
             if kwargs.get("out_t") is not None and t_col0 % bn:
                 continue
             blocks = -(-g.m // bm) * -(-w.n // bn)
-            for pl in (0, 3, 4):
+            for pl in (0, 3, 4, 5, 6):
                 cands.append((t, 1, False, pl))
             if w.geglu or blocks >= 384:
                 continue
             for sp in (2, 3, 4, 6, 8, 12, 16, 24):
                 if sp > kt // 2 or blocks * sp > 1536:
                     break
-                for pl in (0, 3):
+                for pl in (0, 3, 5):
                     if kwargs.get("rowstat_out") is None and kwargs.get("chanstat_out") is None:
                         cands.append((t, sp, False, pl))
                     cands.append((t, sp, True, pl))
@@ -284,6 +284,29 @@ class HipOps:
         best = table[0]
         self.tile_override[key] = (best[1], best[2], best[3], best[4])
         return best, table
+
+    # ---- tuning table persistence (the "find" results are per device generation and shape)
+    def save_tuning(self, path: str):
+        import json
+
+        with open(path, "w") as f:
+            json.dump({"device": torch.cuda.get_device_name(self.device),
+                       "table": [[list(k), list(v)] for k, v in sorted(self.tile_override.items(), key=str)]}, f, indent=0)
+
+    def load_tuning(self, path: str) -> int:
+        import json
+        import os
+
+        if not os.path.exists(path):
+            return 0
+        d = json.load(open(path))
+        n = 0
+        for k, v in d.get("table", []):
+            key = tuple(bool(x) if isinstance(x, bool) else x for x in k)
+            if key not in self.tile_override:
+                self.tile_override[key] = (int(v[0]), int(v[1]), bool(v[2]), int(v[3]))
+                n += 1
+        return n
 
     def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=None):
         if chan_stats is not None:  # statistics were produced by the convs that wrote src0 / src1: one kernel
@@ -340,6 +363,11 @@ class HipOps:
 
     def profile_begin(self):
         self.ctx.call("vsd_profile_begin")
+
+    def profile_overhead_ms(self, n: int = 200) -> float:
+        ms = C.c_float()
+        self.ctx.call("vsd_profile_overhead", self.s, n, C.byref(ms))
+        return float(ms.value)
 
     def profile_end(self):
         self.ctx.call("vsd_profile_end")
