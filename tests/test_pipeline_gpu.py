@@ -114,8 +114,8 @@ def test_two_frames_in_flight_equal_sequential_results(mini_setup):
             assert np.array_equal(got, ref)
 
 
-def test_sd15_width_pipeline_matches_oracle():
-    """Full SD1.5 channel widths / head dims (40, 80, 160) and the real ControlNet tower, small frame."""
+@pytest.fixture(scope="module")
+def sd15_setup():
     from oracle.pipeline import OraclePipeline
     from videosd_amd import config as C
     from videosd_amd.engine import Engine
@@ -125,18 +125,42 @@ def test_sd15_width_pipeline_matches_oracle():
     eng = Engine(HipOps(0), C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
     eng.set_text_embeds(text)
     orc = OraclePipeline(C.SD15_UNET, C.SD15_CONTROLNET, _cpu(wu), _cpu(wc), _cpu(wv))
+    return eng, orc, text
+
+
+def test_sd15_width_pipeline_matches_oracle(sd15_setup):
+    """Full SD1.5 channel widths / head dims (40, 80, 160) and the real ControlNet tower, small frame."""
+    eng, orc, text = sd15_setup
     H, W, steps = 128, 192, 2
     eng.prepare(H, W, steps, 0.6, controlnet_scale=1.0, use_controlnet=True)
     r0, r1, mad, psnr, _ = _compare(eng, orc, _frame(H, W), text, H, W, steps, True, cn_scale=1.0)
     assert r0 <= 5e-3 and r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (r0, r1, mad, psnr)
-    # full-size property checks at the BASELINE size: finite, deterministic, graph == eager
-    H = W = 512
-    eng.prepare(H, W, 4, 0.6, controlnet_scale=1.0, use_controlnet=True)
-    f = _frame(H, W, seed=9)
+
+
+def test_baseline_config1_256_one_step_matches_oracle(sd15_setup):
+    """BASELINE.json configs[0]: SD1.5 img2img 256x256, 1 LCM step (the single-step schedule draws no step noise)."""
+    eng, orc, text = sd15_setup
+    eng.prepare(256, 256, 1, 0.6, controlnet_scale=1.0, use_controlnet=True)
+    assert eng.plan["timesteps"] == [599]
+    r0, r1, mad, psnr, _ = _compare(eng, orc, _frame(256, 256, seed=5), text, 256, 256, 1, True, cn_scale=1.0)
+    assert r0 <= 5e-3 and r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (r0, r1, mad, psnr)
+
+
+@pytest.mark.parametrize("H,W,steps,scale", [(512, 512, 4, 1.0), (768, 768, 8, 2.0), (432, 768, 4, 2.0)])
+def test_full_size_properties(sd15_setup, H, W, steps, scale):
+    """Size-independent properties at BASELINE configs[1] (512x512, 4 steps), configs[4] (768x768, 8 steps,
+    ControlNet scale 2) and the UI's live 768x432 frame (latent 96x54: upsample-to-skip-size path): finite,
+    deterministic across replays, graph replay == eager run, frames do not leak into each other."""
+    eng, orc, text = sd15_setup
+    eng.prepare(H, W, steps, 0.6, controlnet_scale=scale, use_controlnet=True)
+    assert len(eng.plan["timesteps"]) == steps
+    f, g = _frame(H, W, seed=9), _frame(H, W, seed=10)
     a = eng.infer_u8(f)
+    b = eng.infer_u8(g)
+    assert np.array_equal(a, eng.infer_u8(f)) and not np.array_equal(a, b)
+    assert torch.isfinite(eng.buffers["denoised"].float()).all() and a.std() > 1.0
+    eng.prepare(H, W, steps, 0.6, controlnet_scale=scale, use_controlnet=True, use_graph=False)
     assert np.array_equal(a, eng.infer_u8(f))
-    assert torch.isfinite(eng.buffers["denoised"].float()).all()
-    assert a.std() > 1.0
 
 
 @pytest.mark.parametrize("cfg_name", ["MINI_CLIP", "CLIP_L"])
