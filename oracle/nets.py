@@ -42,12 +42,21 @@ def timestep_sinusoid(t, dim):
     return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
 
 
-def time_embedding(w, cfg, t, w_emb=None):
+def time_embedding(w, cfg, t, w_emb=None, added=None):
     t_emb = timestep_sinusoid(t, cfg.block_out_channels[0])
     if w_emb is not None:
         t_emb = t_emb + linear(w, "time_embedding.cond_proj", w_emb)
     h = linear(w, "time_embedding.linear_1", t_emb)
-    return linear(w, "time_embedding.linear_2", F.silu(h))
+    emb = linear(w, "time_embedding.linear_2", F.silu(h))
+    if cfg.add_time_dim:
+        # SDXL addition_embed_type="text_time" (UNet2DConditionModel.forward): aug_emb = add_embedding(cat[pooled text
+        # embeds, flattened sinusoids of the 6 time ids]); emb = emb + aug_emb
+        pooled, time_ids = added
+        tid = timestep_sinusoid(time_ids.flatten(), cfg.add_time_dim).reshape(time_ids.shape[0], -1)
+        a = torch.cat([pooled.float(), tid], dim=-1)
+        a = linear(w, "add_embedding.linear_2", F.silu(linear(w, "add_embedding.linear_1", a)))
+        emb = emb + a
+    return emb
 
 
 def resnet(w, p, cfg, x, temb):
@@ -77,23 +86,33 @@ def attention(w, p, x, ctx, heads):
     return linear(w, p + ".to_out.0", o)
 
 
-def transformer(w, p, cfg, x, text):
+def transformer(w, p, cfg, x, text, depth=1):
+    """Transformer2DModel: `depth` BasicTransformerBlocks between proj_in / proj_out (1x1 conv for SD1.5, Linear on
+    the token matrix when use_linear_projection, SDXL)."""
     b, c, hh, ww = x.shape
+    heads = cfg.heads_for(c)
     res = x
     h = group_norm(w, p + ".norm", x, cfg.groups, 1e-6)
-    h = conv(w, p + ".proj_in", h, padding=0)
-    h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
-    t = p + ".transformer_blocks.0"
-    n = layer_norm(w, t + ".norm1", h)
-    h = h + attention(w, t + ".attn1", n, n, cfg.heads)
-    n = layer_norm(w, t + ".norm2", h)
-    h = h + attention(w, t + ".attn2", n, text, cfg.heads)
-    n = layer_norm(w, t + ".norm3", h)
-    g = linear(w, t + ".ff.net.0.proj", n)
-    hid, gate = g.chunk(2, dim=-1)
-    h = h + linear(w, t + ".ff.net.2", hid * F.gelu(gate))
-    h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)
-    h = conv(w, p + ".proj_out", h, padding=0)
+    if cfg.linear_proj:
+        h = linear(w, p + ".proj_in", h.permute(0, 2, 3, 1).reshape(b, hh * ww, c))
+    else:
+        h = conv(w, p + ".proj_in", h, padding=0)
+        h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
+    for k in range(depth):
+        t = f"{p}.transformer_blocks.{k}"
+        n = layer_norm(w, t + ".norm1", h)
+        h = h + attention(w, t + ".attn1", n, n, heads)
+        n = layer_norm(w, t + ".norm2", h)
+        h = h + attention(w, t + ".attn2", n, text, heads)
+        n = layer_norm(w, t + ".norm3", h)
+        g = linear(w, t + ".ff.net.0.proj", n)
+        hid, gate = g.chunk(2, dim=-1)
+        h = h + linear(w, t + ".ff.net.2", hid * F.gelu(gate))
+    if cfg.linear_proj:
+        h = linear(w, p + ".proj_out", h).reshape(b, hh, ww, c).permute(0, 3, 1, 2)
+    else:
+        h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2)
+        h = conv(w, p + ".proj_out", h, padding=0)
     return h + res
 
 
@@ -104,20 +123,21 @@ def _down_and_mid(w, cfg, h, temb, text):
         for j in range(cfg.layers_per_block):
             h = resnet(w, f"down_blocks.{i}.resnets.{j}", cfg, h, temb)
             if cfg.down_attn[i]:
-                h = transformer(w, f"down_blocks.{i}.attentions.{j}", cfg, h, text)
+                h = transformer(w, f"down_blocks.{i}.attentions.{j}", cfg, h, text, cfg.transformer_depth[i])
             skips.append(h)
         if i < len(ch) - 1:
             h = conv(w, f"down_blocks.{i}.downsamplers.0.conv", h, stride=2, padding=1)
             skips.append(h)
     h = resnet(w, "mid_block.resnets.0", cfg, h, temb)
-    h = transformer(w, "mid_block.attentions.0", cfg, h, text)
+    h = transformer(w, "mid_block.attentions.0", cfg, h, text, cfg.mid_depth)
     h = resnet(w, "mid_block.resnets.1", cfg, h, temb)
     return h, skips
 
 
-def unet_forward(w, cfg, sample, t, text, w_emb=None, down_res=None, mid_res=None):
-    """UNet2DConditionModel.forward as used at lcm_controlnet.py:568-577.  t: int64 [B]."""
-    temb = time_embedding(w, cfg, t, w_emb)
+def unet_forward(w, cfg, sample, t, text, w_emb=None, down_res=None, mid_res=None, added=None):
+    """UNet2DConditionModel.forward as used at lcm_controlnet.py:568-577.  t: int64 [B].
+    added = (pooled text embeds [B, add_pooled_dim], time ids [B, 6]) for the SDXL configuration."""
+    temb = time_embedding(w, cfg, t, w_emb, added)
     h = conv(w, "conv_in", sample)
     h, skips = _down_and_mid(w, cfg, h, temb, text)
     if down_res is not None:
@@ -132,7 +152,7 @@ def unet_forward(w, cfg, sample, t, text, w_emb=None, down_res=None, mid_res=Non
             h = torch.cat([h, skips.pop()], dim=1)
             h = resnet(w, f"up_blocks.{i}.resnets.{j}", cfg, h, temb)
             if cfg.up_attn[i]:
-                h = transformer(w, f"up_blocks.{i}.attentions.{j}", cfg, h, text)
+                h = transformer(w, f"up_blocks.{i}.attentions.{j}", cfg, h, text, cfg.up_depth[i])
         if i < nb - 1:
             if fwd_size:
                 h = F.interpolate(h, size=skips[-1].shape[2:], mode="nearest")

@@ -81,7 +81,8 @@ class OraclePipeline:
 
     @torch.no_grad()
     def infer(self, img: Image.Image, prompt_embeds: torch.Tensor, height=360, width=640, strength=0.4, steps=20,
-              seed=42, controlnet_scale=1.0, use_controlnet=True, keep_trace=False) -> Image.Image:
+              seed=42, controlnet_scale=1.0, use_controlnet=True, keep_trace=False, pooled=None,
+              time_ids=None) -> Image.Image:
         img = center_crop_resize(img, width, height)
         canny = sobel_edges(img, 0.11, 0.8)
         reset_rng(seed)
@@ -96,6 +97,11 @@ class OraclePipeline:
         if self.unet_cfg.cond_proj_dim:
             w_emb = w_embedding(torch.tensor(self.guidance_scale).repeat(1), self.unet_cfg.cond_proj_dim)
         text = prompt_embeds.float()
+        added = None
+        if self.unet_cfg.add_time_dim:  # SDXL: pooled text embeds + (orig size, crop, target size) micro-conditioning
+            if time_ids is None:
+                time_ids = torch.tensor([[height, width, 0, 0, height, width]], dtype=torch.float32)
+            added = (pooled.float().reshape(1, -1), time_ids)
         if keep_trace:
             self.trace = {"init_latents": init.clone(), "noisy_latents": latents.clone(), "eps": [], "denoised": []}
         denoised = None
@@ -105,7 +111,7 @@ class OraclePipeline:
             if use_controlnet:
                 down, mid = nets.controlnet_forward(self.w_cn, self.cn_cfg, latents, tt, text, control,
                                                     conditioning_scale=controlnet_scale, guess_mode=True)
-            eps = nets.unet_forward(self.w_unet, self.unet_cfg, latents, tt, text, w_emb, down, mid)
+            eps = nets.unet_forward(self.w_unet, self.unet_cfg, latents, tt, text, w_emb, down, mid, added)
             latents, denoised = self.sched.step(eps, i, t, latents)
             if keep_trace:
                 self.trace["eps"].append(eps.clone())

@@ -56,6 +56,36 @@ def test_engine_program_matches_oracle(mini, H, W, steps, cn):
     assert diff.mean() < 1.5, diff.mean()
 
 
+@pytest.mark.parametrize("H,Wd,steps", [(64, 64, 2), (56, 40, 1)])
+def test_sdxl_shaped_engine_program_matches_oracle(H, Wd, steps):
+    """BASELINE.json configs[3] topology (SDXL: 3 levels, no attention at level 0, several BasicTransformerBlocks per
+    Transformer2D, Linear proj_in/out, fixed head size, text_time added conditioning, no ControlNet) at reduced width."""
+    cfg = C.MINI_SDXL_UNET
+    wu = W.synthesize(W.unet_spec(cfg), "xl.")
+    wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.")
+    g = torch.Generator().manual_seed(11)
+    text = (torch.randn(77, cfg.cross_dim, generator=g) * 0.5).half()
+    pooled = (torch.randn(cfg.add_pooled_dim, generator=g) * 0.5).half()
+    eng = Engine(FakeOps(), cfg, None, C.TAESD, wu, None, wv)
+    eng.set_text_embeds(text)
+    with pytest.raises(RuntimeError):
+        eng.prepare(H, Wd, steps, 0.6, use_controlnet=False, use_graph=False)  # added conditioning missing
+    eng.set_added_cond(pooled, (H, Wd, 0, 0, H, Wd))
+    plan = eng.prepare(H, Wd, steps, 0.6, use_controlnet=False, use_graph=False)
+    frame = _frame(H, Wd)
+    got = eng.infer_u8(frame)
+    orc = OraclePipeline(cfg, None, wu, None, wv)
+    ref = np.asarray(orc.infer(Image.fromarray(frame, "RGB"), text[None].float(), height=H, width=Wd, strength=0.6,
+                               steps=steps, seed=23, use_controlnet=False, keep_trace=True, pooled=pooled))
+    assert plan["timesteps"] == orc.sched.timesteps.tolist()
+    h0, w0 = H // 8, Wd // 8
+    den = eng.buffers["denoised"][:, :4].float().reshape(h0, w0, 4).permute(2, 0, 1)
+    ref_den = orc.trace["denoised"][-1][0]
+    rel = float((den - ref_den).norm() / ref_den.norm())
+    assert rel < 2e-2, rel
+    assert np.abs(got.astype(int) - ref.astype(int)).mean() < 1.5
+
+
 def test_fused_groupnorm_statistics_wiring(mini):
     """The optional producer-side GroupNorm statistics (chanstat_out -> groupnorm(chan_stats=...)) reach every
     GroupNorm with the right tensors: same image as the default path, through the emulator."""

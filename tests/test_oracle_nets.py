@@ -16,6 +16,8 @@ def test_param_counts_match_published_sizes():
     assert W.count_params([x for x in s if x[0].startswith("encoder")]) == 1_222_532
     assert W.count_params([x for x in s if x[0].startswith("decoder")]) == 1_222_531
     assert round(W.count_params(W.clip_spec(C.CLIP_L)) / 1e6, 2) == 123.06
+    # SDXL-base UNet (2 567 463 684) + the LCM guidance projection 256 -> 320 (81 920): BASELINE.json configs[3]
+    assert W.count_params(W.unet_spec(C.SDXL_UNET)) == 2_567_463_684 + 81_920
 
 
 def test_clip_restatement_matches_transformers():

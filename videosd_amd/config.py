@@ -15,17 +15,38 @@ class UNetConfig:
     in_channels: int = 4
     out_channels: int = 4
     block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
-    down_attn: Tuple[bool, ...] = (True, True, True, False)
+    transformer_depth: Tuple[int, ...] = (1, 1, 1, 0)  # BasicTransformerBlocks per attention at each level (0: none)
+    mid_depth: int = 1
     layers_per_block: int = 2
-    heads: int = 8
+    heads: int = 8                      # SD1.5: `attention_head_dim=8` means 8 heads at every level
+    head_dim: Optional[int] = None      # SDXL: fixed head size (64), heads = C // head_dim
     cross_dim: int = 768
     groups: int = 32
     cond_proj_dim: Optional[int] = 256  # LCM guidance embedding (time_cond_proj_dim); None for ControlNet
     text_len: int = 77
+    linear_proj: bool = False           # use_linear_projection: proj_in / proj_out are Linear instead of 1x1 conv
+    add_time_dim: Optional[int] = None  # SDXL addition_embed_type="text_time": sinusoid width per time id (256)
+    add_pooled_dim: int = 1280          # pooled text embedding width entering add_embedding
+    add_n_ids: int = 6                  # (orig_h, orig_w, crop_top, crop_left, target_h, target_w)
 
     @property
     def temb_dim(self) -> int:
         return 4 * self.block_out_channels[0]
+
+    @property
+    def down_attn(self) -> Tuple[bool, ...]:
+        return tuple(d > 0 for d in self.transformer_depth)
+
+    @property
+    def up_depth(self) -> Tuple[int, ...]:
+        return tuple(reversed(self.transformer_depth))
+
+    @property
+    def add_in_dim(self) -> int:
+        return self.add_pooled_dim + self.add_n_ids * self.add_time_dim if self.add_time_dim else 0
+
+    def heads_for(self, c: int) -> int:
+        return c // self.head_dim if self.head_dim else self.heads
 
     @property
     def up_attn(self) -> Tuple[bool, ...]:
@@ -58,6 +79,10 @@ class CLIPTextConfig:
 
 
 SD15_UNET = UNetConfig()
+# BASELINE.json configs[3]: SDXL-base UNet with the LCM guidance projection (latent-consistency/lcm-sdxl), 2 567.55 M
+# parameters.  Not in the reference: same per-frame loop, no ControlNet, TAESD-XL has TAESD's shape.
+SDXL_UNET = UNetConfig(block_out_channels=(320, 640, 1280), transformer_depth=(0, 2, 10), mid_depth=10, head_dim=64,
+                       cross_dim=2048, linear_proj=True, add_time_dim=256)
 SD15_CONTROLNET = ControlNetConfig()
 TAESD = TAESDConfig()
 CLIP_L = CLIPTextConfig()
@@ -67,4 +92,6 @@ CLIP_L = CLIPTextConfig()
 MINI_UNET = UNetConfig(block_out_channels=(64, 128, 256, 256), cross_dim=128, cond_proj_dim=64)
 MINI_CONTROLNET = ControlNetConfig(unet=UNetConfig(block_out_channels=(64, 128, 256, 256), cross_dim=128,
                                                     cond_proj_dim=None), cond_channels=(16, 32, 96, 256))
+MINI_SDXL_UNET = UNetConfig(block_out_channels=(64, 128, 256), transformer_depth=(0, 2, 3), mid_depth=3, head_dim=32,
+                            cross_dim=128, cond_proj_dim=64, linear_proj=True, add_time_dim=32, add_pooled_dim=96)
 MINI_CLIP = CLIPTextConfig(vocab=1000, width=128, heads=2, layers=2, mlp=512)

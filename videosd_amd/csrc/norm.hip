@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int GN_MAX_PART = 32;
+constexpr int GN_MAX_PART = 64;
 
 struct GnParams {
   const half_t* src0;
@@ -37,6 +37,9 @@ __device__ __forceinline__ half8 gn_load(const GnParams& p, int row, int ch8) {
   return *reinterpret_cast<const half8*>(s);
 }
 
+// Both kernels are latency- rather than bandwidth-bound at these sizes (a few MB, L2 resident): every thread issues
+// its row loads four at a time before consuming them, and the partial folds are spread over all threads with every
+// load of a thread independent of the others, so each phase costs about one memory round trip.
 __global__ void gn_stats_kernel(const GnParams p) {
   extern __shared__ float sm[];  // [rpp][c][2] per-thread channel sums, folded in a fixed order
   const int t = threadIdx.x;
@@ -48,7 +51,20 @@ __global__ void gn_stats_kernel(const GnParams p) {
   float s[8], q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
-  for (int r = r0 + rl; r < r1; r += p.rpp) {
+  int r = r0 + rl;
+  for (; r + 3 * p.rpp < r1; r += 4 * p.rpp) {
+    half8 x0 = gn_load(p, r, ch8), x1 = gn_load(p, r + p.rpp, ch8);
+    half8 x2 = gn_load(p, r + 2 * p.rpp, ch8), x3 = gn_load(p, r + 3 * p.rpp, ch8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v0 = (float)x0[i], v1 = (float)x1[i], v2 = (float)x2[i], v3 = (float)x3[i];
+      s[i] += v0; q[i] += v0 * v0;
+      s[i] += v1; q[i] += v1 * v1;
+      s[i] += v2; q[i] += v2 * v2;
+      s[i] += v3; q[i] += v3 * v3;
+    }
+  }
+  for (; r < r1; r += p.rpp) {
     half8 x = gn_load(p, r, ch8);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -64,26 +80,24 @@ __global__ void gn_stats_kernel(const GnParams p) {
     mine[2 * i + 1] = q[i];
   }
   __syncthreads();
-  for (int g = t; g < p.groups; g += blockDim.x) {
-    float gs = 0.f, gq = 0.f;
-    for (int r = 0; r < p.rpp; ++r) {
-      const float* row = sm + ((size_t)r * p.c + g * p.cpg) * 2;
-      for (int c = 0; c < p.cpg; ++c) {
-        gs += row[2 * c];
-        gq += row[2 * c + 1];
-      }
+  // one thread per (group, sum | sumsq): rows outer, channels inner -- a fixed order
+  for (int i = t; i < p.groups * 2; i += blockDim.x) {
+    const int g = i >> 1, which = i & 1;
+    float acc = 0.f;
+    for (int rr = 0; rr < p.rpp; ++rr) {
+      const float* row = sm + ((size_t)rr * p.c + g * p.cpg) * 2 + which;
+      for (int c = 0; c < p.cpg; ++c) acc += row[2 * c];
     }
-    p.part[((size_t)blockIdx.x * p.groups + g) * 2] = gs;
-    p.part[((size_t)blockIdx.x * p.groups + g) * 2 + 1] = gq;
+    p.part[(size_t)blockIdx.x * p.groups * 2 + i] = acc;
   }
 }
 
 __global__ void gn_apply_kernel(const GnParams p) {
-  extern __shared__ float sm[];  // [groups][2] -> mean, rstd
+  extern __shared__ float sm[];  // [groups][2] mean, rstd | [nch][groups*2] partial folds
   const int t = threadIdx.x;
-  // fold the stats partials in a fixed order: one thread per (group, sum|sumsq), loads independent of each other
+  const int npairs = p.groups * 2;
   if (p.chan0) {
-    for (int i = t; i < p.groups * 2; i += blockDim.x) {
+    for (int i = t; i < npairs; i += blockDim.x) {
       const int g = i >> 1, which = i & 1;
       float acc = 0.f;
       for (int j = 0; j < p.cpg; ++j) {
@@ -92,33 +106,44 @@ __global__ void gn_apply_kernel(const GnParams p) {
       }
       sm[i] = acc;
     }
-  } else
-  for (int i = t; i < p.groups * 2; i += blockDim.x) {
-    float acc = 0.f;
-    const float* src = p.part + i;
-    const int stride = p.groups * 2;
-    int b = 0;
-    for (; b + 4 <= p.nblk; b += 4) {
-      float v0 = src[(size_t)(b + 0) * stride], v1 = src[(size_t)(b + 1) * stride];
-      float v2 = src[(size_t)(b + 2) * stride], v3 = src[(size_t)(b + 3) * stride];
-      acc += v0; acc += v1; acc += v2; acc += v3;
+  } else {
+    // fold the statistics partials: (pair, chunk) per thread, chunk ch sums blocks ch, ch+nch, ... (at most 16 loads,
+    // all independent), then the chunks are added in order: deterministic
+    int nch = (int)blockDim.x / npairs;
+    nch = nch < 1 ? 1 : (nch > 4 ? 4 : nch);
+    float* fold = sm + npairs;
+    for (int i = t; i < npairs * nch; i += blockDim.x) {
+      const int pair = i % npairs, ch = i / npairs;
+      const float* src = p.part + pair;
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int b = ch + j * nch;
+        v[j] = b < p.nblk ? src[(size_t)b * npairs] : 0.f;
+      }
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc += v[j];
+      for (int b = ch + 16 * nch; b < p.nblk; b += nch) acc += src[(size_t)b * npairs];
+      fold[ch * npairs + pair] = acc;
     }
-    for (; b < p.nblk; ++b) acc += src[(size_t)b * stride];
-    sm[i] = acc;
+    __syncthreads();
+    for (int i = t; i < npairs; i += blockDim.x) {
+      float acc = 0.f;
+      for (int ch = 0; ch < nch; ++ch) acc += fold[ch * npairs + i];
+      sm[i] = acc;
+    }
   }
   __syncthreads();
   float mean_r = 0.f, rstd_r = 0.f;
-  if (t < p.groups) {
+  for (int g = t; g < p.groups; g += blockDim.x) {  // groups <= blockDim is not guaranteed for tiny C
     float n = (float)p.hw * (float)p.cpg;
-    float mean = sm[t * 2] / n;
-    float var = fmaxf(sm[t * 2 + 1] / n - mean * mean, 0.f);
+    float mean = sm[g * 2] / n;
+    float var = fmaxf(sm[g * 2 + 1] / n - mean * mean, 0.f);
     mean_r = mean;
     rstd_r = rsqrtf(var + p.eps);
-  }
-  __syncthreads();
-  if (t < p.groups) {
-    sm[t * 2] = mean_r;
-    sm[t * 2 + 1] = rstd_r;
+    sm[g * 2] = mean_r;       // in place: entry g is read and written by this thread only
+    sm[g * 2 + 1] = rstd_r;
   }
   __syncthreads();
   const int ch8 = t % p.c8;
@@ -138,8 +163,7 @@ __global__ void gn_apply_kernel(const GnParams p) {
   const int rows_per_blk = (p.hw + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rows_per_blk;
   const int r1 = min(p.hw, r0 + rows_per_blk);
-  for (int r = r0 + rl; r < r1; r += p.rpp) {
-    half8 x = gn_load(p, r, ch8);
+  auto norm_store = [&](int r, const half8& x) {
     half8 y;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -148,6 +172,19 @@ __global__ void gn_apply_kernel(const GnParams p) {
       y[i] = (half_t)v;
     }
     *reinterpret_cast<half8*>(p.out + (size_t)r * p.c + ch8 * 8) = y;
+  };
+  int r = r0 + rl;
+  for (; r + 3 * p.rpp < r1; r += 4 * p.rpp) {
+    half8 x0 = gn_load(p, r, ch8), x1 = gn_load(p, r + p.rpp, ch8);
+    half8 x2 = gn_load(p, r + 2 * p.rpp, ch8), x3 = gn_load(p, r + 3 * p.rpp, ch8);
+    norm_store(r, x0);
+    norm_store(r + p.rpp, x1);
+    norm_store(r + 2 * p.rpp, x2);
+    norm_store(r + 3 * p.rpp, x3);
+  }
+  for (; r < r1; r += p.rpp) {
+    half8 x = gn_load(p, r, ch8);
+    norm_store(r, x);
   }
 }
 
@@ -230,14 +267,15 @@ extern "C" int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, i
   p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.silu = silu;
   p.out = (half_t*)out; p.part = (float*)workspace;
   p.chan0 = nullptr; p.chan1 = nullptr;
-  p.rpp = p.c8 >= 256 ? 1 : 256 / p.c8;
+  p.rpp = p.c8 >= 512 ? 1 : 512 / p.c8;
+  if (p.rpp > hw) p.rpp = hw;
   const int threads = p.c8 * p.rpp;
-  int nblk = cdiv(hw, 8 * p.rpp);
+  int nblk = cdiv(hw, 4 * p.rpp);
   if (nblk > GN_MAX_PART) nblk = GN_MAX_PART;
   if (nblk < 1) nblk = 1;
   p.nblk = nblk;
   hipStream_t s = (hipStream_t)stream;
-  const size_t smem = (size_t)groups * 2 * sizeof(float);
+  const size_t smem = (size_t)groups * 2 * 5 * sizeof(float);
   {
     const size_t smem_stats = (size_t)p.rpp * p.c * 2 * sizeof(float);
     LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
@@ -246,7 +284,7 @@ extern "C" int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, i
     if (rc) return rc;
   }
   {
-    int ablk = cdiv(hw, 4 * p.rpp);
+    int ablk = cdiv(hw, 2 * p.rpp);
     if (ablk > 256) ablk = 256;
     LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk), dim3(threads), smem, s, p);
@@ -273,10 +311,11 @@ extern "C" int vsd_groupnorm_prestat(vsd_ctx* ctx, const void* src0, const void*
   p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.silu = silu;
   p.out = (half_t*)out; p.part = nullptr; p.nblk = 0;
   p.chan0 = (const float*)chan0; p.chan1 = (const float*)chan1;
-  p.rpp = p.c8 >= 256 ? 1 : 256 / p.c8;
+  p.rpp = p.c8 >= 512 ? 1 : 512 / p.c8;
+  if (p.rpp > hw) p.rpp = hw;
   const int threads = p.c8 * p.rpp;
   hipStream_t s = (hipStream_t)stream;
-  int ablk = cdiv(hw, 4 * p.rpp);
+  int ablk = cdiv(hw, 2 * p.rpp);
   if (ablk > 256) ablk = 256;
   LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk), dim3(threads), (size_t)groups * 2 * sizeof(float), s, p);

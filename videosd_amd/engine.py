@@ -101,10 +101,8 @@ class ResnetW:
 
 
 @dataclass
-class TransformerW:
-    c: int
-    norm: Tuple[torch.Tensor, torch.Tensor]
-    proj_in: PackedConv
+class BlockW:
+    """One BasicTransformerBlock."""
     qkv: PackedConv            # LayerNorm norm1 folded in (pack_linear_ln)
     out1: PackedConv
     q2: PackedConv             # norm2 folded in
@@ -112,8 +110,17 @@ class TransformerW:
     out2: PackedConv
     ff1: PackedConv            # norm3 folded in, GEGLU tile-packed
     ff2: PackedConv
-    proj_out: PackedConv
     kv_index: int              # slot in the per-prompt cross-attention K / V^T cache
+
+
+@dataclass
+class TransformerW:
+    """Transformer2DModel: GroupNorm, proj_in, `depth` blocks (1 for SD1.5; 2 / 10 for SDXL), proj_out."""
+    c: int
+    norm: Tuple[torch.Tensor, torch.Tensor]
+    proj_in: PackedConv
+    blocks: List[BlockW]
+    proj_out: PackedConv
 
 
 class NetWeights:
@@ -125,13 +132,15 @@ class NetWeights:
         self._w = w
         self._temb_w, self._temb_b = [], []
         self._temb_cols = 0
-        self.transformers: List[TransformerW] = []
+        self.transformers: List[BlockW] = []  # every BasicTransformerBlock, in kv_cache order
         dev = ops.to_device
         ch = cfg.block_out_channels
         self.conv_in = self._conv("conv_in", cin_pad=8)
         self.time_l1 = self._lin("time_embedding.linear_1")
         self.time_l2 = self._lin("time_embedding.linear_2")
         self.cond_proj = self._lin("time_embedding.cond_proj") if cfg.cond_proj_dim else None
+        self.add_l1 = self._lin("add_embedding.linear_1") if cfg.add_time_dim else None
+        self.add_l2 = self._lin("add_embedding.linear_2") if cfg.add_time_dim else None
         self.down: List[List[Tuple[ResnetW, Optional[TransformerW]]]] = []
         self.downsamplers: List[Optional[PackedConv]] = []
         cin = ch[0]
@@ -139,13 +148,14 @@ class NetWeights:
             blk = []
             for j in range(cfg.layers_per_block):
                 r = self._resnet(f"down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
-                t = self._transformer(f"down_blocks.{i}.attentions.{j}", cout) if cfg.down_attn[i] else None
+                t = (self._transformer(f"down_blocks.{i}.attentions.{j}", cout, cfg.transformer_depth[i])
+                     if cfg.down_attn[i] else None)
                 blk.append((r, t))
             self.down.append(blk)
             self.downsamplers.append(self._conv(f"down_blocks.{i}.downsamplers.0.conv") if i < len(ch) - 1 else None)
             cin = cout
         self.mid = (self._resnet("mid_block.resnets.0", ch[-1], ch[-1]),
-                    self._transformer("mid_block.attentions.0", ch[-1]),
+                    self._transformer("mid_block.attentions.0", ch[-1], cfg.mid_depth),
                     self._resnet("mid_block.resnets.1", ch[-1], ch[-1]))
         if not is_controlnet:
             skips = skip_channels(cfg)
@@ -158,7 +168,8 @@ class NetWeights:
                 for j in range(cfg.layers_per_block + 1):
                     sc = skips.pop()
                     r = self._resnet(f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else cout) + sc, cout)
-                    t = self._transformer(f"up_blocks.{i}.attentions.{j}", cout) if cfg.up_attn[i] else None
+                    t = (self._transformer(f"up_blocks.{i}.attentions.{j}", cout, cfg.up_depth[i])
+                         if cfg.up_attn[i] else None)
                     blk.append((r, t))
                 self.up.append(blk)
                 self.upsamplers.append(self._conv(f"up_blocks.{i}.upsamplers.0.conv") if i < len(rev) - 1 else None)
@@ -213,20 +224,24 @@ class NetWeights:
         return ResnetW(cin, cout, self._norm(p + ".norm1"), self._conv(p + ".conv1", with_bias=False),
                        self._norm(p + ".norm2"), self._conv(p + ".conv2"), sc, off)
 
-    def _transformer(self, p, c) -> TransformerW:
+    def _transformer(self, p, c, depth=1) -> TransformerW:
         w = self._w
-        b = p + ".transformer_blocks.0"
-        ln = lambda n: (w[f"{b}.{n}.weight"], w[f"{b}.{n}.bias"])  # noqa: E731
-        qkv = self._to_dev(pack_linear_ln([w[f"{b}.attn1.to_q.weight"], w[f"{b}.attn1.to_k.weight"],
-                                           w[f"{b}.attn1.to_v.weight"]], None, *ln("norm1")))
-        q2 = self._to_dev(pack_linear_ln([w[f"{b}.attn2.to_q.weight"]], None, *ln("norm2")))
-        kv2 = self._to_dev(pack_linear_cat([w[f"{b}.attn2.to_k.weight"], w[f"{b}.attn2.to_v.weight"]]))
-        ff1 = self._to_dev(pack_geglu_ln(w[f"{b}.ff.net.0.proj.weight"], w[f"{b}.ff.net.0.proj.bias"], *ln("norm3")))
-        t = TransformerW(c, self._norm(p + ".norm"), self._conv(p + ".proj_in"), qkv, self._lin(b + ".attn1.to_out.0"),
-                         q2, kv2, self._lin(b + ".attn2.to_out.0"), ff1, self._lin(b + ".ff.net.2"),
-                         self._conv(p + ".proj_out"), len(self.transformers))
-        self.transformers.append(t)
-        return t
+        blocks = []
+        for kb in range(depth):
+            b = f"{p}.transformer_blocks.{kb}"
+            ln = lambda n: (w[f"{b}.{n}.weight"], w[f"{b}.{n}.bias"])  # noqa: E731
+            qkv = self._to_dev(pack_linear_ln([w[f"{b}.attn1.to_q.weight"], w[f"{b}.attn1.to_k.weight"],
+                                               w[f"{b}.attn1.to_v.weight"]], None, *ln("norm1")))
+            q2 = self._to_dev(pack_linear_ln([w[f"{b}.attn2.to_q.weight"]], None, *ln("norm2")))
+            kv2 = self._to_dev(pack_linear_cat([w[f"{b}.attn2.to_k.weight"], w[f"{b}.attn2.to_v.weight"]]))
+            ff1 = self._to_dev(pack_geglu_ln(w[f"{b}.ff.net.0.proj.weight"], w[f"{b}.ff.net.0.proj.bias"], *ln("norm3")))
+            blk = BlockW(qkv, self._lin(b + ".attn1.to_out.0"), q2, kv2, self._lin(b + ".attn2.to_out.0"), ff1,
+                         self._lin(b + ".ff.net.2"), len(self.transformers))
+            self.transformers.append(blk)
+            blocks.append(blk)
+        # use_linear_projection (SDXL): Linear on the token matrix == the 1x1 conv of SD1.5 in this layout
+        proj = self._lin if self.cfg.linear_proj else self._conv
+        return TransformerW(c, self._norm(p + ".norm"), proj(p + ".proj_in"), blocks, proj(p + ".proj_out"))
 
 
 class TAESDWeights:
@@ -289,6 +304,7 @@ class Engine:
         self.vae = TAESDWeights(ops, w_vae)
         self.guidance_scale = guidance_scale  # never forwarded by the reference (videopipeline.py:114-124): 7.5
         self.text = None
+        self.added = None  # SDXL: (pooled text embeds, 6 time ids)
         self.plan = None
         self.graph = None
         self.use_graph = True
@@ -328,11 +344,17 @@ class Engine:
             if first:
                 net.kv_cache = []
             for i, t in enumerate(net.transformers):
+                c = t.kv2.n // 2
                 if first:
-                    net.kv_cache.append((ops.zeros(tl, t.c), ops.zeros(t.c, ldt)))
+                    net.kv_cache.append((ops.zeros(tl, c), ops.zeros(c, ldt)))
                 k, vt = net.kv_cache[i]
-                ops.conv(self.text, None, Geom.linear(tl), t.kv2, k, ldo=t.c, out_t=vt, ldt=ldt, t_col0=t.c)
+                ops.conv(self.text, None, Geom.linear(tl), t.kv2, k, ldo=c, out_t=vt, ldt=ldt, t_col0=c)
         ops.synchronize()
+
+    def set_added_cond(self, pooled: torch.Tensor, time_ids):
+        """SDXL micro-conditioning: pooled text embedding [add_pooled_dim] and the 6 time ids
+        (orig_h, orig_w, crop_top, crop_left, target_h, target_w).  Takes effect at the next `prepare`."""
+        self.added = (pooled.detach().float().cpu().reshape(-1), [float(v) for v in time_ids])
 
     # ---------------------------------------------------------------- schedule-dependent constants
     def _time_embeddings(self, net: NetWeights, sched: LCMSchedule, out: torch.Tensor):
@@ -350,7 +372,21 @@ class Engine:
         h1 = ops.empty(n, cfg.temb_dim)
         ops.conv(x, None, Geom.linear(n), net.time_l1, h1, act=L.ACT_SILU)
         h2 = ops.empty(n, cfg.temb_dim)
-        ops.conv(h1, None, Geom.linear(n), net.time_l2, h2, act=L.ACT_SILU)  # SiLU(temb): all consumers apply it
+        if net.add_l1 is not None:
+            # SDXL text_time conditioning: temb += add_embedding(cat[pooled text embeds, sinusoids of the 6 time ids])
+            # (UNet2DConditionModel.get_aug_embed); the same vector for every step
+            if self.added is None:
+                raise RuntimeError("this UNet needs set_added_cond(pooled, time_ids) before prepare")
+            pooled, time_ids = self.added
+            tid = timestep_sinusoid([float(v) for v in time_ids], cfg.add_time_dim).reshape(1, -1)
+            a0 = ops.to_device(torch.cat([pooled.float().reshape(1, -1), tid], dim=-1).half().expand(n, -1).contiguous())
+            a1 = ops.empty(n, cfg.temb_dim)
+            ops.conv(a0, None, Geom.linear(n), net.add_l1, a1, act=L.ACT_SILU)
+            aug = ops.empty(n, cfg.temb_dim)
+            ops.conv(a1, None, Geom.linear(n), net.add_l2, aug)
+            ops.conv(h1, None, Geom.linear(n), net.time_l2, h2, residual=aug, act=L.ACT_SILU | L.ACT_POST)
+        else:
+            ops.conv(h1, None, Geom.linear(n), net.time_l2, h2, act=L.ACT_SILU)  # SiLU(temb): all consumers apply it
         ops.conv(h2, None, Geom.linear(n), net.temb_proj, out[:n])
         ops.synchronize()
 
@@ -378,7 +414,8 @@ class Engine:
 
     def _transformer(self, r, tw: TransformerW, net, x, hw, out2=None, add2=None):
         a, cfg = self.arena, net.cfg
-        c, heads = tw.c, cfg.heads
+        c = tw.c
+        heads = cfg.heads_for(c)
         d = c // heads
         lin = Geom.linear(hw)
         t = a.alloc(hw, c)
@@ -386,34 +423,39 @@ class Engine:
         # The three LayerNorms are never materialised: every producer of the token stream leaves per-row
         # (sum, sumsq) partials (rowstat_out) and the consuming GEMM applies the norm in its epilogue (ln_part).
         ng = c // 64
+        stat = lambda: a.alloc(hw, ng * 2, dtype=torch.float32).view(hw, ng, 2)  # noqa: E731
         h = a.alloc(hw, c)
-        rs = a.alloc(hw, ng * 2, dtype=torch.float32).view(hw, ng, 2)
+        rs = stat()
         r.conv(t, None, lin, tw.proj_in, h, rowstat_out=rs)
-        # self-attention
-        qk = a.alloc(hw, 2 * c)
         ldvt = _ru(hw, 64)
-        vt = self._vt_buffer(c, ldvt)
-        r.conv(h, None, lin, tw.qkv, qk, ldo=2 * c, out_t=vt, ldt=ldvt, t_col0=2 * c, ln_part=rs)
-        att = a.alloc(hw, c)
-        r.attention(qk, 2 * c, qk[:, c:], 2 * c, vt, ldvt, att, c, hw, hw, heads, d, d ** -0.5)
-        h1 = a.alloc(hw, c)
-        rs1 = a.alloc(hw, ng * 2, dtype=torch.float32).view(hw, ng, 2)
-        r.conv(att, None, lin, tw.out1, h1, residual=h, rowstat_out=rs1)
-        # cross-attention over the cached text K / V^T
-        q = a.alloc(hw, c)
-        r.conv(h1, None, lin, tw.q2, q, ln_part=rs1)
-        kt, vtt = net.kv_cache[tw.kv_index]
-        r.attention(q, c, kt, c, vtt, vtt.shape[1], att, c, hw, kt.shape[0], heads, d, d ** -0.5)
-        h2 = a.alloc(hw, c)
-        rs2 = a.alloc(hw, ng * 2, dtype=torch.float32).view(hw, ng, 2)
-        r.conv(att, None, lin, tw.out2, h2, residual=h1, rowstat_out=rs2)
-        # GEGLU feed-forward
-        f = a.alloc(hw, 4 * c)
-        r.conv(h2, None, lin, tw.ff1, f, ln_part=rs2)
-        h3 = a.alloc(hw, c)
-        r.conv(f, None, lin, tw.ff2, h3, residual=h2)
+        for bi, bw in enumerate(tw.blocks):
+            # self-attention
+            qk = a.alloc(hw, 2 * c)
+            vt = self._vt_buffer(c, ldvt)
+            r.conv(h, None, lin, bw.qkv, qk, ldo=2 * c, out_t=vt, ldt=ldvt, t_col0=2 * c, ln_part=rs)
+            att = a.alloc(hw, c)
+            r.attention(qk, 2 * c, qk[:, c:], 2 * c, vt, ldvt, att, c, hw, hw, heads, d, d ** -0.5)
+            h1 = a.alloc(hw, c)
+            rs1 = stat()
+            r.conv(att, None, lin, bw.out1, h1, residual=h, rowstat_out=rs1)
+            # cross-attention over the cached text K / V^T
+            q = a.alloc(hw, c)
+            r.conv(h1, None, lin, bw.q2, q, ln_part=rs1)
+            kt, vtt = net.kv_cache[bw.kv_index]
+            r.attention(q, c, kt, c, vtt, vtt.shape[1], att, c, hw, kt.shape[0], heads, d, d ** -0.5)
+            h2 = a.alloc(hw, c)
+            rs2 = stat()
+            r.conv(att, None, lin, bw.out2, h2, residual=h1, rowstat_out=rs2)
+            # GEGLU feed-forward
+            f = a.alloc(hw, 4 * c)
+            r.conv(h2, None, lin, bw.ff1, f, ln_part=rs2)
+            h3 = a.alloc(hw, c)
+            last = bi == len(tw.blocks) - 1
+            rs = None if last else stat()  # the next block's norm1 statistics
+            r.conv(f, None, lin, bw.ff2, h3, residual=h2, rowstat_out=rs)
+            h = h3
         out = a.alloc(hw, c)
-        r.conv(h3, None, lin, tw.proj_out, out, residual=x, out2=out2, add2=add2, chanstat_out=self._stat_buf(out, c))
+        r.conv(h, None, lin, tw.proj_out, out, residual=x, out2=out2, add2=add2, chanstat_out=self._stat_buf(out, c))
         return out
 
     # ---- fused GroupNorm statistics: a conv that writes a tensor a GroupNorm will read also leaves the tensor's

@@ -43,23 +43,30 @@ def _resnet(spec: Spec, p: str, cin: int, cout: int, temb: int):
         _conv(spec, p + ".conv_shortcut", cout, cin, 1)
 
 
-def _transformer(spec: Spec, p: str, c: int, cross: int):
+def _transformer(spec: Spec, p: str, c: int, cross: int, depth: int = 1, linear_proj: bool = False):
     _norm(spec, p + ".norm", c)
-    _conv(spec, p + ".proj_in", c, c, 1)
-    b = p + ".transformer_blocks.0"
-    _norm(spec, b + ".norm1", c)
-    for n in ("to_q", "to_k", "to_v"):
-        _lin(spec, f"{b}.attn1.{n}", c, c, bias=False)
-    _lin(spec, b + ".attn1.to_out.0", c, c)
-    _norm(spec, b + ".norm2", c)
-    _lin(spec, b + ".attn2.to_q", c, c, bias=False)
-    _lin(spec, b + ".attn2.to_k", c, cross, bias=False)
-    _lin(spec, b + ".attn2.to_v", c, cross, bias=False)
-    _lin(spec, b + ".attn2.to_out.0", c, c)
-    _norm(spec, b + ".norm3", c)
-    _lin(spec, b + ".ff.net.0.proj", 8 * c, c)
-    _lin(spec, b + ".ff.net.2", c, 4 * c)
-    _conv(spec, p + ".proj_out", c, c, 1)
+    if linear_proj:
+        _lin(spec, p + ".proj_in", c, c)
+    else:
+        _conv(spec, p + ".proj_in", c, c, 1)
+    for k in range(depth):
+        b = f"{p}.transformer_blocks.{k}"
+        _norm(spec, b + ".norm1", c)
+        for n in ("to_q", "to_k", "to_v"):
+            _lin(spec, f"{b}.attn1.{n}", c, c, bias=False)
+        _lin(spec, b + ".attn1.to_out.0", c, c)
+        _norm(spec, b + ".norm2", c)
+        _lin(spec, b + ".attn2.to_q", c, c, bias=False)
+        _lin(spec, b + ".attn2.to_k", c, cross, bias=False)
+        _lin(spec, b + ".attn2.to_v", c, cross, bias=False)
+        _lin(spec, b + ".attn2.to_out.0", c, c)
+        _norm(spec, b + ".norm3", c)
+        _lin(spec, b + ".ff.net.0.proj", 8 * c, c)
+        _lin(spec, b + ".ff.net.2", c, 4 * c)
+    if linear_proj:
+        _lin(spec, p + ".proj_out", c, c)
+    else:
+        _conv(spec, p + ".proj_out", c, c, 1)
 
 
 def _encoder_half(spec: Spec, cfg: UNetConfig):
@@ -70,22 +77,26 @@ def _encoder_half(spec: Spec, cfg: UNetConfig):
     _lin(spec, "time_embedding.linear_2", cfg.temb_dim, cfg.temb_dim)
     if cfg.cond_proj_dim:
         _lin(spec, "time_embedding.cond_proj", ch[0], cfg.cond_proj_dim, bias=False)
+    if cfg.add_time_dim:  # SDXL text_time conditioning: TimestepEmbedding(pooled + 6 sinusoids -> temb_dim)
+        _lin(spec, "add_embedding.linear_1", cfg.temb_dim, cfg.add_in_dim)
+        _lin(spec, "add_embedding.linear_2", cfg.temb_dim, cfg.temb_dim)
     cin = ch[0]
     for i, cout in enumerate(ch):
         for j in range(cfg.layers_per_block):
             _resnet(spec, f"down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout, cfg.temb_dim)
             if cfg.down_attn[i]:
-                _transformer(spec, f"down_blocks.{i}.attentions.{j}", cout, cfg.cross_dim)
+                _transformer(spec, f"down_blocks.{i}.attentions.{j}", cout, cfg.cross_dim, cfg.transformer_depth[i],
+                             cfg.linear_proj)
         if i < len(ch) - 1:
             _conv(spec, f"down_blocks.{i}.downsamplers.0.conv", cout, cout, 3)
         cin = cout
     _resnet(spec, "mid_block.resnets.0", ch[-1], ch[-1], cfg.temb_dim)
-    _transformer(spec, "mid_block.attentions.0", ch[-1], cfg.cross_dim)
+    _transformer(spec, "mid_block.attentions.0", ch[-1], cfg.cross_dim, cfg.mid_depth, cfg.linear_proj)
     _resnet(spec, "mid_block.resnets.1", ch[-1], ch[-1], cfg.temb_dim)
 
 
 def skip_channels(cfg: UNetConfig) -> List[int]:
-    """Channel count of each of the 12 skip tensors in push order."""
+    """Channel count of each skip tensor (12 for SD1.5, 9 for SDXL) in push order."""
     ch = cfg.block_out_channels
     out = [ch[0]]
     for i, c in enumerate(ch):
@@ -108,7 +119,7 @@ def unet_spec(cfg: UNetConfig) -> Spec:
             cin = (prev if j == 0 else cout) + sc
             _resnet(spec, f"up_blocks.{i}.resnets.{j}", cin, cout, cfg.temb_dim)
             if cfg.up_attn[i]:
-                _transformer(spec, f"up_blocks.{i}.attentions.{j}", cout, cfg.cross_dim)
+                _transformer(spec, f"up_blocks.{i}.attentions.{j}", cout, cfg.cross_dim, cfg.up_depth[i], cfg.linear_proj)
         if i < len(rev) - 1:
             _conv(spec, f"up_blocks.{i}.upsamplers.0.conv", cout, cout, 3)
         prev = cout
