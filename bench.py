@@ -86,7 +86,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--slots", type=int, default=3, help="frames in flight per GPU (independent frames, one graph each)")
+    ap.add_argument("--slots", type=int, default=3, help="launches in flight per GPU (independent frames, one graph each)")
+    ap.add_argument("--batch", type=int, default=1, help="frames per launch (stacked along the GEMM M dimension)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--retune", action="store_true", help="ignore profiles/tuning_mi355x.json and time all kernel configs again")
     ap.add_argument("--save-tuning", action="store_true", help="write the tuning table back to profiles/tuning_mi355x.json")
@@ -121,39 +122,44 @@ def main():
     # throughput configuration: several frames in flight, one stream each (with >= 3 frames in flight the GPU's
     # hardware queues are already full, so the intra-frame ControlNet/UNet two-stream overlap is switched off;
     # the single-frame latency below is measured with it on)
+    B = max(1, args.batch)
     eng.overlap_controlnet = args.slots < 3
-    plan = eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True)
+    plan = eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=B)
     # frames are independent (the reference resets its RNG per frame): keep `slots` of them in flight per GPU,
     # each with its own buffers, streams and hipGraph, sharing the weight replica
     engines = [eng]
     for _ in range(max(1, args.slots) - 1):
         sl = eng.make_slot()
-        sl.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True)
+        sl.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=B)
         engines.append(sl)
 
     # this rank's shard of the synthetic stream, resident in HBM before the timed region
-    nres = 8
+    nres = 12
     frames_host = synthetic_frames(nres * world, H, W)[rank::world]
     frames_dev = ops.to_device(torch.from_numpy(frames_host))
 
     def one_frame(i, pool=None):
+        """launch i: the next B frames of this rank's shard (device-to-device, on the slot's own stream), one graph replay"""
         pool = pool or engines
         e = pool[i % len(pool)]
-        e.ops.copy_(e.frame_u8, frames_dev[i % nres])  # device-to-device, on the slot's own stream
+        nb = e.plan["batch"]
+        k = (i * nb) % nres
+        e.ops.copy_(e.frame_u8, frames_dev[k:k + nb] if k + nb <= nres else frames_dev[:nb])
         e.launch()
 
     def sync_all():
         for e in engines:
             e.ops.synchronize()
 
-    for i in range(args.warmup):
+    n_launch = -(-args.steps // B)  # K frames = ceil(K / B) launches (a ragged last launch still does B frames of work)
+    for i in range(-(-args.warmup // B)):
         one_frame(i)
     sync_all()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(n_launch):
         one_frame(i)
     sync_all()
     torch.cuda.synchronize()
@@ -185,11 +191,11 @@ def main():
                 lat_loaded.append((time.perf_counter() - t_sub[i - len(engines)]) * 1e3)
             if i < nl:
                 t_sub[i] = time.perf_counter()
-                e.ops.upload(e.frame_u8, torch.from_numpy(frames_host[i % nres]))
+                e.ops.upload(e.frame_u8, torch.from_numpy(frames_host[:B]))
                 e.launch()
         sync_all()
     eng.overlap_controlnet = True
-    eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True)
+    eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
     lat = []
     for i in range(min(30, max(5, args.steps))):
         t1 = time.perf_counter()
@@ -198,24 +204,25 @@ def main():
     p50 = statistics.median(lat)
 
     # ---- the same graph without the ControlNet tower (engine extension)
+    eng.overlap_controlnet = args.slots < 3
     for e in engines:
-        e.prepare(H, W, LCM_STEPS, STRENGTH, use_controlnet=False)
+        e.prepare(H, W, LCM_STEPS, STRENGTH, use_controlnet=False, batch=B)
     for i in range(3):
         one_frame(i)
     sync_all()
     t1 = time.perf_counter()
-    nn = max(10, args.steps // 3)
+    nn = max(10, args.steps // 3 // B)
     for i in range(nn):
         one_frame(i)
     sync_all()
-    fps_nocn = nn / (time.perf_counter() - t1)
+    fps_nocn = nn * B / (time.perf_counter() - t1)
 
     if args.save_tuning:
         ops.save_tuning(tuning)
 
     # ---- dominant kernel (implicit-GEMM conv) against the MFMA roofline: HIP events around every launch of
     #      one eager pass of the same program on the same stream
-    eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
+    eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, use_graph=False, batch=B)
     one_frame(0, [eng])
     ops.synchronize()
     ops.profile_begin()
@@ -236,21 +243,21 @@ def main():
     roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear, all shapes of one frame)",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "launches_per_frame": cg["launches"], "avg_launch_us": round(cg_ms * 1e3 / max(cg["launches"], 1), 2),
+                "launches_per_pass": cg["launches"], "frames_per_pass": B, "avg_launch_us": round(cg_ms * 1e3 / max(cg["launches"], 1), 2),
                 "avg_launch_us_raw_events": round(cg["ms"] * 1e3 / max(cg["launches"], 1), 2),
                 "event_bracket_overhead_us": round(ovh_ms * 1e3, 2),
                 "flop_per_launch_avg": cg["flops"] / max(cg["launches"], 1),
-                "families_ms_per_frame": {k: round(v["ms"], 3) for k, v in st.items()}}
+                "families_ms_per_pass": {k: round(v["ms"], 3) for k, v in st.items()}}
 
     out = {
         "metric": "frames/sec (whole node) + p50 per-frame latency, SD1.5 512x512 LCM 4-step",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 3),  # wall time per frame (K frames in ceil(K/B) launches) "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16 (fp32 accumulate)", "data": "synthetic",
         "config": {"workload": "SD1.5 512x512 LCM 4-step img2img, batch=1, ControlNet-canny + TAESD (BASELINE configs[1], "
                                "reference-faithful: the reference always runs ControlNet)",
                    "frames_per_rank": args.steps, "sharding": f"round-robin frames over {world} GPU(s)",
-                   "frames_in_flight_per_gpu": len(engines),
+                   "frames_per_launch": B, "launches_in_flight_per_gpu": len(engines),
                    "timesteps": plan["timesteps"], "kernels_per_frame": plan["n_ops"]},
         "p50_latency_ms": round(p50, 3),
         "p50_latency_ms_under_load": round(statistics.median(lat_loaded), 3) if lat_loaded else None,

@@ -115,6 +115,12 @@ typedef struct vsd_conv_desc {
                              inside the kernel (the last workgroup to arrive at a tile sums the slabs in a fixed
                              order and runs the epilogue, leaving its counter at zero); when NULL a second
                              kernel (splitk_reduce) does it.  Results are bit-identical either way. */
+  int32_t batch;          /* images stacked along M (0 or 1: a single image): M = batch * ho * wo, every image has the
+                             geometry above, image b's rows are [b*ho*wo, (b+1)*ho*wo) of the output / residuals and
+                             its source pixels start at row b*hs*ws of src0 / src1.  Several frames (of independent
+                             streams) share one launch and one pass over the weights. */
+  int32_t t_img;          /* transposed output with batch > 1: image b's row m goes to column b*t_img + (m - b*ho*wo)
+                             of out_t (t_img >= ho*wo, a multiple of 8; 0 = ho*wo) */
 } vsd_conv_desc;
 #define VSD_SPLITK_MAX_TILES 16384
 
@@ -126,7 +132,12 @@ int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream);
 int64_t vsd_groupnorm_workspace_bytes(int hw, int c, int groups);
 int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int groups, float eps,
                   const void* gamma, const void* beta, int silu, void* out, void* workspace, void* stream);
-/* Same, with the statistics pass skipped: chan0 / chan1 are the per-channel (sum, sumsq) fp32 [c][2] arrays the
+/* `batch` images stacked along the rows ([batch*hw][C]), each normalised with its own statistics.
+ * workspace: >= batch * vsd_groupnorm_workspace_bytes(hw, c0 + c1, groups) bytes.                     */
+int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int batch, int groups,
+                          float eps, const void* gamma, const void* beta, int silu, void* out, void* workspace,
+                          void* stream);
+/* Same as vsd_groupnorm, with the statistics pass skipped: chan0 / chan1 are the per-channel (sum, sumsq) fp32 [c][2] arrays the
  * producing vsd_conv_gemm launches left behind (chanstat_out) for src0 / src1.  One kernel instead of two. */
 int vsd_groupnorm_prestat(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int groups, float eps,
                           const void* gamma, const void* beta, int silu, void* out, const void* chan0, const void* chan1,
@@ -142,6 +153,13 @@ int vsd_layernorm(vsd_ctx* ctx, const void* x, int rows, int c, const void* gamm
  * d in {8..160}, multiple of 8.  causal != 0: key j visible to query i iff j <= i (CLIP).            */
 int vsd_attention(vsd_ctx* ctx, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out,
                   int ldo, int sq, int sk, int heads, int d, float scale, int causal, void* stream);
+
+/* `batch` independent problems in one launch: image b uses q / out rows [b*sq, (b+1)*sq), k rows from b*k_batch_rows
+ * (sk for self-attention, 0 when all images share the keys, e.g. the text) and V^T columns from b*vt_batch_cols
+ * (a multiple of 8; 0 when shared).  V^T beyond an image's sk keys must be finite (the next image or zeros).   */
+int vsd_attention_batched(vsd_ctx* ctx, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* out,
+                          int ldo, int sq, int sk, int heads, int d, float scale, int causal, int batch, int k_batch_rows,
+                          int vt_batch_cols, void* stream);
 
 /* ---- per-frame elementwise kernels -----------------------------------------------------------------
  * Latent-like tensors (4 channels) are stored with row stride 8 (channels 4..7 zero).                 */

@@ -54,18 +54,19 @@ class FakeOps:
         return src.clone()
 
     @staticmethod
-    def _nhwc(t, h, w, c):
-        """[h*w][>=c] buffer (possibly a strided view) -> NCHW fp32"""
-        return t[:, :c].float().reshape(h, w, c).permute(2, 0, 1)[None]
+    def _nhwc(t, h, w, c, b=1):
+        """[b*h*w][>=c] buffer (possibly a strided view) -> NCHW fp32"""
+        return t[:, :c].float().reshape(b, h, w, c).permute(0, 3, 1, 2)
 
     def conv(self, src0, src1, g, w, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None, residual2=None,
              ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0, t_col0=0, tile=None,
              split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None, ln_eps=1e-5,
-             chanstat_out=None):
+             chanstat_out=None, t_img=0):
         c0 = c0 if c0 is not None else (w.cin - c1)
-        x = self._nhwc(src0, g.hs, g.ws, c0)
+        B = g.batch
+        x = self._nhwc(src0, g.hs, g.ws, c0, B)
         if src1 is not None and c1:
-            x = torch.cat([x, self._nhwc(src1, g.hs, g.ws, c1)], dim=1)
+            x = torch.cat([x, self._nhwc(src1, g.hs, g.ws, c1, B)], dim=1)
         assert x.shape[1] == w.cin, (x.shape, w.cin)
         if (g.hi, g.wi) != (g.hs, g.ws):
             x = F.interpolate(x, size=(g.hi, g.wi), mode="nearest")
@@ -86,7 +87,7 @@ class FakeOps:
         wt = wt.reshape(w.n, w.ksize, w.ksize, w.cin).permute(0, 3, 1, 2)
         y = F.conv2d(x, wt, bias, stride=g.stride, padding=g.pad)
         assert y.shape[2:] == (g.ho, g.wo), (y.shape, g)
-        y = y[0].permute(1, 2, 0).reshape(g.m, w.n)
+        y = y.permute(0, 2, 3, 1).reshape(g.m, w.n)
         if ln_part is not None:
             tot = ln_part.float().sum(dim=1)  # [M, 2]
             mean = tot[:, 0] / w.k
@@ -116,7 +117,14 @@ class FakeOps:
         nout = y.shape[1]
         if out_t is not None:
             yt = y[:, t_col0:]
-            out_t[: yt.shape[1], : g.m] = yt.t().half()
+            if B == 1:
+                out_t[: yt.shape[1], : g.m] = yt.t().half()
+            else:
+                hw = g.m // B
+                ti = t_img or hw
+                assert ti >= hw and B * ti <= out_t.shape[1]
+                for b in range(B):
+                    out_t[: yt.shape[1], b * ti: b * ti + hw] = yt[b * hw:(b + 1) * hw].t().half()
             y = y[:, :t_col0]
             nout = t_col0
         if residual is not None:
@@ -137,7 +145,14 @@ class FakeOps:
         if out2 is not None:
             out2[:, :nout] = (y + add2[:, :nout].float()).half()
 
-    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=None):
+    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=None, batch=1):
+        if batch > 1:
+            assert chan_stats is None
+            for b in range(batch):
+                sl = slice(b * hw, (b + 1) * hw)
+                self.groupnorm(src0[sl], None if src1 is None else src1[sl], c0, c1, hw, groups, eps, gamma, beta, silu,
+                               out[sl])
+            return
         x = src0[:, :c0].float()
         if src1 is not None and c1:
             x = torch.cat([x, src1[:, :c1].float()], dim=1)
@@ -160,12 +175,20 @@ class FakeOps:
     def layernorm(self, x, rows, c, gamma, beta, eps, out):
         out[:, :c] = F.layer_norm(x[:, :c].float(), (c,), gamma.float(), beta.float(), eps).half()
 
-    def attention(self, q, ldq, k, ldk, vt, ldvt, out, ldo, sq, sk, heads, d, scale, causal=False):
+    def attention(self, q, ldq, k, ldk, vt, ldvt, out, ldo, sq, sk, heads, d, scale, causal=False, batch=1, k_brows=0,
+                  vt_bcols=0):
+        if batch > 1:
+            for b in range(batch):
+                self.attention(q[b * sq:], ldq, k[b * k_brows:], ldk, vt[:, b * vt_bcols:], ldvt, out[b * sq:], ldo, sq, sk,
+                               heads, d, scale, causal, batch=-1)
+            return
         c = heads * d
         qh = q[:sq, :c].float().reshape(sq, heads, d).transpose(0, 1)
         kh = k[:sk, :c].float().reshape(sk, heads, d).transpose(0, 1)
         vh = vt[:c, :sk].float().t().reshape(sk, heads, d).transpose(0, 1)
-        assert (vt[:c, sk:] == 0).all(), "V^T key padding must be zero"
+        pad_end = -(-sk // 64) * 64
+        assert batch == -1 or (vt[:c, sk:pad_end] == 0).all(), "V^T key padding must be zero"
+        assert torch.isfinite(vt[:c, sk:pad_end].float()).all()
         s = qh @ kh.transpose(-1, -2) * scale
         if causal:
             s = s + torch.full((sq, sk), float("-inf")).triu(1)
@@ -173,7 +196,7 @@ class FakeOps:
         out[:sq, :c] = o.half()
 
     def preprocess_rgb(self, rgb_u8, h, w, out):
-        x = rgb_u8.reshape(h * w, 3).float() / 255.0
+        x = rgb_u8.reshape(h * w, 3).float() / 255.0  # h may be batch * H: purely per pixel
         y = (2.0 * x - 1.0).half()
         out.zero_()
         out[:, :3] = ((y.float() + 1.0).half().float() * 0.5).half()

@@ -86,6 +86,26 @@ def test_sdxl_shaped_engine_program_matches_oracle(H, Wd, steps):
     assert np.abs(got.astype(int) - ref.astype(int)).mean() < 1.5
 
 
+@pytest.mark.parametrize("H,Wd,cn", [(64, 64, True), (56, 40, True), (48, 72, False)])
+def test_batched_frames_equal_single_frames(mini, H, Wd, cn):
+    """Several frames stacked along M in one program (prepare(batch=B)) give every frame the result it gets alone:
+    per-image conv padding, GroupNorm statistics, self-attention keys, Sobel maximum and noise draws."""
+    wu, wc, wv, text = mini
+    frames = np.stack([_frame(H, Wd, seed=s) for s in (1, 2, 3)])
+    eng = Engine(FakeOps(), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
+    eng.set_text_embeds(text)
+    eng.prepare(H, Wd, 2, 0.6, controlnet_scale=1.5, use_controlnet=cn, use_graph=False)
+    single = np.stack([eng.infer_u8(f) for f in frames])
+    eng.prepare(H, Wd, 2, 0.6, controlnet_scale=1.5, use_controlnet=cn, use_graph=False, batch=3)
+    assert eng.plan["batch"] == 3
+    got = eng.infer_u8(frames)
+    assert got.shape == single.shape
+    diff = np.abs(got.astype(int) - single.astype(int))  # torch's batched conv sums in a different order: a few LSB flips
+    assert diff.max() <= 4 and diff.mean() < 0.25, (diff.max(), diff.mean())
+    with pytest.raises(ValueError):
+        eng.infer_u8(frames[0])
+
+
 def test_fused_groupnorm_statistics_wiring(mini):
     """The optional producer-side GroupNorm statistics (chanstat_out -> groupnorm(chan_stats=...)) reach every
     GroupNorm with the right tensors: same image as the default path, through the emulator."""

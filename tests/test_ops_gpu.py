@@ -526,3 +526,93 @@ def test_errors_are_reported_not_fatal(ops):
         ops.conv(x, x, Geom.conv(4, 4), pw, out, c0=40, c1=24)
     with pytest.raises(RuntimeError, match="head_dim"):
         ops.attention(x, 64, x, 64, x, 64, out, 64, 16, 16, 1, 12, 1.0)
+
+
+# ---------------------------------------------------------------------------------------------- batched launches
+@pytest.mark.parametrize("h,w,stride,up,c1,pipeline,tile,split", [(18, 14, 1, None, 0, 3, 2, 1), (18, 14, 1, None, 64, 0, 1, 3),
+                                                                   (27, 48, 2, None, 0, 5, 0, 1), (7, 12, 1, (14, 24), 0, 4, 3, 2),
+                                                                   (9, 9, 1, None, 0, 6, 2, 4)])
+def test_conv_batched_images_keep_their_borders(ops, h, w, stride, up, c1, pipeline, tile, split):
+    """vsd_conv_desc.batch: B images stacked along M; zero padding, stride, nearest resize and channel concat are per
+    image (no bleeding across the image boundary)."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    B, c0, cout = 3, 128, 96
+    cin = c0 + c1
+    xs = rnd(B, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
+    bias = rnd(cout, seed=3, scale=0.1)
+    pw = ops.to_device_pack(pack_conv(wt, bias))
+    g = Geom.conv(h, w, stride=stride, up_to=up, batch=B)
+    nhwc = xs.permute(0, 2, 3, 1).reshape(B * h * w, cin)
+    s0 = nhwc[:, :c0].contiguous().cuda()
+    s1 = nhwc[:, c0:].contiguous().cuda() if c1 else None
+    res = rnd(g.m, cout, seed=5)
+    out = torch.zeros(g.m, cout, dtype=torch.float16, device="cuda")
+    ops.conv(s0, s1, g, pw, out, c0=c0, c1=c1, residual=res.cuda(), act=2, tile=tile, split_k=split, pipeline=pipeline)
+    ops.synchronize()
+    xin = xs.float()
+    if up is not None:
+        xin = F.interpolate(xin, size=up, mode="nearest")
+    ref = F.silu(F.conv2d(xin, wt.float(), bias.float(), stride=stride, padding=1))
+    ref = ref.permute(0, 2, 3, 1).reshape(g.m, cout) + res.float()
+    check(out, ref, f"batched conv {h}x{w} stride={stride} up={up}")
+
+
+def test_qkv_batched_transposed_output_slabs(ops):
+    """Transposed (V^T) output with batch: image b's tokens land in columns [b*t_img, b*t_img + hw), padding stays 0."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_linear_cat
+
+    B, hw, c = 3, 84, 128  # 84 tokens (7x12 latent): not a multiple of 8
+    t_img = 128
+    x = rnd(B * hw, c, seed=1)
+    wq, wk, wv = (rnd(c, c, seed=i, scale=c ** -0.5) for i in (2, 3, 4))
+    pw = ops.to_device_pack(pack_linear_cat([wq, wk, wv]))
+    qk = torch.zeros(B * hw, 2 * c, dtype=torch.float16, device="cuda")
+    vt = torch.zeros(c, B * t_img, dtype=torch.float16, device="cuda")
+    for split in (1, 2):
+        vt.zero_()
+        ops.conv(x.cuda(), None, Geom.linear(hw, batch=B), pw, qk, ldo=2 * c, out_t=vt, ldt=B * t_img, t_col0=2 * c,
+                 t_img=t_img, split_k=split, tile=2)
+        ops.synchronize()
+        check(qk[:, :c], F.linear(x.float(), wq.float()), "q")
+        v = F.linear(x.float(), wv.float())
+        for b in range(B):
+            check(vt[:, b * t_img: b * t_img + hw], v[b * hw:(b + 1) * hw].t(), f"v^T image {b}")
+            assert (vt[:, b * t_img + hw:(b + 1) * t_img] == 0).all()
+
+
+@pytest.mark.parametrize("c0,c1,hw,silu", [(320, 0, 1024, True), (128, 64, 35, False), (1280, 1280, 64, True)])
+def test_groupnorm_batched(ops, c0, c1, hw, silu):
+    B, c = 3, c0 + c1
+    a = rnd(B * hw, c0, seed=1) * torch.tensor([1.0, 3.0, 0.3]).repeat_interleave(hw)[:, None].half() + 0.5
+    b = rnd(B * hw, c1, seed=2) if c1 else None
+    gamma, beta = (1 + 0.1 * rnd(c, seed=3).float()).half(), rnd(c, seed=4, scale=0.1)
+    out = torch.zeros(B * hw, c, dtype=torch.float16, device="cuda")
+    ops.groupnorm(a.cuda(), None if b is None else b.cuda(), c0, c1, hw, 32, 1e-5, gamma.cuda(), beta.cuda(), silu, out, batch=B)
+    ops.synchronize()
+    x = a.float() if b is None else torch.cat([a.float(), b.float()], dim=1)
+    ref = F.group_norm(x.reshape(B, hw, c).transpose(1, 2), 32, gamma.float(), beta.float(), 1e-5).transpose(1, 2).reshape(B * hw, c)
+    if silu:
+        ref = F.silu(ref)
+    check(out, ref, f"batched groupnorm C={c} hw={hw}")
+
+
+@pytest.mark.parametrize("sq,heads,d", [(84, 8, 40), (256, 4, 64), (1024, 8, 80)])
+def test_attention_batched_self(ops, sq, heads, d):
+    """Self-attention of B images in one launch: keys never cross an image boundary."""
+    B, c = 3, heads * d
+    t_img = (sq + 63) // 64 * 64
+    q, k, v = rnd(B * sq, c, seed=1), rnd(B * sq, c, seed=2), rnd(B * sq, c, seed=3)
+    vt = torch.zeros(c, B * t_img, dtype=torch.float16)
+    for b in range(B):
+        vt[:, b * t_img: b * t_img + sq] = v[b * sq:(b + 1) * sq].t()
+    out = torch.zeros(B * sq, c, dtype=torch.float16, device="cuda")
+    ops.attention(q.cuda(), c, k.cuda(), c, vt.cuda(), B * t_img, out, c, sq, sq, heads, d, d ** -0.5, batch=B, k_brows=sq,
+                  vt_bcols=t_img)
+    ops.synchronize()
+    sp = lambda t: t.float().reshape(B, sq, heads, d).transpose(1, 2)  # noqa: E731
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B * sq, c)
+    check(out, ref, f"batched attention sq={sq} d={d}", rel=3e-3)

@@ -114,6 +114,30 @@ def test_two_frames_in_flight_equal_sequential_results(mini_setup):
             assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("H,W,cn", [(128, 128, True), (120, 72, True), (96, 160, False)])
+def test_batched_frames_match_oracle_and_single_frames(mini_setup, H, W, cn):
+    """prepare(batch=3): three frames per launch.  Every frame matches the oracle like a lone frame does, and stays
+    within a few LSB of its single-frame result (different tiling / split-K => different fp32 summation order)."""
+    eng, orc, text = mini_setup
+    frames = np.stack([_frame(H, W, seed=s) for s in (21, 22, 23)])
+    eng.prepare(H, W, 2, 0.6, controlnet_scale=1.5, use_controlnet=cn)
+    single = np.stack([eng.infer_u8(f) for f in frames])
+    eng.prepare(H, W, 2, 0.6, controlnet_scale=1.5, use_controlnet=cn, batch=3)
+    got = eng.infer_u8(frames)
+    assert np.array_equal(got, eng.infer_u8(frames))  # deterministic replay
+    h0, w0 = H // 8, W // 8
+    den = eng.buffers["denoised"][:, :4].float().cpu().reshape(3, h0, w0, 4).permute(0, 3, 1, 2)
+    for b in range(3):
+        ref = np.asarray(orc.infer(Image.fromarray(frames[b], "RGB"), text[None].float(), height=H, width=W, strength=0.6,
+                                   steps=2, seed=23, controlnet_scale=1.5, use_controlnet=cn, keep_trace=True))
+        ref_den = orc.trace["denoised"][-1][0]
+        r1 = float((den[b] - ref_den).norm() / ref_den.norm())
+        mad = float(np.abs(got[b].astype(int) - ref.astype(int)).mean())
+        assert r1 <= 2e-2 and mad <= 1.5 and _psnr(got[b], ref) >= 38.0, (b, r1, mad)
+        assert np.abs(got[b].astype(int) - single[b].astype(int)).mean() < 0.5
+    eng.prepare(H, W, 2, 0.6, controlnet_scale=1.5, use_controlnet=cn, batch=1)
+
+
 @pytest.fixture(scope="module")
 def sd15_setup():
     from oracle.pipeline import OraclePipeline

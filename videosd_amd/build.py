@@ -7,6 +7,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvsd.so")
 SOURCES = ["api.hip", "conv_gemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+# attention keeps its O / S accumulators live across the key loop and touches them with VALU every tile (online-softmax
+# rescale, exp): with the default AGPR placement the compiler moves them through v_accvgpr_read/write every tile
+# (~190 of 1300 instructions in the d=40 kernel); VGPR-form MFMA operands remove those moves.
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def needs_build() -> bool:
@@ -26,7 +30,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for f in SOURCES:
         o = os.path.join(HERE, "build", f.replace(".hip", ".o"))
-        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", os.path.join(CSRC, f), "-o", o]
+        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"] + EXTRA_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), f))

@@ -59,6 +59,10 @@ struct ConvParams {
   const half_t* zeros;  // >= 16 zero bytes: source of out-of-bounds chunks for the direct-to-LDS loader
   int* counters;  // per-tile arrival tickets for the in-kernel split-K reduction (all zero between launches)
   int tiles_m, tiles_n;
+  int batch;    // images stacked along M: M = batch * ho * wo, image b's source pixels start at b * hs * ws
+  int hw_out;   // ho * wo
+  int img_in;   // hs * ws
+  int t_img;    // transposed output: columns per image (image b's rows m land at b * t_img + (m - b * hw_out))
 };
 
 // ---------------------------------------------------------------- epilogue (shared with the reducer)
@@ -104,9 +108,14 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
     for (int i = 0; i < 8; ++i) v[i] *= p.out_scale;
   }
   if (p.out_t && n >= p.t_col0) {
+    int col = m;
+    if (p.batch > 1) {
+      const int b = m / p.hw_out;
+      col = b * p.t_img + (m - b * p.hw_out);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (n + i < p.N) p.out_t[(size_t)(n + i - p.t_col0) * p.ldt + m] = (half_t)v[i];
+      if (n + i < p.N) p.out_t[(size_t)(n + i - p.t_col0) * p.ldt + col] = (half_t)v[i];
     return;
   }
   if (full) {
@@ -286,13 +295,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   // ---- loader coordinates
   const int cc = tid & 7;    // 16-byte chunk within the 128-byte tile row
   const int lr = tid >> 3;   // 0..31
-  int iy0[AR], ix0[AR];
+  int iy0[AR], ix0[AR], ib[AR];  // ib: first source pixel of the row's image
   bool mvalid[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     int m = m0 + lr + 32 * i;
     mvalid[i] = m < p.M;
     int mm = mvalid[i] ? m : 0;
+    int b = 0;
+    if (p.batch > 1) {
+      b = mm / p.hw_out;
+      mm -= b * p.hw_out;
+    }
+    ib[i] = b * p.img_in;
     int oy = mm / p.wo, ox = mm - oy * p.wo;
     iy0[i] = oy * p.stride - p.pad;
     ix0[i] = ox * p.stride - p.pad;
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi; \
       /* nearest resize as a fixed-point multiply: floor(i*hs/hi) exactly for i*hi < 2^22 (identity: 2^22) */ \
       const int sy = (int)(((unsigned)iy * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)ix * p.rmul_x) >> p.rshift); \
-      size_t off = ok ? ((size_t)(sy * p.ws + sx)) * cs_ + c_ : 0;                                  \
+      size_t off = ok ? ((size_t)(ib[i] + sy * p.ws + sx)) * cs_ + c_ : 0;                                  \
       u32x4 v = *reinterpret_cast<const u32x4*>(src_ + off);                                        \
       areg[i] = ok ? v : zero4;                                                                     \
     }                                                                                               \
@@ -453,7 +468,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       int iy = iy0[i] + ky_, ix = ix0[i] + kx_;                                                       \
       bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi;  \
       const int sy = (int)(((unsigned)iy * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)ix * p.rmul_x) >> p.rshift); \
-      const half_t* g_ = ok ? src_ + ((size_t)(sy * p.ws + sx)) * cs_ + c_ : p.zeros;                 \
+      const half_t* g_ = ok ? src_ + ((size_t)(ib[i] + sy * p.ws + sx)) * cs_ + c_ : p.zeros;                 \
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(a_ + (8 * wave + 32 * i) * BK), 16, 0, 0); \
     }                                                                                                 \
   }
@@ -562,7 +577,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             int iy = iy0[i] + ky_, ix = ix0[i] + kx_;
             bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi;
             const int sy = (int)(((unsigned)iy * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)ix * p.rmul_x) >> p.rshift);
-            const half_t* g_ = ok ? src_ + ((size_t)(sy * p.ws + sx)) * cs_ + c_ : p.zeros;
+            const half_t* g_ = ok ? src_ + ((size_t)(ib[i] + sy * p.ws + sx)) * cs_ + c_ : p.zeros;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(na + (8 * wave + 32 * i) * BK), 16, 0, 0);
           }
           if (pc == 0) {
@@ -891,7 +906,11 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   }
   p.generic = (p.cin % 64) != 0;
   p.w = (const half_t*)d->weight;
-  p.M = d->ho * d->wo;
+  p.batch = d->batch < 1 ? 1 : d->batch;
+  p.hw_out = d->ho * d->wo;
+  p.img_in = d->hs * d->ws;
+  p.t_img = d->t_img > 0 ? d->t_img : p.hw_out;
+  p.M = p.batch * p.hw_out;
   p.N = d->n; p.K = d->k; p.Kp = d->kp;
   p.bias = (const half_t*)d->bias;
   p.rowvec = (const half_t*)d->rowvec;
@@ -927,6 +946,9 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   if (p.Kp % BK || p.Kp < p.K) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: Kp=%d must be K rounded up to 64", p.Kp);
   if (p.ksize != 1 && p.ksize != 3) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: ksize %d", p.ksize);
   if (p.ldo % 8 || (p.residual && p.ldr % 8)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: ld must be a multiple of 8");
+  if (p.batch > 1 && p.chanstat_out) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: chanstat_out is per tensor, not per image (batch must be 1)");
+  if (p.out_t && p.batch > 1 && (p.t_img < p.hw_out || (int64_t)p.batch * p.t_img > p.ldt))
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: transposed output needs hw <= t_img and batch * t_img <= ldt");
   if (p.out2 && !p.add2) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: out2 without add2");
   if (p.rowstat_out && (p.N % 64 || p.out_t || (p.split_k > 1 && !d->counters)))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: rowstat_out needs N %% 64 == 0, no transposed output and the in-kernel split-K form");

@@ -27,8 +27,9 @@ struct GnParams {
   float* part;  // [nblk][groups][2]
   const float* chan0;  // pre-computed per-channel (sum, sumsq) of src0 / src1 (fused into the producer), or null
   const float* chan1;
-  int nblk;     // stats workgroups
+  int nblk;     // stats workgroups (per image)
   int rpp;      // rows per pass = blockDim / c8
+  int batch;    // images stacked along the rows (blockIdx.y): each normalised with its own statistics
 };
 
 __device__ __forceinline__ half8 gn_load(const GnParams& p, int row, int ch8) {
@@ -46,8 +47,9 @@ __global__ void gn_stats_kernel(const GnParams p) {
   const int ch8 = t % p.c8;
   const int rl = t / p.c8;
   const int rows_per_blk = (p.hw + p.nblk - 1) / p.nblk;
-  const int r0 = blockIdx.x * rows_per_blk;
-  const int r1 = min(p.hw, r0 + rows_per_blk);
+  const int img0 = blockIdx.y * p.hw;  // first row of this image
+  const int r0 = img0 + blockIdx.x * rows_per_blk;
+  const int r1 = min(img0 + p.hw, r0 + rows_per_blk);
   float s[8], q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
@@ -88,7 +90,7 @@ __global__ void gn_stats_kernel(const GnParams p) {
       const float* row = sm + ((size_t)rr * p.c + g * p.cpg) * 2 + which;
       for (int c = 0; c < p.cpg; ++c) acc += row[2 * c];
     }
-    p.part[(size_t)blockIdx.x * p.groups * 2 + i] = acc;
+    p.part[((size_t)blockIdx.y * p.nblk + blockIdx.x) * p.groups * 2 + i] = acc;
   }
 }
 
@@ -114,7 +116,7 @@ __global__ void gn_apply_kernel(const GnParams p) {
     float* fold = sm + npairs;
     for (int i = t; i < npairs * nch; i += blockDim.x) {
       const int pair = i % npairs, ch = i / npairs;
-      const float* src = p.part + pair;
+      const float* src = p.part + (size_t)blockIdx.y * p.nblk * npairs + pair;
       float v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -161,8 +163,9 @@ __global__ void gn_apply_kernel(const GnParams p) {
     }
   }
   const int rows_per_blk = (p.hw + gridDim.x - 1) / gridDim.x;
-  const int r0 = blockIdx.x * rows_per_blk;
-  const int r1 = min(p.hw, r0 + rows_per_blk);
+  const int img0 = blockIdx.y * p.hw;
+  const int r0 = img0 + blockIdx.x * rows_per_blk;
+  const int r1 = min(img0 + p.hw, r0 + rows_per_blk);
   auto norm_store = [&](int r, const half8& x) {
     half8 y;
 #pragma unroll
@@ -250,8 +253,16 @@ extern "C" int64_t vsd_groupnorm_workspace_bytes(int hw, int c, int groups) {
 extern "C" int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int groups,
                              float eps, const void* gamma, const void* beta, int silu, void* out, void* workspace,
                              void* stream) {
+  return vsd_groupnorm_batched(ctx, src0, src1, c0, c1, hw, 1, groups, eps, gamma, beta, silu, out, workspace, stream);
+}
+
+extern "C" int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int batch,
+                                     int groups, float eps, const void* gamma, const void* beta, int silu, void* out,
+                                     void* workspace, void* stream) {
   if (!ctx) return VSD_ERR_ARG;
+  if (batch < 1 || batch > 65535) return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm: batch=%d", batch);
   GnParams p;
+  p.batch = batch;
   p.src0 = (const half_t*)src0;
   p.src1 = (const half_t*)src1;
   p.c0 = c0;
@@ -279,7 +290,7 @@ extern "C" int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, i
   {
     const size_t smem_stats = (size_t)p.rpp * p.c * 2 * sizeof(float);
     LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk), dim3(threads), smem_stats, s, p);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, batch), dim3(threads), smem_stats, s, p);
     int rc = ls.finish();
     if (rc) return rc;
   }
@@ -287,7 +298,7 @@ extern "C" int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, i
     int ablk = cdiv(hw, 2 * p.rpp);
     if (ablk > 256) ablk = 256;
     LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk), dim3(threads), smem, s, p);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk, batch), dim3(threads), smem, s, p);
     return ls.finish();
   }
 }
@@ -309,7 +320,7 @@ extern "C" int vsd_groupnorm_prestat(vsd_ctx* ctx, const void* src0, const void*
   if (p.c8 > 1024) return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm_prestat: C=%d too large", p.c);
   p.hw = hw; p.groups = groups; p.cpg = p.c / groups; p.eps = eps;
   p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.silu = silu;
-  p.out = (half_t*)out; p.part = nullptr; p.nblk = 0;
+  p.out = (half_t*)out; p.part = nullptr; p.nblk = 0; p.batch = 1;
   p.chan0 = (const float*)chan0; p.chan1 = (const float*)chan1;
   p.rpp = p.c8 >= 512 ? 1 : 512 / p.c8;
   if (p.rpp > hw) p.rpp = hw;

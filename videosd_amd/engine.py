@@ -309,6 +309,7 @@ class Engine:
         self.graph = None
         self.use_graph = True
         self.is_slot = False
+        self.batch = 1
         # GroupNorm statistics can be produced by the convs' epilogues (chanstat_out); measured on MI355X this costs
         # the short-lived conv workgroups more (LDS fold + arrival ticket at their tail) than the separate, overlappable
         # statistics kernels it removes, so it is off by default.
@@ -392,22 +393,23 @@ class Engine:
 
     # ---------------------------------------------------------------- network builders (record ops)
     def _resnet(self, r, rw: ResnetW, net, step, x, x2, c0, c1, hw, geom, out=None, out2=None, add2=None, residual2=None):
-        """x (and optional concat partner x2) -> ResnetBlock2D output [hw][cout]."""
+        """x (and optional concat partner x2) -> ResnetBlock2D output [batch*hw][cout]  (hw = pixels per image)."""
         a, cfg = self.arena, net.cfg
         cin = c0 + c1
-        t1 = a.alloc(hw, cin)
+        rows = self.batch * hw
+        t1 = a.alloc(rows, cin)
         self._gn(r, x, x2, c0, c1, hw, cfg.groups, 1e-5, rw.n1[0], rw.n1[1], True, t1)
-        h = a.alloc(hw, rw.cout)
+        h = a.alloc(rows, rw.cout)
         tv = net.temb_all[step, rw.temb_off:rw.temb_off + rw.cout]
         r.conv(t1, None, geom, rw.conv1, h, rowvec=tv, chanstat_out=self._stat_buf(h, rw.cout))
-        t2 = a.alloc(hw, rw.cout)
+        t2 = a.alloc(rows, rw.cout)
         self._gn(r, h, None, rw.cout, 0, hw, cfg.groups, 1e-5, rw.n2[0], rw.n2[1], True, t2)
         if rw.shortcut is not None:
-            sc = a.alloc(hw, rw.cout)
-            r.conv(x, x2, Geom.linear(hw), rw.shortcut, sc, c0=c0, c1=c1)
+            sc = a.alloc(rows, rw.cout)
+            r.conv(x, x2, Geom.linear(rows), rw.shortcut, sc, c0=c0, c1=c1)
         else:
             sc = x
-        out = out if out is not None else a.alloc(hw, rw.cout)
+        out = out if out is not None else a.alloc(rows, rw.cout)
         r.conv(t2, None, geom, rw.conv2, out, residual=sc, residual2=residual2, out2=out2, add2=add2,
                chanstat_out=self._stat_buf(out, rw.cout))
         return out
@@ -417,51 +419,56 @@ class Engine:
         c = tw.c
         heads = cfg.heads_for(c)
         d = c // heads
-        lin = Geom.linear(hw)
-        t = a.alloc(hw, c)
+        B = self.batch
+        rows = B * hw                      # the token matrix of all images in flight: [B*hw][C]
+        lin = Geom.linear(rows)
+        t = a.alloc(rows, c)
         self._gn(r, x, None, c, 0, hw, cfg.groups, 1e-6, tw.norm[0], tw.norm[1], False, t)
         # The three LayerNorms are never materialised: every producer of the token stream leaves per-row
         # (sum, sumsq) partials (rowstat_out) and the consuming GEMM applies the norm in its epilogue (ln_part).
         ng = c // 64
-        stat = lambda: a.alloc(hw, ng * 2, dtype=torch.float32).view(hw, ng, 2)  # noqa: E731
-        h = a.alloc(hw, c)
+        stat = lambda: a.alloc(rows, ng * 2, dtype=torch.float32).view(rows, ng, 2)  # noqa: E731
+        h = a.alloc(rows, c)
         rs = stat()
         r.conv(t, None, lin, tw.proj_in, h, rowstat_out=rs)
-        ldvt = _ru(hw, 64)
+        t_img = _ru(hw, 64)                # V^T columns per image (key padding stays zero)
+        ldvt = B * t_img
         for bi, bw in enumerate(tw.blocks):
-            # self-attention
-            qk = a.alloc(hw, 2 * c)
+            # self-attention (per image: keys never cross an image boundary)
+            qk = a.alloc(rows, 2 * c)
             vt = self._vt_buffer(c, ldvt)
-            r.conv(h, None, lin, bw.qkv, qk, ldo=2 * c, out_t=vt, ldt=ldvt, t_col0=2 * c, ln_part=rs)
-            att = a.alloc(hw, c)
-            r.attention(qk, 2 * c, qk[:, c:], 2 * c, vt, ldvt, att, c, hw, hw, heads, d, d ** -0.5)
-            h1 = a.alloc(hw, c)
+            r.conv(h, None, Geom.linear(hw, batch=B), bw.qkv, qk, ldo=2 * c, out_t=vt, ldt=ldvt, t_col0=2 * c, ln_part=rs,
+                   t_img=t_img)
+            att = a.alloc(rows, c)
+            r.attention(qk, 2 * c, qk[:, c:], 2 * c, vt, ldvt, att, c, hw, hw, heads, d, d ** -0.5, batch=B, k_brows=hw,
+                        vt_bcols=t_img)
+            h1 = a.alloc(rows, c)
             rs1 = stat()
             r.conv(att, None, lin, bw.out1, h1, residual=h, rowstat_out=rs1)
-            # cross-attention over the cached text K / V^T
-            q = a.alloc(hw, c)
+            # cross-attention over the cached text K / V^T (shared by all images)
+            q = a.alloc(rows, c)
             r.conv(h1, None, lin, bw.q2, q, ln_part=rs1)
             kt, vtt = net.kv_cache[bw.kv_index]
-            r.attention(q, c, kt, c, vtt, vtt.shape[1], att, c, hw, kt.shape[0], heads, d, d ** -0.5)
-            h2 = a.alloc(hw, c)
+            r.attention(q, c, kt, c, vtt, vtt.shape[1], att, c, rows, kt.shape[0], heads, d, d ** -0.5)
+            h2 = a.alloc(rows, c)
             rs2 = stat()
             r.conv(att, None, lin, bw.out2, h2, residual=h1, rowstat_out=rs2)
             # GEGLU feed-forward
-            f = a.alloc(hw, 4 * c)
+            f = a.alloc(rows, 4 * c)
             r.conv(h2, None, lin, bw.ff1, f, ln_part=rs2)
-            h3 = a.alloc(hw, c)
+            h3 = a.alloc(rows, c)
             last = bi == len(tw.blocks) - 1
             rs = None if last else stat()  # the next block's norm1 statistics
             r.conv(f, None, lin, bw.ff2, h3, residual=h2, rowstat_out=rs)
             h = h3
-        out = a.alloc(hw, c)
+        out = a.alloc(rows, c)
         r.conv(h, None, lin, tw.proj_out, out, residual=x, out2=out2, add2=add2, chanstat_out=self._stat_buf(out, c))
         return out
 
     # ---- fused GroupNorm statistics: a conv that writes a tensor a GroupNorm will read also leaves the tensor's
     #      per-channel (sum, sumsq); the GroupNorm then needs no statistics pass of its own
     def _stat_buf(self, tensor, c):
-        if not self.fuse_gn_stats:
+        if not self.fuse_gn_stats or self.batch > 1:  # producer-side statistics are per tensor, not per image
             return None
         sb = self.arena.alloc(c, 2, dtype=torch.float32)
         self._stats[tensor.data_ptr()] = sb
@@ -474,7 +481,10 @@ class Engine:
             s1 = self._stats.get(x2.data_ptr()) if x2 is not None else None
             if s0 is not None and (x2 is None or s1 is not None):
                 cs = (s0, s1)
-        r.groupnorm(x, x2, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=cs)
+        if self.batch > 1:
+            r.groupnorm(x, x2, c0, c1, hw, groups, eps, gamma, beta, silu, out, batch=self.batch)
+        else:
+            r.groupnorm(x, x2, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=cs)
 
     def _vt_buffer(self, c, ldvt):
         # V^T buffers live outside the rewound arena: their key-padding columns must stay zero forever
@@ -494,7 +504,7 @@ class Engine:
         for i, c in enumerate(ch):
             hh, ww = sizes[i]
             hw = hh * ww
-            g3 = Geom.conv(hh, ww)
+            g3 = Geom.conv(hh, ww, batch=self.batch)
             for j, (rw, tw) in enumerate(net.down[i]):
                 h = self._resnet(r, rw, net, step, h, None, rw.cin, 0, hw, g3)
                 if tw is not None:
@@ -503,13 +513,13 @@ class Engine:
             ds = net.downsamplers[i]
             if ds is not None:
                 h2, w2 = sizes[i + 1]
-                o = a.alloc(h2 * w2, c)
-                r.conv(h, None, Geom.conv(hh, ww, stride=2), ds, o, chanstat_out=self._stat_buf(o, c))
+                o = a.alloc(self.batch * h2 * w2, c)
+                r.conv(h, None, Geom.conv(hh, ww, stride=2, batch=self.batch), ds, o, chanstat_out=self._stat_buf(o, c))
                 h = o
                 skips.append((o, c, i + 1))
         hh, ww = sizes[-1]
         hw = hh * ww
-        g3 = Geom.conv(hh, ww)
+        g3 = Geom.conv(hh, ww, batch=self.batch)
         c = ch[-1]
         h = self._resnet(r, net.mid[0], net, step, h, None, c, 0, hw, g3)
         h = self._transformer(r, net.mid[1], net, h, hw)
@@ -520,8 +530,8 @@ class Engine:
         a, net = self.arena, self.unet
         ch = net.cfg.block_out_channels
         h0, w0 = sizes[0]
-        x = a.alloc(h0 * w0, ch[0])
-        r.conv(lat, None, Geom.conv(h0, w0), net.conv_in, x, chanstat_out=self._stat_buf(x, ch[0]))
+        x = a.alloc(self.batch * h0 * w0, ch[0])
+        r.conv(lat, None, Geom.conv(h0, w0, batch=self.batch), net.conv_in, x, chanstat_out=self._stat_buf(x, ch[0]))
         h, skips = self._down_mid(r, net, step, x, sizes)
         return h, [(x, ch[0], 0)] + skips
 
@@ -537,7 +547,7 @@ class Engine:
             lvl = nlev - 1 - i
             hh, ww = sizes[lvl]
             hw = hh * ww
-            g3 = Geom.conv(hh, ww)
+            g3 = Geom.conv(hh, ww, batch=self.batch)
             for j, (rw, tw) in enumerate(net.up[i]):
                 s, sc, slvl = skips.pop()
                 assert slvl == lvl and rw.cin == cprev + sc, (slvl, lvl, rw.cin, cprev, sc)
@@ -548,20 +558,22 @@ class Engine:
             up = net.upsamplers[i]
             if up is not None:
                 h2, w2 = sizes[lvl - 1]
-                o = a.alloc(h2 * w2, cprev)
+                o = a.alloc(self.batch * h2 * w2, cprev)
                 # nearest resize to the next skip's size folded into the conv's gather (Upsample2D)
-                r.conv(h, None, Geom.conv(hh, ww, up_to=(h2, w2)), up, o, chanstat_out=self._stat_buf(o, cprev))
+                r.conv(h, None, Geom.conv(hh, ww, up_to=(h2, w2), batch=self.batch), up, o,
+                       chanstat_out=self._stat_buf(o, cprev))
                 h = o
-        t = a.alloc(hw0, ch[0])
+        t = a.alloc(self.batch * hw0, ch[0])
         self._gn(r, h, None, ch[0], 0, hw0, net.cfg.groups, 1e-5, net.norm_out[0], net.norm_out[1], True, t)
-        r.conv(t, None, Geom.conv(h0, w0), net.conv_out, eps_out, ldo=8)
+        r.conv(t, None, Geom.conv(h0, w0, batch=self.batch), net.conv_out, eps_out, ldo=8)
 
     def _controlnet_encoder(self, r, step, lat, sizes, cond_emb):
         a, net = self.arena, self.cn
         ch = net.cfg.block_out_channels
         h0, w0 = sizes[0]
-        x = a.alloc(h0 * w0, ch[0])
-        r.conv(lat, None, Geom.conv(h0, w0), net.conv_in, x, residual=cond_emb, chanstat_out=self._stat_buf(x, ch[0]))
+        x = a.alloc(self.batch * h0 * w0, ch[0])
+        r.conv(lat, None, Geom.conv(h0, w0, batch=self.batch), net.conv_in, x, residual=cond_emb,
+               chanstat_out=self._stat_buf(x, ch[0]))
         h, skips = self._down_mid(r, net, step, x, sizes)
         return h, [(x, ch[0], 0)] + skips
 
@@ -576,14 +588,16 @@ class Engine:
         for i, ((s, c, lvl), (us, uc, ulvl)) in enumerate(zip(cn_skips, u_skips)):
             assert (c, lvl) == (uc, ulvl)
             hh, ww = sizes[lvl]
-            o = a.alloc(hh * ww, c)
-            r.conv(s, None, Geom.linear(hh * ww), net.zero_convs[i], o, out_scale=float(scales[i]), residual=us,
+            rows = self.batch * hh * ww
+            o = a.alloc(rows, c)
+            r.conv(s, None, Geom.linear(rows), net.zero_convs[i], o, out_scale=float(scales[i]), residual=us,
                    chanstat_out=self._stat_buf(o, c))
             merged.append((o, c, lvl))
         hh, ww = sizes[-1]
+        rows = self.batch * hh * ww
         c = net.cfg.block_out_channels[-1]
-        mid = a.alloc(hh * ww, c)
-        r.conv(cn_mid, None, Geom.linear(hh * ww), net.zero_mid, mid, out_scale=float(scales[-1]), residual=u_mid,
+        mid = a.alloc(rows, c)
+        r.conv(cn_mid, None, Geom.linear(rows), net.zero_mid, mid, out_scale=float(scales[-1]), residual=u_mid,
                chanstat_out=self._stat_buf(mid, c))
         return mid, merged
 
@@ -591,17 +605,18 @@ class Engine:
         a, net = self.arena, self.cn
         h, hh, ww = ctrl, H, W
         for pw, stride in net.cond_convs:
-            g = Geom.conv(hh, ww, stride=stride)
+            g = Geom.conv(hh, ww, stride=stride, batch=self.batch)
             o = a.alloc(g.m, pw.n)
             r.conv(h, None, g, pw, o, act=L.ACT_SILU)
             h, hh, ww = o, g.ho, g.wo
-        o = a.alloc(hh * ww, net.cond_out.n)
-        r.conv(h, None, Geom.conv(hh, ww), net.cond_out, o)
+        g = Geom.conv(hh, ww, batch=self.batch)
+        o = a.alloc(g.m, net.cond_out.n)
+        r.conv(h, None, g, net.cond_out, o)
         return o
 
     def _taesd_block(self, r, blk, x, hh, ww):
         a = self.arena
-        g = Geom.conv(hh, ww)
+        g = Geom.conv(hh, ww, batch=self.batch)
         c = blk[0].n
         t1 = a.alloc(g.m, c)
         r.conv(x, None, g, blk[0], t1, act=L.ACT_RELU)
@@ -614,34 +629,36 @@ class Engine:
     def _encode(self, r, img8, H, W, out):
         a, v = self.arena, self.vae
         c = v.enc_in.n
-        h = a.alloc(H * W, c)
-        r.conv(img8, None, Geom.conv(H, W), v.enc_in, h)
+        B = self.batch
+        h = a.alloc(B * H * W, c)
+        r.conv(img8, None, Geom.conv(H, W, batch=B), v.enc_in, h)
         for b in v.enc_blocks0:
             h = self._taesd_block(r, b, h, H, W)
         hh, ww = H, W
         for down, bs in v.enc_stages:
-            g = Geom.conv(hh, ww, stride=2)
+            g = Geom.conv(hh, ww, stride=2, batch=B)
             o = a.alloc(g.m, c)
             r.conv(h, None, g, down, o)
             h, hh, ww = o, g.ho, g.wo
             for b in bs:
                 h = self._taesd_block(r, b, h, hh, ww)
-        r.conv(h, None, Geom.conv(hh, ww), v.enc_out, out, ldo=8)
+        r.conv(h, None, Geom.conv(hh, ww, batch=B), v.enc_out, out, ldo=8)
 
     def _decode(self, r, z8, hh, ww, out):
         a, v = self.arena, self.vae
         c = v.dec_in.n
-        h = a.alloc(hh * ww, c)
-        r.conv(z8, None, Geom.conv(hh, ww), v.dec_in, h, act=L.ACT_RELU)
+        B = self.batch
+        h = a.alloc(B * hh * ww, c)
+        r.conv(z8, None, Geom.conv(hh, ww, batch=B), v.dec_in, h, act=L.ACT_RELU)
         for bs, up in v.dec_stages:
             for b in bs:
                 h = self._taesd_block(r, b, h, hh, ww)
-            g = Geom.conv(hh, ww, up_to=(2 * hh, 2 * ww))  # nn.Upsample(scale_factor=2) folded into the conv
+            g = Geom.conv(hh, ww, up_to=(2 * hh, 2 * ww), batch=B)  # nn.Upsample(scale_factor=2) folded into the conv
             o = a.alloc(g.m, c)
             r.conv(h, None, g, up, o)
             h, hh, ww = o, g.ho, g.wo
         h = self._taesd_block(r, v.dec_last_block, h, hh, ww)
-        r.conv(h, None, Geom.conv(hh, ww), v.dec_out, out, ldo=8)
+        r.conv(h, None, Geom.conv(hh, ww, batch=B), v.dec_out, out, ldo=8)
 
     # ---------------------------------------------------------------- prepare: build + capture
     def autotune(self, verbose: bool = False):
@@ -664,9 +681,17 @@ class Engine:
         return seen
 
     def prepare(self, H: int, W: int, steps: int, strength: float, controlnet_scale: float = 1.0,
-                use_controlnet: bool = True, use_graph: Optional[bool] = None, autotune: bool = True):
+                use_controlnet: bool = True, use_graph: Optional[bool] = None, autotune: bool = True, batch: int = 1):
         """Fix the frame geometry and schedule; build the static program and capture it into a hipGraph
-        (the reference's intent at videopipeline.py:35-47, `compile_model`)."""
+        (the reference's intent at videopipeline.py:35-47, `compile_model`).
+
+        batch > 1: that many frames (of independent streams / sessions, or consecutive frames of one stream) go
+        through every kernel together, stacked along the GEMM M dimension: one pass over the 2.45 GB of weights and
+        one launch per layer serve all of them.  Each frame is still denoised independently (own GroupNorm statistics,
+        own attention, same noise draws as a lone frame: the reference resets its RNG per frame)."""
+        if batch < 1:
+            raise ValueError("batch must be >= 1")
+        self.batch = batch
         if H % 8 or W % 8:
             raise ValueError("height and width must be multiples of 8 (TAESD / latent stride)")
         if self.text is None:
@@ -687,13 +712,14 @@ class Engine:
         if self.graph is not None:
             ops.graph_destroy(self.graph)
             self.graph = None
-        self.arena = Arena(ops)
+        self.arena = Arena(ops, chunk_bytes=max(256 << 20, _ru(batch * H * W * 64 * 2, 1 << 20)))  # >= one TAESD tensor
         self._stats = {}
         self._vt_pool, self._vt_count = getattr(self, "_vt_pool", {}), 0
         # persistent per-frame I/O and constants
-        self.frame_u8 = ops.zeros(H, W, 3, dtype=torch.uint8)
-        self.out_u8 = ops.zeros(H, W, 3, dtype=torch.uint8)
-        self.edge_u8 = ops.zeros(H * W, dtype=torch.uint8)
+        B = batch
+        self.frame_u8 = ops.zeros(B, H, W, 3, dtype=torch.uint8)
+        self.out_u8 = ops.zeros(B, H, W, 3, dtype=torch.uint8)
+        self.edge_u8 = ops.zeros(B * H * W, dtype=torch.uint8)
         for net in [self.unet] + ([self.cn] if use_controlnet else []):
             if self.is_slot:  # schedule constants were computed by the parent engine's prepare
                 assert net.temb_all.shape[0] == n, "prepare the parent engine with the same schedule first"
@@ -704,26 +730,29 @@ class Engine:
         # frame (videopipeline.py:126), so for a fixed shape the draws are the same every frame.
         self.noise = ops.to_device(self.host_noise(n, h0, w0))
         a = self.arena
-        enc_in = a.alloc(H * W, 8)
-        x0 = a.alloc(hw0, 8)
-        lat = [a.alloc(hw0, 8), a.alloc(hw0, 8)]
-        eps = a.alloc(hw0, 8)
-        den = a.alloc(hw0, 8)
-        dec_in = a.alloc(hw0, 8)
-        dec_out = a.alloc(H * W, 8)
+        enc_in = a.alloc(B * H * W, 8)
+        x0 = a.alloc(B * hw0, 8)
+        lat = [a.alloc(B * hw0, 8), a.alloc(B * hw0, 8)]
+        eps = a.alloc(B * hw0, 8)
+        den = a.alloc(B * hw0, 8)
+        dec_in = a.alloc(B * hw0, 8)
+        dec_out = a.alloc(B * H * W, 8)
         for t in (x0, lat[0], lat[1], eps, den, dec_in):
             ops.zero_(t)
         self.buffers = {"x0": x0, "lat": lat, "eps": eps, "denoised": den, "dec_in": dec_in, "dec_out": dec_out}
         r = Recorder(ops)
-        r.preprocess_rgb(self.frame_u8, H, W, enc_in)
+        img = lambda t, b, n: t[b * n:(b + 1) * n]  # noqa: E731  rows of image b
+        r.preprocess_rgb(self.frame_u8, B * H, W, enc_in)
         cond_emb = None
         if use_controlnet:
-            ctrl = a.alloc(H * W, 8)
-            r.sobel_control(self.frame_u8, H, W, 0.11, 0.8, self.edge_u8, ctrl)  # videopipeline.py:109
+            ctrl = a.alloc(B * H * W, 8)
+            for b in range(B):  # the edge map is normalised by ITS frame's maximum (canny_gpu.py:39)
+                r.sobel_control(self.frame_u8[b], H, W, 0.11, 0.8, img(self.edge_u8, b, H * W), img(ctrl, b, H * W))  # videopipeline.py:109
             cond_emb = self._cond_embedding(r, ctrl, H, W)
         self._encode(r, enc_in, H, W, x0)
         sa, sb = sched.add_noise_coef()
-        r.add_noise(x0, self.noise[0], sa, sb, hw0, lat[0])
+        for b in range(B):  # every frame gets the same draws: the reference resets its RNG per frame
+            r.add_noise(img(x0, b, hw0), self.noise[0], sa, sb, hw0, img(lat[0], b, hw0))
         mark = a.mark()
         for i in range(n):
             a.rewind(mark)
@@ -747,11 +776,13 @@ class Engine:
             self._unet_decoder(r, i, u_mid, u_skips, sizes, eps)
             nz = self.noise[i + 1] if sched.multistep else None
             last = i == n - 1
-            r.lcm_step(eps, cur, nz, sched.step_coef(i), hw0, nxt, den, dec_in if last else None)
+            for b in range(B):
+                r.lcm_step(img(eps, b, hw0), img(cur, b, hw0), nz, sched.step_coef(i), hw0, img(nxt, b, hw0), img(den, b, hw0),
+                           img(dec_in, b, hw0) if last else None)
         self._decode(r, dec_in, h0, w0, dec_out)
-        r.postprocess_rgb(dec_out, 8, H * W, self.out_u8)
+        r.postprocess_rgb(dec_out, 8, B * H * W, self.out_u8)
         self.program = r
-        self.plan = dict(H=H, W=W, steps=steps, strength=strength, cn_scale=controlnet_scale, cn=use_controlnet, n=n,
+        self.plan = dict(H=H, W=W, steps=steps, strength=strength, cn_scale=controlnet_scale, cn=use_controlnet, n=n, batch=B,
                          sizes=sizes, timesteps=sched.timesteps, n_ops=len(r.calls), arena_bytes=a.peak)
         # per-shape kernel configuration (timed once per shape, cached in ops.tile_override), warm-up, capture
         torch.cuda.synchronize() if torch.cuda.is_available() else None  # allocation fills vs. kernel streams
@@ -793,10 +824,12 @@ class Engine:
             self.program.run()
 
     def infer_u8(self, frame: np.ndarray) -> np.ndarray:
-        """frame: uint8 [H][W][3] already cropped/resized by the caller -> uint8 [H][W][3]."""
+        """frame: uint8 [H][W][3] already cropped/resized by the caller -> uint8 [H][W][3]
+        (prepared with batch B > 1: uint8 [B][H][W][3] -> [B][H][W][3])."""
         p = self.plan
-        if frame.shape != (p["H"], p["W"], 3) or frame.dtype != np.uint8:
-            raise ValueError(f"frame must be uint8 {(p['H'], p['W'], 3)}, got {frame.dtype} {frame.shape}")
+        want = (p["H"], p["W"], 3) if p["batch"] == 1 else (p["batch"], p["H"], p["W"], 3)
+        if frame.shape != want or frame.dtype != np.uint8:
+            raise ValueError(f"frame must be uint8 {want}, got {frame.dtype} {frame.shape}")
         self.ops.upload(self.frame_u8, torch.from_numpy(np.ascontiguousarray(frame)))
         self.launch()
-        return self.ops.download(self.out_u8).numpy()
+        return self.ops.download(self.out_u8).numpy().reshape(want)

@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("chan_counters", C.c_void_p), ("ln_part", C.c_void_p), ("ln_groups", C.c_int32), ("ln_eps", C.c_float),
         ("ln_s", C.c_void_p), ("ln_t", C.c_void_p),
         ("counters", C.c_void_p),
+        ("batch", C.c_int32), ("t_img", C.c_int32),
     ]
 
 
@@ -57,6 +58,11 @@ SIGNATURES = {
                                 C.c_void_p, C.c_void_p]),
     "vsd_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "vsd_attention_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p]),
+    "vsd_groupnorm_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsd_preprocess_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vsd_sobel_control": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -26,22 +26,25 @@ class Geom:
     ksize: int = 1
     stride: int = 1
     pad: int = 0
+    batch: int = 1  # images stacked along M (frames of independent streams sharing one launch)
 
     @staticmethod
-    def linear(rows: int) -> "Geom":
-        return Geom(1, rows, 1, rows, 1, rows, 1, 1, 0)
+    def linear(rows: int, batch: int = 1) -> "Geom":
+        """`rows` per image; a plain GEMM does not care where one image ends (batch only matters to a transposed
+        output, which keeps each image in its own column slab)."""
+        return Geom(1, rows, 1, rows, 1, rows, 1, 1, 0, batch)
 
     @staticmethod
-    def conv(h: int, w: int, ksize=3, stride=1, up_to=None) -> "Geom":
+    def conv(h: int, w: int, ksize=3, stride=1, up_to=None, batch=1) -> "Geom":
         hi, wi = (h, w) if up_to is None else up_to
         pad = ksize // 2
         ho = (hi + 2 * pad - ksize) // stride + 1
         wo = (wi + 2 * pad - ksize) // stride + 1
-        return Geom(h, w, hi, wi, ho, wo, ksize, stride, pad)
+        return Geom(h, w, hi, wi, ho, wo, ksize, stride, pad, batch)
 
     @property
     def m(self) -> int:
-        return self.ho * self.wo
+        return self.batch * self.ho * self.wo
 
 
 def choose_tile(m: int, n: int, kp: int, geglu: bool = False, t_col0: int = 0):
@@ -179,7 +182,8 @@ class HipOps:
     def conv(self, src0, src1, g: Geom, w: PackedConv, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None,
              residual2=None, ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0,
              t_col0=0, tile=None, split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None,
-             ln_eps=1e-5, chanstat_out=None):
+             ln_eps=1e-5, chanstat_out=None, t_img=0):
+        """t_img: with g.batch > 1, columns of out_t per image (image b's pixels start at column b * t_img)."""
         m = g.m
         c0 = c0 if c0 is not None else (w.cin - c1)
         if w.geglu:
@@ -220,6 +224,7 @@ class HipOps:
         d.ldo = ldo if ldo is not None else w.n_out
         d.out2, d.add2 = self._p(out2), self._p(add2)
         d.out_t, d.ldt, d.t_col0 = self._p(out_t), ldt, t_col0
+        d.batch, d.t_img = g.batch, t_img
         d.tile, d.split_k = tile, split_k
         d.pipeline = self.default_pipeline if pipeline is None else pipeline
         if split_k > 1:
@@ -308,7 +313,14 @@ class HipOps:
                 n += 1
         return n
 
-    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=None):
+    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=None, batch=1):
+        if batch > 1:
+            if chan_stats is not None:
+                raise RuntimeError("groupnorm: producer-side statistics are per tensor (batch must be 1)")
+            ws = self.workspace("gn", batch * int(self.ctx.lib.vsd_groupnorm_workspace_bytes(hw, c0 + c1, groups)))
+            self.ctx.call("vsd_groupnorm_batched", self._p(src0), self._p(src1), c0, c1, hw, batch, groups, eps,
+                          self._p(gamma), self._p(beta), int(silu), self._p(out), self._p(ws), self.s)
+            return
         if chan_stats is not None:  # statistics were produced by the convs that wrote src0 / src1: one kernel
             self.ctx.call("vsd_groupnorm_prestat", self._p(src0), self._p(src1), c0, c1, hw, groups, eps, self._p(gamma),
                           self._p(beta), int(silu), self._p(out), self._p(chan_stats[0]), self._p(chan_stats[1]), self.s)
@@ -320,7 +332,13 @@ class HipOps:
     def layernorm(self, x, rows, c, gamma, beta, eps, out):
         self.ctx.call("vsd_layernorm", self._p(x), rows, c, self._p(gamma), self._p(beta), eps, self._p(out), self.s)
 
-    def attention(self, q, ldq, k, ldk, vt, ldvt, out, ldo, sq, sk, heads, d, scale, causal=False):
+    def attention(self, q, ldq, k, ldk, vt, ldvt, out, ldo, sq, sk, heads, d, scale, causal=False, batch=1, k_brows=0,
+                  vt_bcols=0):
+        """batch > 1: image b uses q/out rows [b*sq, (b+1)*sq), K rows from b*k_brows, V^T columns from b*vt_bcols."""
+        if batch > 1:
+            self.ctx.call("vsd_attention_batched", self._p(q), ldq, self._p(k), ldk, self._p(vt), ldvt, self._p(out), ldo,
+                          sq, sk, heads, d, scale, int(causal), batch, k_brows, vt_bcols, self.s)
+            return
         self.ctx.call("vsd_attention", self._p(q), ldq, self._p(k), ldk, self._p(vt), ldvt, self._p(out), ldo, sq, sk,
                       heads, d, scale, int(causal), self.s)
 
