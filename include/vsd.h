@@ -37,7 +37,8 @@ enum vsd_act { VSD_ACT_NONE = 0, VSD_ACT_RELU = 1, VSD_ACT_SILU = 2, VSD_ACT_GEG
                VSD_ACT_POST = 256 /* flag: apply the activation AFTER the residual adds (TAESD block) */ };
 
 /* tile shapes of the implicit-GEMM kernel (BM x BN output tile per 256-thread workgroup) */
-enum vsd_tile { VSD_TILE_128x128 = 0, VSD_TILE_128x64 = 1, VSD_TILE_64x64 = 2, VSD_TILE_64x128 = 3 };
+enum vsd_tile { VSD_TILE_128x128 = 0, VSD_TILE_128x64 = 1, VSD_TILE_64x64 = 2, VSD_TILE_64x128 = 3,
+                VSD_TILE_256x128 = 4 /* Cin % 64 == 0, no resize, pipeline 3 or 5 only */ };
 
 /* kernel families for vsd_stage_times */
 enum vsd_family {

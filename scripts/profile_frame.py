@@ -10,8 +10,10 @@ from videosd_amd.ops import HipOps, choose_tile
 
 cn = "--no-cn" not in sys.argv
 size = 512
+batch = 1
 for a in sys.argv[1:]:
     if a.startswith("--size="): size = int(a.split("=")[1])
+    if a.startswith("--batch="): batch = int(a.split("=")[1])
 tag = sys.argv[-1] if not sys.argv[-1].startswith("--") and len(sys.argv) > 1 else "r1"
 ops = HipOps(0)
 wu = W.synthesize(W.unet_spec(C.SD15_UNET), "unet.", device="cuda")
@@ -21,7 +23,7 @@ eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
 eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half())
 ops.load_tuning(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tuning_mi355x.json"))
 eng.overlap_controlnet = False
-eng.prepare(size, size, 4, 0.6, use_controlnet=cn, use_graph=False)
+eng.prepare(size, size, 4, 0.6, use_controlnet=cn, use_graph=False, batch=batch)
 meta = []
 for fn, a, k in eng.program.calls:
     name = fn.__name__
@@ -48,11 +50,11 @@ for fn, a, k in eng.program.calls:
     elif name == "layernorm":
         m.update(rows=a[1], C=a[2])
     elif name == "attention":
-        m.update(sq=a[8], sk=a[9], heads=a[10], d=a[11], flops=4.0 * a[8] * a[9] * a[10] * a[11])
+        m.update(sq=a[8], sk=a[9], heads=a[10], d=a[11], flops=4.0 * a[8] * a[9] * a[10] * a[11] * k.get("batch", 1))
     meta.append(m)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(meta, open(f"gpurun_out/ops_{tag}.json", "w"))
-f = np.random.default_rng(0).integers(0, 256, (size, size, 3), dtype=np.uint8)
+f = np.random.default_rng(0).integers(0, 256, (size, size, 3) if batch == 1 else (batch, size, size, 3), dtype=np.uint8)
 for _ in range(4):
     eng.infer_u8(f)
 ops.synchronize()

@@ -616,3 +616,19 @@ def test_attention_batched_self(ops, sq, heads, d):
     sp = lambda t: t.float().reshape(B, sq, heads, d).transpose(1, 2)  # noqa: E731
     ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B * sq, c)
     check(out, ref, f"batched attention sq={sq} d={d}", rel=3e-3)
+
+
+@pytest.mark.parametrize("pipeline,split_k", [(3, 1), (5, 1), (3, 3), (5, 2)])
+def test_conv_256x128_tile(ops, pipeline, split_k):
+    """VSD_TILE_256x128 (buffer-load path): ragged M and N, concat sources, fused epilogue, split-K."""
+    h, w, c0, c1, cout = 30, 22, 128, 64, 200  # M = 660 (2.6 tiles), N = 200 (1.6 tiles)
+    a, b = rnd(1, c0, h, w, seed=1), rnd(1, c1, h, w, seed=2)
+    wt = rnd(cout, c0 + c1, 3, 3, seed=3, scale=((c0 + c1) * 9) ** -0.5)
+    res = rnd(h * w, cout, seed=5)
+    got, ref = run_conv(ops, [a, b], h, w, wt, rnd(cout, seed=4, scale=0.1), ksize=3, tile=4, split_k=split_k, pipeline=pipeline,
+                        residual=res, act=2)
+    check(got, ref, f"256x128 tile pipeline={pipeline} split={split_k}")
+    x = rnd(1, 320, 1, 700, seed=7)
+    wl = rnd(384, 320, 1, 1, seed=8, scale=320 ** -0.5)
+    got, ref = run_conv(ops, [x], 1, 700, wl, None, ksize=1, tile=4, split_k=1, pipeline=pipeline)
+    check(got, ref, "256x128 tile linear")

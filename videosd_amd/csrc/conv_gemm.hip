@@ -13,6 +13,9 @@
 //
 // Algorithmic work per launch: 2*M*N*K FLOP, fp16 bytes: N*Kp (weights) + M*Cin (input) + M*N (output).
 #include <stdarg.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -30,6 +33,7 @@ struct ConvParams {
   unsigned rmul_y, rmul_x;  // resize: ceil(hs * 2^22 / hi), source row = (iy * rmul_y) >> 22; else 1 and shift 0
   int rshift;
   int generic;  // cin % 64 != 0: per-chunk tap computation
+  int fast;     // buffer-load address path usable: !generic, no resize, every operand < 2 GB
   const half_t* w;
   int M, N, K, Kp;
   const half_t* bias;
@@ -59,16 +63,42 @@ struct ConvParams {
   const half_t* zeros;  // >= 16 zero bytes: source of out-of-bounds chunks for the direct-to-LDS loader
   int* counters;  // per-tile arrival tickets for the in-kernel split-K reduction (all zero between launches)
   int tiles_m, tiles_n;
+#ifdef VSD_CONV_PROBE
+  long long* probe;  // scripts/conv_probe.cpp: per-section shader-clock totals of wave 0 of workgroup 0
+#endif
   int batch;    // images stacked along M: M = batch * ho * wo, image b's source pixels start at b * hs * ws
   int hw_out;   // ho * wo
   int img_in;   // hs * ws
   int t_img;    // transposed output: columns per image (image b's rows m land at b * t_img + (m - b * hw_out))
 };
 
+#ifdef VSD_CONV_PROBE
+long long* g_conv_probe = nullptr;
+#define CPROBE(I_)                                         \
+  {                                                        \
+    long long t_ = __builtin_readcyclecounter();           \
+    pacc[I_] += t_ - plast;                                \
+    plast = t_;                                            \
+  }
+#define CPROBE_OUT()                                                                       \
+  if (p.probe && blockIdx.x == 0 && threadIdx.x == 0)                                      \
+    for (int i_ = 0; i_ < 8; ++i_) p.probe[i_] = pacc[i_];
+#else
+#define CPROBE(I_)
+#define CPROBE_OUT()
+#endif
+
 // ---------------------------------------------------------------- epilogue (shared with the reducer)
-__device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int n, float (&v)[8], float& rsum, float& rsq) {
+__device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int n, float (&v)[8], float& rsum, float& rsq,
+                                                const half8* res_pre = nullptr, const float* brv_pre = nullptr) {
   // n is a multiple of 8; handles n + 8 > N by scalar fallback
+  // res_pre / brv_pre: the residual chunk / bias + rowvec of these 8 columns, loaded by the caller BEFORE its first
+  // store (vmcnt counts stores too: a load issued after a store is only waited for once that store has retired)
   const bool full = (n + 8 <= p.N);
+  if (brv_pre) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += brv_pre[i];
+  } else {
   if (p.bias) {
     if (full) {
       half8 b = *reinterpret_cast<const half8*>(p.bias + n);
@@ -90,6 +120,7 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
       for (int i = 0; i < 8; ++i)
         if (n + i < p.N) v[i] += (float)p.rowvec[n + i];
     }
+  }
   }
   const int act = p.act & 0xff;
   const bool post = (p.act & VSD_ACT_POST) != 0;
@@ -120,7 +151,7 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
   }
   if (full) {
     if (p.residual) {
-      half8 r = *reinterpret_cast<const half8*>(p.residual + (size_t)m * p.ldr + n);
+      half8 r = res_pre ? *res_pre : *reinterpret_cast<const half8*>(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += (float)r[i];
     }
@@ -245,7 +276,15 @@ __device__ __forceinline__ void load_chunk8(const ConvParams& p, const float* Cs
 // STAGES >= 3: direct-to-LDS ring (global_load_lds, 16 B per lane) with STAGES-1 tiles in flight behind counted
 //              vmcnt waits and raw barriers; the XOR swizzle is applied on the per-lane SOURCE address because a
 //              wave's LDS-DMA destination is lane-linear; out-of-bounds chunks read a zero page.
-template <int BM, int BN, bool GENERIC, int STAGES, bool ILV>
+// FAST (direct-to-LDS ring, cin % 64 == 0, no resize): the per-tile operand addresses come almost for free.  The
+//   generic issue path recomputes tap / channel / bounds / 64-bit addresses for every 16-byte chunk of every K tile
+//   (~160 instructions, a dozen quarter-rate integer multiplies and a scalar division per tile -- 3x the issue time
+//   of the 16 MFMAs they feed).  Here every chunk is a raw BUFFER load to LDS: the per-row byte offset of the tile
+//   row's CENTRE pixel and a 9-bit "which taps are inside the image" mask are computed once; per K tile the tap /
+//   channel displacement is ONE scalar (the instruction's soffset, kept by an incremental scalar cursor instead of a
+//   division), an out-of-image tap turns the lane's offset into an out-of-range one (the buffer unit then writes
+//   zeros into LDS: the conv's zero padding), and the weight rows need no vector instruction at all.
+template <int BM, int BN, bool GENERIC, int STAGES, bool ILV, bool FAST>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   constexpr int WM = 2, WN = 2;             // 2x2 waves
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
@@ -375,6 +414,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }                                                                                               \
   }
 
+#ifdef VSD_CONV_PROBE
+  long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long plast = __builtin_readcyclecounter();
+#endif
   f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -437,6 +480,81 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     const int nt = kt_end - kt_begin;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    // ---- FAST path state (see the kernel's header comment)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // scalar: the DMA's LDS base goes to M0 without a v_readfirstlane
+    [[maybe_unused]] int apix[AR];          // centre pixel (oy*stride, ox*stride) of the row, in pixels from the tensor start
+    [[maybe_unused]] unsigned tapmask[AR];  // bit (ky*ksize + kx): that tap of this row lies inside the image
+    [[maybe_unused]] int bvoff[BR];         // weight row byte offset (+ this lane's chunk), or out of range
+    [[maybe_unused]] int cur_c = 0, cur_tap = 0, cur_ky = 0, cur_kx = 0, cur_kt = kt_begin;  // scalar cursor: next tile to fetch
+    // the A descriptors start (pad*ws + pad) pixels BEFORE the tensor: soffset = (ky*ws + kx)*cs*2 + c*2 is then
+    // never negative; a lane only ever adds it to a centre pixel whose tap is inside the image.  (Descriptors are
+    // rebuilt from these scalars per tile: a handful of SALU moves.)
+    const int neg_pix = p.pad * p.ws + p.pad;
+    [[maybe_unused]] const half_t* abase0 = p.src0 - (size_t)neg_pix * p.c0;
+    [[maybe_unused]] const half_t* abase1 = (p.src1 ? p.src1 : p.src0) - (size_t)neg_pix * p.c1;
+    [[maybe_unused]] const int anr0 = (int)(((size_t)p.batch * p.img_in + neg_pix) * p.c0 * 2);
+    [[maybe_unused]] const int anr1 = (int)(((size_t)p.batch * p.img_in + neg_pix) * p.c1 * 2);
+    [[maybe_unused]] const int bnr = (int)((size_t)p.N * p.Kp * 2);
+    constexpr int OOB = (int)0x80000000;
+    if constexpr (FAST) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        apix[i] = ib[i] + (iy0[i] + p.pad) * p.ws + (ix0[i] + p.pad);
+        unsigned mk = 0;
+        for (int ky = 0; ky < p.ksize; ++ky)
+          for (int kx = 0; kx < p.ksize; ++kx) {
+            const bool in = mvalid[i] && (unsigned)(iy0[i] + ky) < (unsigned)p.hi && (unsigned)(ix0[i] + kx) < (unsigned)p.wi;
+            mk |= (in ? 1u : 0u) << (ky * p.ksize + kx);
+          }
+        tapmask[i] = mk;
+      }
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const int n = n0 + lr + 32 * i;
+        bvoff[i] = n < p.N ? n * p.Kp * 2 + lc * 16 : OOB;
+      }
+      const int k0 = kt_begin * BK;
+      cur_tap = k0 / p.cin;
+      cur_c = k0 - cur_tap * p.cin;
+      cur_ky = cur_tap / p.ksize;
+      cur_kx = cur_tap - cur_ky * p.ksize;
+    }
+// fetch the cursor's tile into ring slot SLOT_, then (ADV_) move the cursor one K tile on
+#define VSD_ISSUE_FAST(SLOT_, ADV_)                                                                    \
+  {                                                                                                    \
+    half_t* a_ = reinterpret_cast<half_t*>(smem) + (SLOT_) * STAGE_HALFS;                              \
+    half_t* b_ = a_ + BM * BK;                                                                         \
+    const int soff_b_ = cur_kt * (BK * 2);                                                             \
+    /* (descriptors are made next to their use: hipcc drops the host stub of a kernel that reads one declared in an \
+       outer scope) */                                                                                 \
+    const __amdgpu_buffer_rsrc_t rsb_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, bnr, 0x00020000); \
+    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                   \
+      const int bv_ = bvoff[i] + 0;                                                                    \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb_, (lds_ptr_t)(b_ + (8 * wave_s + 32 * i) * BK), 16, bv_, soff_b_, 0, 0); \
+    }                                                                                                  \
+    const bool second_ = cur_c >= p.c0;                                                                \
+    const int cs2_ = (second_ ? p.c1 : p.c0) * 2;                                                      \
+    const int soff_a_ = (cur_ky * p.ws + cur_kx) * cs2_ + (second_ ? cur_c - p.c0 : cur_c) * 2;        \
+    const __amdgpu_buffer_rsrc_t rs_ =                                                                 \
+        __builtin_amdgcn_make_buffer_rsrc((void*)(second_ ? abase1 : abase0), 0, second_ ? anr1 : anr0, 0x00020000); \
+    const unsigned bit_ = 1u << cur_tap;                                                               \
+    _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                   \
+      const int vo_ = (tapmask[i] & bit_) ? __mul24(apix[i], cs2_) + lc * 16 : OOB; /* < 2^24 pixels: host check */                            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)(a_ + (8 * wave_s + 32 * i) * BK), 16, vo_, soff_a_, 0, 0); \
+    }                                                                                                  \
+    if (ADV_) {                                                                                        \
+      ++cur_kt;                                                                                        \
+      cur_c += BK;                                                                                     \
+      if (cur_c >= p.cin) {                                                                            \
+        cur_c = 0;                                                                                     \
+        ++cur_tap;                                                                                     \
+        if (++cur_kx == p.ksize) {                                                                     \
+          cur_kx = 0;                                                                                  \
+          ++cur_ky;                                                                                    \
+        }                                                                                              \
+      }                                                                                                \
+    }                                                                                                  \
+  }
 #define VSD_ISSUE_TILE(KT_, SLOT_)                                                                    \
   {                                                                                                   \
     const int kt_ = (KT_);                                                                            \
@@ -475,8 +593,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     if constexpr (!ILV) {
   #pragma unroll
       for (int st = 0; st < STAGES - 1; ++st)
-        if (st < nt) VSD_ISSUE_TILE(kt_begin + st, st)
+        if (st < nt) {
+          if constexpr (FAST) VSD_ISSUE_FAST(st, true)
+          else VSD_ISSUE_TILE(kt_begin + st, st)
+        }
       VSD_LN_ROWSTATS()
+      CPROBE(0)
       int slot = 0;
       for (int t = 0; t < nt; ++t) {
         // tile t has landed once all but the younger tiles' loads are done; then everyone's has (barrier)
@@ -484,12 +606,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CPROBE(1)
         __builtin_amdgcn_s_barrier();
+        CPROBE(2)
         if (t + STAGES - 1 < nt) {
           int ns = slot + STAGES - 1;
           if (ns >= STAGES) ns -= STAGES;
-          VSD_ISSUE_TILE(kt_begin + t + STAGES - 1, ns)
+          if constexpr (FAST) VSD_ISSUE_FAST(ns, true)
+          else VSD_ISSUE_TILE(kt_begin + t + STAGES - 1, ns)
         }
+        CPROBE(3)
         const half_t* a = reinterpret_cast<const half_t*>(smem) + slot * STAGE_HALFS;
         const half_t* b = a + BM * BK;
   #pragma unroll
@@ -511,6 +637,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             for (int j = 0; j < FN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        CPROBE(4)
         if (++slot == STAGES) slot = 0;
       }
 
@@ -521,7 +648,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       // (sched_group_barrier), instead of running "all loads, then all reads, then all MFMAs" back to back.
       const int kt_last = kt_end - 1;
 #pragma unroll
-      for (int st = 0; st < STAGES - 1; ++st) VSD_ISSUE_TILE(min(kt_begin + st, kt_last), st)
+      for (int st = 0; st < STAGES - 1; ++st) {
+        if constexpr (FAST) VSD_ISSUE_FAST(st, cur_kt < kt_last)
+        else VSD_ISSUE_TILE(min(kt_begin + st, kt_last), st)
+      }
       VSD_LN_ROWSTATS()
       int slot = 0;
       constexpr int NM = FM * FN * 2;       // MFMAs per tile per wave
@@ -530,28 +660,42 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         __builtin_amdgcn_s_barrier();
         int ns = slot + STAGES - 1;
         if (ns >= STAGES) ns -= STAGES;
-        // ---- per-tile scalars of the tile to fetch (same arithmetic as VSD_ISSUE_TILE)
-        const int ktn = min(kt_begin + t + STAGES - 1, kt_last);
+        // ---- per-tile scalars of the tile to fetch (same arithmetic as VSD_ISSUE_TILE / VSD_ISSUE_FAST)
         half_t* na = reinterpret_cast<half_t*>(smem) + ns * STAGE_HALFS;
         half_t* nb = na + BM * BK;
-        int k_, cs_;
-        const half_t* src_;
-        bool kok_ = true;
-        if (!GENERIC) {
-          k_ = ktn * BK;
+        [[maybe_unused]] int ktn = 0, k_ = 0, cs_ = 0, c_ = 0, ky_ = 0, kx_ = 0;
+        [[maybe_unused]] const half_t* src_ = nullptr;
+        [[maybe_unused]] bool kok_ = true;
+        [[maybe_unused]] int f_soff_b = 0, f_soff_a = 0, f_cs2 = 0;
+        [[maybe_unused]] unsigned f_bit = 0;
+        const bool f_second = FAST && cur_c >= p.c0;
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t f_rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(f_second ? abase1 : abase0), 0, f_second ? anr1 : anr0, 0x00020000);
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t f_rsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, bnr, 0x00020000);
+        if constexpr (FAST) {
+          f_soff_b = cur_kt * (BK * 2);
+          f_cs2 = (f_second ? p.c1 : p.c0) * 2;
+          f_soff_a = (cur_ky * p.ws + cur_kx) * f_cs2 + (f_second ? cur_c - p.c0 : cur_c) * 2;
+          f_bit = 1u << cur_tap;
         } else {
-          k_ = ktn * BK + lc * 8;
-          kok_ = k_ < p.K;
+          ktn = min(kt_begin + t + STAGES - 1, kt_last);
+          if (!GENERIC) {
+            k_ = ktn * BK;
+          } else {
+            k_ = ktn * BK + lc * 8;
+            kok_ = k_ < p.K;
+          }
+          const int tap_ = k_ / p.cin;
+          c_ = k_ - tap_ * p.cin;
+          ky_ = tap_ / p.ksize;
+          kx_ = tap_ - ky_ * p.ksize;
+          if (!GENERIC && c_ >= p.c0) {
+            src_ = p.src1; cs_ = p.c1; c_ -= p.c0;
+          } else {
+            src_ = p.src0; cs_ = p.c0;
+          }
+          if (!GENERIC) c_ += lc * 8;
         }
-        const int tap_ = k_ / p.cin;
-        int c_ = k_ - tap_ * p.cin;
-        const int ky_ = tap_ / p.ksize, kx_ = tap_ - ky_ * p.ksize;
-        if (!GENERIC && c_ >= p.c0) {
-          src_ = p.src1; cs_ = p.c1; c_ -= p.c0;
-        } else {
-          src_ = p.src0; cs_ = p.c0;
-        }
-        if (!GENERIC) c_ += lc * 8;
         const half_t* a = reinterpret_cast<const half_t*>(smem) + slot * STAGE_HALFS;
         const half_t* b = a + BM * BK;
         half8 af[2][FM], bf[2][FN];
@@ -568,7 +712,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         // ---- LPT pieces: one LDS-DMA issue, then MPP MFMAs; the k-step-1 fragments are read half way
 #pragma unroll
         for (int pc = 0; pc < LPT; ++pc) {
-          if (pc < BR) {
+          if constexpr (FAST) {
+            if (pc < BR) {
+              const int bv_ = bvoff[pc < BR ? pc : 0] + 0;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rsb, (lds_ptr_t)(nb + (8 * wave_s + 32 * pc) * BK), 16, bv_, f_soff_b, 0, 0);
+            } else {
+              const int i = pc - BR;
+              const int vo_ = (tapmask[i] & f_bit) ? __mul24(apix[i], f_cs2) + lc * 16 : OOB;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rs, (lds_ptr_t)(na + (8 * wave_s + 32 * i) * BK), 16, vo_, f_soff_a, 0, 0);
+            }
+          } else if (pc < BR) {
             const int i = pc;
             const half_t* g_ = nvalid[i] ? (wrow[i] - cc * 8 + lc * 8 + (size_t)ktn * BK) : p.zeros;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(nb + (8 * wave + 32 * i) * BK), 16, 0, 0);
@@ -600,12 +753,65 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
           }
           __builtin_amdgcn_sched_barrier(0);  // keep the DMA / MFMA alternation as written
         }
+        if constexpr (FAST) {
+          if (cur_kt < kt_last) {  // clamped like ktn: past the end the last tile is fetched again into a slot nobody reads
+            ++cur_kt;
+            cur_c += BK;
+            if (cur_c >= p.cin) {
+              cur_c = 0;
+              ++cur_tap;
+              if (++cur_kx == p.ksize) {
+                cur_kx = 0;
+                ++cur_ky;
+              }
+            }
+          }
+        }
         if (++slot == STAGES) slot = 0;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail fetches must land before the LDS is reused
     }
     __syncthreads();  // every wave is done reading the ring before the epilogue reuses the LDS
 #undef VSD_ISSUE_TILE
+#undef VSD_ISSUE_FAST
+  }
+
+  // ---- residual prefetch.  The epilogue below walks this thread's 8-wide output chunks one after the other; loading
+  // each chunk's residual inside that walk exposes one full memory round trip PER CHUNK (measured: 7.4k of the 17k
+  // cycles a 128x64 workgroup of a K=320 layer lives).  The addresses do not depend on the GEMM, so the loads are
+  // issued here, before the accumulator transpose, and land while it and its barrier run.
+  constexpr int CHP = BN / 8;
+  constexpr int NITP = BM * CHP / 256;
+  constexpr int NPRE = NITP <= 8 ? NITP : 8;
+  half8 rpre[NPRE];
+  const bool use_pre = p.residual != nullptr && p.split_k == 1 && (p.act & 0xff) != VSD_ACT_GEGLU && !(p.out_t && n0 >= p.t_col0);
+  // bias + rowvec of this thread's 8 columns (the same columns in every chunk it handles: 256 % CHP == 0)
+  float brv[8];
+  const int pre_n = n0 + (tid % CHP) * 8;
+  const bool use_brv = pre_n + 8 <= p.N && (p.act & 0xff) != VSD_ACT_GEGLU && !(p.out_t && n0 >= p.t_col0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) brv[i] = 0.f;
+  if (use_brv) {
+    if (p.bias) {
+      half8 b = *reinterpret_cast<const half8*>(p.bias + pre_n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) brv[i] += (float)b[i];
+    }
+    if (p.rowvec) {
+      half8 b = *reinterpret_cast<const half8*>(p.rowvec + pre_n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) brv[i] += (float)b[i];
+    }
+  }
+  if (use_pre) {
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int q = tid + j * 256;
+      const int r = q / CHP, c8 = (q - r * CHP) * 8;
+      const int m = m0 + r, n = n0 + c8;
+      const bool ok = m < p.M && n + 8 <= p.N;  // (otherwise an in-range dummy address; the value is not used)
+      rpre[j] = *reinterpret_cast<const half8*>(p.residual + (ok ? (size_t)m * p.ldr + n : 0));
+    }
   }
 
   // ---- epilogue: accumulators -> LDS (fp32) -> row-contiguous 8-wide chunks
@@ -622,6 +828,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }
   __syncthreads();
 
+  CPROBE(5)
   bool from_slabs = false;
   if (p.split_k > 1) {
     constexpr int CH = BN / 8;
@@ -736,12 +943,66 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       float rs = 0.f, rq = 0.f;
       epilogue_store8(p, m, n, v, rs, rq);
     }
+  } else if (!p.ln_part && !p.rowstat_out && !p.chanstat_out && !p.out2 && !p.residual2 && !from_slabs &&
+             p.out_scale == 1.0f && (p.N & 7) == 0 && NITP <= NPRE && (!p.residual || use_pre)) {
+    // ---- the common epilogue (bias / time vector, one activation, one residual), specialised per activation: the
+    // general loop below tests ~25 uniform flags per 8-wide chunk and inlines every activation twice (15k instructions
+    // per kernel); for the short-K layers that walk was 40 % of the workgroup's life
+    constexpr int CH = BN / 8;
+    auto simple = [&](auto act_tag) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(act_tag)::value;  // 0 none, 1 relu, 2 silu, 3 relu AFTER the residual, 4 quick-gelu
+#pragma unroll
+      for (int j = 0; j < NITP; ++j) {
+        const int q = tid + j * 256;
+        const int r = q / CH, c8 = (q - r * CH) * 8;
+        const int m = m0 + r, n = n0 + c8;
+        if (m < p.M && n < p.N) {
+          f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8);
+          f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8 + 4);
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          half8 o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float x = v[i] + brv[i];
+            if (ACT == 1) x = fmaxf(x, 0.f);
+            if (ACT == 2) x = silu_f(x);
+            if (ACT == 4) x = quick_gelu_f(x);
+            if (p.residual) x += (float)rpre[j < NPRE ? j : 0][i];
+            if (ACT == 3) x = fmaxf(x, 0.f);
+            o[i] = (half_t)x;
+          }
+          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
+        }
+      }
+    };
+    const int act = p.act & 0xff;
+    const bool post = (p.act & VSD_ACT_POST) != 0;
+    if (act == VSD_ACT_NONE) simple(std::integral_constant<int, 0>{});
+    else if (act == VSD_ACT_RELU && !post) simple(std::integral_constant<int, 1>{});
+    else if (act == VSD_ACT_SILU && !post) simple(std::integral_constant<int, 2>{});
+    else if (act == VSD_ACT_RELU && post) simple(std::integral_constant<int, 3>{});
+    else if (act == VSD_ACT_QUICKGELU && !post) simple(std::integral_constant<int, 4>{});
+    else {  // (activation after the residual other than ReLU: not used by the networks; keep it correct)
+#pragma unroll
+      for (int j = 0; j < NITP; ++j) {
+        const int q = tid + j * 256;
+        const int r = q / CH, c8 = (q - r * CH) * 8;
+        const int m = m0 + r, n = n0 + c8;
+        if (m < p.M && n < p.N) {
+          float v[8], rs = 0.f, rq = 0.f;
+          load_chunk8(p, Cs, BNP, false, r, c8, m, n, v);
+          epilogue_store8(p, m, n, v, rs, rq);
+        }
+      }
+    }
   } else {
     constexpr int CH = BN / 8;
     float cs[8], cq[8];  // this thread's 8 columns (fixed: c8 = (tid % CH) * 8), summed over its rows
 #pragma unroll
     for (int i = 0; i < 8; ++i) cs[i] = cq[i] = 0.f;
-    for (int q = tid; q < BM * CH; q += 256) {  // BM*CH is a multiple of 256: every lane runs every iteration
+#pragma unroll
+    for (int j = 0; j < NITP; ++j) {  // BM*CH is a multiple of 256: every lane runs every iteration
+      const int q = tid + j * 256;
       int r = q / CH, c8 = (q - r * CH) * 8;
       int m = m0 + r, n = n0 + c8;
       const bool valid = m < p.M && n < p.N;
@@ -750,7 +1011,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         float v[8];
         load_chunk8(p, Cs, BNP, from_slabs, r, c8, m, n, v);
         if (p.ln_part) ln_transform8(p, n, rowms[2 * r], rowms[2 * r + 1], v);
-        epilogue_store8(p, m, n, v, rs, rq);
+        epilogue_store8(p, m, n, v, rs, rq, (use_pre && j < NPRE) ? &rpre[j < NPRE ? j : 0] : nullptr, use_brv ? brv : nullptr);
         if (p.chanstat_out) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -827,6 +1088,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       }
     }
   }
+  CPROBE(6)
+  CPROBE_OUT()
 }
 
 // ---------------------------------------------------------------- split-K reducer
@@ -866,10 +1129,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
   }
 }
 
+// the FAST form exists for the direct-to-LDS rings only (STAGES >= 3)
+template <int BM, int BN, int STAGES, bool ILV>
+struct FastLaunch {
+  static void go(const ConvParams& p, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, STAGES, ILV, true>), dim3(grid), dim3(256), 0, s, p);
+  }
+};
+template <int BM, int BN, bool ILV>
+struct FastLaunch<BM, BN, 0, ILV> {
+  static void go(const ConvParams& p, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, 0, ILV, false>), dim3(grid), dim3(256), 0, s, p);
+  }
+};
+
 template <int BM, int BN, int STAGES, bool ILV>
 void launch2(const ConvParams& p, int grid, hipStream_t s) {
-  if (p.generic) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, STAGES, ILV>), dim3(grid), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, STAGES, ILV>), dim3(grid), dim3(256), 0, s, p);
+  if (p.generic) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, STAGES, ILV, false>), dim3(grid), dim3(256), 0, s, p);
+  else if (STAGES >= 3 && p.fast) FastLaunch<BM, BN, STAGES, ILV>::go(p, grid, s);
+  else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, STAGES, ILV, false>), dim3(grid), dim3(256), 0, s, p);
 }
 template <int BM, int BN>
 void launch(const ConvParams& p, int grid, int stages, hipStream_t s) {
@@ -881,6 +1159,10 @@ void launch(const ConvParams& p, int grid, int stages, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef VSD_CONV_PROBE
+extern "C" void vsd_conv_set_probe(void* buf) { g_conv_probe = (long long*)buf; }
+#endif
 
 extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream) {
   if (!ctx || !d) return VSD_ERR_ARG;
@@ -905,6 +1187,12 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     p.rmul_y = p.rmul_x = 1;
   }
   p.generic = (p.cin % 64) != 0;
+  {
+    const size_t a_pix = (size_t)(d->batch < 1 ? 1 : d->batch) * d->hs * d->ws + (size_t)d->pad * d->ws + d->pad;
+    const size_t cmax = (size_t)(d->c0 > d->c1 ? d->c0 : d->c1);
+    p.fast = !p.generic && !p.resize && a_pix < (1u << 24) && a_pix * cmax * 2 < 0x7fffffffull && (size_t)d->n * d->kp * 2 < 0x7fffffffull &&
+             d->ksize * d->ksize <= 32 && !getenv("VSD_CONV_NO_FAST");
+  }
   p.w = (const half_t*)d->weight;
   p.batch = d->batch < 1 ? 1 : d->batch;
   p.hw_out = d->ho * d->wo;
@@ -926,6 +1214,9 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.ws_partial = (float*)d->workspace;
   p.counters = (int*)d->counters;
   p.zeros = (const half_t*)ctx->zero_page;
+#ifdef VSD_CONV_PROBE
+  p.probe = g_conv_probe;
+#endif
   p.rowstat_out = (float*)d->rowstat_out;
   p.chanstat_part = (float*)d->chanstat_part;
   p.chanstat_out = (float*)d->chanstat_out;
@@ -965,8 +1256,12 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     case VSD_TILE_128x64: BM = 128; BN = 64; break;
     case VSD_TILE_64x64: BM = 64; BN = 64; break;
     case VSD_TILE_64x128: BM = 64; BN = 128; break;
+    case VSD_TILE_256x128: BM = 256; BN = 128; break;
     default: return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: tile %d", d->tile);
   }
+  if (BM == 256 && (!p.fast || (stages != 3 && stages != 5)))
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 256x128 tile exists for the buffer-load path (Cin %% 64 == 0, no resize) "
+                    "with the 3-stage ring (pipeline 3 or 5) only");
   if ((p.act & 0xff) == VSD_ACT_GEGLU) {
     if (BN != 128 || p.N % 128 || p.split_k != 1 || (!p.bias && !p.ln_part) || p.out_t)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: GEGLU needs BN=128, N %% 128 == 0, bias, no split-K");
@@ -984,7 +1279,10 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   const int grid = p.tiles_m * p.tiles_n * p.split_k;
   {
     LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
-    if (BM == 128 && BN == 128) launch<128, 128>(p, grid, stages, s);
+    if (BM == 256) {  // 2x2 waves of 128x64: 85 FLOP per byte staged through LDS (128x128: 64, 64x64: 32)
+      if (stages == 3) FastLaunch<256, 128, 3, false>::go(p, grid, s);
+      else FastLaunch<256, 128, 3, true>::go(p, grid, s);
+    } else if (BM == 128 && BN == 128) launch<128, 128>(p, grid, stages, s);
     else if (BM == 128 && BN == 64) launch<128, 64>(p, grid, stages, s);
     else if (BM == 64 && BN == 64) launch<64, 64>(p, grid, stages, s);
     else launch<64, 128>(p, grid, stages, s);

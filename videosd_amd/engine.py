@@ -717,8 +717,11 @@ class Engine:
         self._vt_pool, self._vt_count = getattr(self, "_vt_pool", {}), 0
         # persistent per-frame I/O and constants
         B = batch
-        self.frame_u8 = ops.zeros(B, H, W, 3, dtype=torch.uint8)
-        self.out_u8 = ops.zeros(B, H, W, 3, dtype=torch.uint8)
+        frame_b = ops.zeros(B, H, W, 3, dtype=torch.uint8)
+        out_b = ops.zeros(B, H, W, 3, dtype=torch.uint8)
+        # public I/O buffers: [H][W][3] for a single frame (as before), [B][H][W][3] for a batch
+        self.frame_u8 = frame_b[0] if B == 1 else frame_b
+        self.out_u8 = out_b[0] if B == 1 else out_b
         self.edge_u8 = ops.zeros(B * H * W, dtype=torch.uint8)
         for net in [self.unet] + ([self.cn] if use_controlnet else []):
             if self.is_slot:  # schedule constants were computed by the parent engine's prepare
@@ -742,12 +745,12 @@ class Engine:
         self.buffers = {"x0": x0, "lat": lat, "eps": eps, "denoised": den, "dec_in": dec_in, "dec_out": dec_out}
         r = Recorder(ops)
         img = lambda t, b, n: t[b * n:(b + 1) * n]  # noqa: E731  rows of image b
-        r.preprocess_rgb(self.frame_u8, B * H, W, enc_in)
+        r.preprocess_rgb(frame_b, B * H, W, enc_in)
         cond_emb = None
         if use_controlnet:
             ctrl = a.alloc(B * H * W, 8)
             for b in range(B):  # the edge map is normalised by ITS frame's maximum (canny_gpu.py:39)
-                r.sobel_control(self.frame_u8[b], H, W, 0.11, 0.8, img(self.edge_u8, b, H * W), img(ctrl, b, H * W))  # videopipeline.py:109
+                r.sobel_control(frame_b[b], H, W, 0.11, 0.8, img(self.edge_u8, b, H * W), img(ctrl, b, H * W))  # videopipeline.py:109
             cond_emb = self._cond_embedding(r, ctrl, H, W)
         self._encode(r, enc_in, H, W, x0)
         sa, sb = sched.add_noise_coef()
@@ -780,7 +783,7 @@ class Engine:
                 r.lcm_step(img(eps, b, hw0), img(cur, b, hw0), nz, sched.step_coef(i), hw0, img(nxt, b, hw0), img(den, b, hw0),
                            img(dec_in, b, hw0) if last else None)
         self._decode(r, dec_in, h0, w0, dec_out)
-        r.postprocess_rgb(dec_out, 8, B * H * W, self.out_u8)
+        r.postprocess_rgb(dec_out, 8, B * H * W, out_b)
         self.program = r
         self.plan = dict(H=H, W=W, steps=steps, strength=strength, cn_scale=controlnet_scale, cn=use_controlnet, n=n, batch=B,
                          sizes=sizes, timesteps=sched.timesteps, n_ops=len(r.calls), arena_bytes=a.peak)

@@ -247,20 +247,24 @@ class HipOps:
         key = self.conv_key(g, w, t_col0, kwargs.get("rowstat_out") is not None or kwargs.get("chanstat_out") is not None)
         kt = w.kp // 64
         tiles = [L.TILE_128x128, L.TILE_64x128] if w.geglu else [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64]
+        # the 256x128 tile (buffer-load path only: Cin % 64 == 0, no resize) pays when M is large (batched frames, TAESD)
+        big_ok = w.cin % 64 == 0 and (g.hi, g.wi) == (g.hs, g.ws) and g.m >= 1024
+        if big_ok:
+            tiles = tiles + [L.TILE_256x128]
         cands = []
         for t in tiles:
             bm, bn = L.TILE_DIMS[t]
             if kwargs.get("out_t") is not None and t_col0 % bn:
                 continue
             blocks = -(-g.m // bm) * -(-w.n // bn)
-            for pl in (0, 3, 4, 5, 6):
+            for pl in ((3, 5) if t == L.TILE_256x128 else (0, 3, 4, 5, 6)):
                 cands.append((t, 1, False, pl))
             if w.geglu or blocks >= 384:
                 continue
             for sp in (2, 3, 4, 6, 8, 12, 16, 24):
                 if sp > kt // 2 or blocks * sp > 1536:
                     break
-                for pl in (0, 3, 5):
+                for pl in ((3, 5) if t == L.TILE_256x128 else (0, 3, 5)):
                     if kwargs.get("rowstat_out") is None and kwargs.get("chanstat_out") is None:
                         cands.append((t, sp, False, pl))
                     cands.append((t, sp, True, pl))
