@@ -24,6 +24,19 @@ class FakePipeline:
         a[0, 0, 0] = self.device  # tag the worker that produced the frame
         return Image.fromarray(a.astype(np.uint8), "RGB")
 
+    def infer_batch(self, imgs, **opts):
+        """One 'launch' for all frames: one delay, every frame tagged with the size of the batch it rode in."""
+        if opts.get("strength", 0.4) < 0:
+            raise ValueError("negative strength")
+        time.sleep(self.delay)
+        outs = []
+        for img in imgs:
+            a = 255 - np.asarray(img.convert("RGB").resize((opts.get("width", 640), opts.get("height", 360))))
+            a[0, 0, 0] = self.device
+            a[0, 0, 1] = len(imgs)
+            outs.append(Image.fromarray(a.astype(np.uint8), "RGB"))
+        return outs
+
     def compile_model(self):
         return Image.new("RGB", (8, 8))
 

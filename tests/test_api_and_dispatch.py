@@ -151,6 +151,62 @@ def test_dispatcher_round_robin_in_order_release_and_drop_if_busy():
             p.close()
 
 
+def test_worker_coalesces_queued_frames_into_batched_launches():
+    """RemotePipeline(batch=3): frames that are already waiting behind the one being served ride in one `infer_batch`
+    launch (same options only); a lone frame is served at once; every caller still gets its own frame back."""
+    p = RemotePipeline(factory=FAKE, model="m", controlnet="c", device=1, delay=0.25, batch=3)
+    try:
+        async def go():
+            futs = [p.infer.remote(_img(10 * (k + 1)), height=12, width=16) for k in range(5)]
+            other = p.infer.remote(_img(90), height=12, width=16, strength=0.7)  # different options: its own launch
+            return [await f for f in futs], await other
+
+        outs, other = asyncio.run(go())
+        vals = [int(np.asarray(o)[1, 1, 0]) for o in outs]
+        assert vals == [245, 235, 225, 215, 205]  # everyone got their own frame
+        sizes = [int(np.asarray(o)[0, 0, 1]) for o in outs]
+        # frame 0 was taken alone or with whatever had already arrived; the rest were coalesced (never more than 3)
+        assert max(sizes) <= 3 and sum(1 for s_ in sizes if s_ > 1) >= 3, sizes
+        assert int(np.asarray(other)[1, 1, 0]) == 165 and int(np.asarray(other)[0, 0, 1]) in (0, 1)  # served on its own
+        # an error inside a batched launch reaches every caller of that launch
+        async def bad():
+            a = p.infer.remote(_img(1), strength=-1.0)
+            b = p.infer.remote(_img(2), strength=-1.0)
+            res = []
+            for f in (a, b):
+                try:
+                    await f
+                    res.append(None)
+                except RuntimeError as e:
+                    res.append(str(e))
+            return res
+
+        errs = asyncio.run(bad())
+        assert all(e and "negative strength" in e for e in errs), errs
+    finally:
+        p.close()
+
+
+def test_dispatcher_depth_keeps_several_frames_per_worker():
+    ps = [RemotePipeline(factory=FAKE, model="m", controlnet="c", device=i, delay=0.1, batch=2) for i in range(2)]
+    try:
+        async def go():
+            d = FrameDispatcher(ps, mode="in_order", depth=2)
+            t = [d.submit(_img(10 * (k + 1)), height=12, width=16) for k in range(5)]
+            assert t == [0, 1, 2, 3, None] and d.dropped == 1  # two frames per worker, the fifth finds worker 0 full
+            out = [await d.next_result() for _ in range(4)]
+            assert [o[0] for o in out] == [0, 1, 2, 3]
+            assert [int(np.asarray(o[1])[0, 0, 0]) for o in out] == [0, 1, 0, 1]  # frame k -> worker k mod 2
+            assert [int(np.asarray(o[1])[1, 1, 0]) for o in out] == [245, 235, 225, 215]
+            assert d.busy == [0, 0]
+            return True
+
+        assert asyncio.run(go())
+    finally:
+        for p in ps:
+            p.close()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

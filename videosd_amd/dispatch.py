@@ -56,22 +56,41 @@ def _resolve(path: str) -> Callable:
     return getattr(importlib.import_module(mod), name)
 
 
-def _worker_main(conn, factory: str, config: Dict[str, Any]):
+def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1):
+    """Serve calls one at a time, like a Ray actor.  With max_batch > 1, `infer` calls that are ALREADY queued behind
+    the one being taken (frames of other sessions, or of the same stream submitted ahead) and carry the same options
+    are coalesced into one `infer_batch` launch: no waiting for a batch to fill, so a lone frame is never delayed."""
     try:
         pipe = _resolve(factory)(**config)
         conn.send(("ready", None))
     except BaseException as e:  # construction errors travel to the parent (the reference re-raises KeyError)
         conn.send(("error", (type(e).__name__, str(e))))
         return
+    backlog = []
     while True:
-        msg = conn.recv()
+        msg = backlog.pop(0) if backlog else conn.recv()
         if msg is None:
             break
         rid, method, args, kwargs = msg
+        group = [(rid, args)]
+        if max_batch > 1 and method == "infer" and len(args) == 1 and hasattr(pipe, "infer_batch"):
+            while len(group) < max_batch and (backlog or conn.poll(0)):
+                nxt = backlog.pop(0) if backlog else conn.recv()
+                if nxt is not None and nxt[1] == "infer" and len(nxt[2]) == 1 and nxt[3] == kwargs:
+                    group.append((nxt[0], nxt[2]))
+                else:  # different options / another method / shutdown: serve it next, stop growing this batch
+                    backlog.insert(0, nxt)
+                    break
         try:
-            conn.send((rid, True, getattr(pipe, method)(*args, **kwargs)))
+            if len(group) > 1:
+                outs = pipe.infer_batch([a[0] for _, a in group], **kwargs)
+                for (r, _), o in zip(group, outs):
+                    conn.send((r, True, o))
+            else:
+                conn.send((rid, True, getattr(pipe, method)(*args, **kwargs)))
         except BaseException as e:
-            conn.send((rid, False, (type(e).__name__, str(e))))
+            for r, _ in group:
+                conn.send((r, False, (type(e).__name__, str(e))))
 
 
 class _RemoteMethod:
@@ -90,10 +109,12 @@ class RemotePipeline:
     """A VideoSDPipeline living in its own process (one per GPU), like the reference's Ray actor: calls are
     serialised per worker, inputs/outputs are pickled copies."""
 
-    def __init__(self, factory: str = "videosd_amd.pipeline:VideoSDPipeline", start_timeout: float = 600.0, **config):
+    def __init__(self, factory: str = "videosd_amd.pipeline:VideoSDPipeline", start_timeout: float = 600.0, batch: int = 1,
+                 **config):
+        """batch > 1: the worker coalesces up to `batch` queued `infer` calls with equal options into one launch."""
         ctx = mp.get_context("spawn")
         self._conn, child = ctx.Pipe()
-        self._proc = ctx.Process(target=_worker_main, args=(child, factory, config), daemon=True)
+        self._proc = ctx.Process(target=_worker_main, args=(child, factory, config, int(batch)), daemon=True)
         self._proc.start()
         child.close()
         if not self._conn.poll(start_timeout):
@@ -183,11 +204,14 @@ class FrameDispatcher:
     (the frame is dropped, as the reference does while every GPU is generating).  Results come out of
     `await next_result()`: in submission order ("in_order") or whichever finished last ("latest")."""
 
-    def __init__(self, pipelines: List[Any], mode: str = "in_order"):
+    def __init__(self, pipelines: List[Any], mode: str = "in_order", depth: int = 1):
+        """depth: frames one worker may hold at once (1 = the reference's `generating[gpu]` flag; set it to the
+        workers' `batch` x launches in flight so that queued frames can be coalesced)."""
         assert mode in ("in_order", "latest")
         self.pipelines, self.mode = pipelines, mode
         self.n = len(pipelines)
-        self.busy = [False] * self.n          # server.py:277 `generating`
+        self.depth = max(1, int(depth))
+        self.busy = [0] * self.n              # server.py:277 `generating`, as a count
         self.healthy = [True] * self.n
         self.seq = 0
         self.submitted = 0
@@ -203,11 +227,11 @@ class FrameDispatcher:
         self.seq += 1
         gpu = owner_of(k, self.n)
         if not self.healthy[gpu]:
-            gpu = next((g for g in range(self.n) if self.healthy[g] and not self.busy[g]), gpu)
-        if self.busy[gpu] or not self.healthy[gpu]:
+            gpu = next((g for g in range(self.n) if self.healthy[g] and self.busy[g] < self.depth), gpu)
+        if self.busy[gpu] >= self.depth or not self.healthy[gpu]:
             self.dropped += 1
             return None
-        self.busy[gpu] = True
+        self.busy[gpu] += 1
         ticket = self.submitted
         self.submitted += 1
         self._inflight.add(ticket)
@@ -223,7 +247,7 @@ class FrameDispatcher:
             self.healthy[gpu] = False
             self._done[ticket] = e
         finally:
-            self.busy[gpu] = False
+            self.busy[gpu] -= 1
             self._inflight.discard(ticket)
         self.avg_gen_time = 0.95 * self.avg_gen_time + 0.05 * (time.time() - t0)
         self._event.set()

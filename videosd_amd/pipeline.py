@@ -62,6 +62,8 @@ class VideoSDPipeline:
             raise
         self._prompt_key = None
         self._plan_key = None
+        self._engines = {}  # (plan_key, batch) -> prepared engine (the first one is self.model, the others are its slots)
+        self.max_plans = int(kwargs.get("max_plans", 4))
 
     # ------------------------------------------------------------------ model loading
     def load_model(self, model_name, controlnet_model="lllyasviel/control_v11p_sd15_canny"):
@@ -124,20 +126,48 @@ class VideoSDPipeline:
         """Same contract as videopipeline.py:75-128.  `guidance_scale`, `ref`, `style_fidelity` and
         `controlnet` are accepted and ignored exactly like the reference (ControlNet always runs; 7.5 is baked
         in); `seed` does not change the result because the reference resets the CPU generator state per frame."""
-        img = center_crop_resize(img, width, height)
+        return self.infer_batch([img], prompt=prompt, height=height, width=width, strength=strength, steps=steps,
+                                guidance_scale=guidance_scale, ref=ref, style_fidelity=style_fidelity,
+                                controlnet=controlnet, seed=seed, controlnet_scale=controlnet_scale)[0]
+
+    def infer_batch(self, imgs, prompt=["pixar, cg"], height=360, width=640, strength=0.4, steps=20, guidance_scale=7.5,
+                    ref=False, style_fidelity=0.0, controlnet=False, seed=42, controlnet_scale=1):
+        """Several frames (of different sessions, or consecutive frames of one stream) with the SAME options through
+        one batched launch: same result per frame as `infer` (frames are denoised independently), one pass over the
+        weights for all of them.  Extension of the reference surface; `RemotePipeline(batch=B)` coalesces queued
+        `infer` calls into this."""
+        imgs = [center_crop_resize(im, width, height) for im in imgs]
         pkey = prompt if isinstance(prompt, str) else tuple(prompt)
         if pkey != self._prompt_key:
             self.model.set_text_embeds(self.encode_prompt(prompt))
-            self._prompt_key = pkey
+            self._prompt_key = pkey  # (the cross-attention K / V^T caches are rewritten in place: captured graphs stay valid)
         use_cn = bool(controlnet) if self.honor_controlnet_flag else True
         plan_key = (height, width, int(steps), float(strength), float(controlnet_scale), use_cn)
-        if plan_key != self._plan_key:
-            self.model.prepare(height, width, int(steps), float(strength), controlnet_scale=float(controlnet_scale),
-                               use_controlnet=use_cn)
-            self._plan_key = plan_key
+        eng = self._engine_for(plan_key, len(imgs))
         np.random.seed(seed)  # kept for parity with videopipeline.py:112 (nothing downstream consumes it)
-        out = self.model.infer_u8(np.asarray(img.convert("RGB"), dtype=np.uint8))
-        return Image.fromarray(out, mode="RGB")
+        frames = np.stack([np.asarray(im.convert("RGB"), dtype=np.uint8) for im in imgs])
+        out = eng.infer_u8(frames[0] if len(imgs) == 1 else frames)
+        out = out[None] if len(imgs) == 1 else out
+        return [Image.fromarray(o, mode="RGB") for o in out]
+
+    def _engine_for(self, plan_key, batch: int):
+        """A prepared engine per (options, batch size): the parent engine serves the first plan, slots (shared
+        weights, own arena / graph) serve the others, so switching between batch sizes costs nothing per frame."""
+        key = (plan_key, batch)
+        eng = self._engines.get(key)
+        if eng is not None:
+            return eng
+        height, width, steps, strength, cn_scale, use_cn = plan_key
+        if plan_key != self._plan_key or len(self._engines) >= self.max_plans:
+            self._engines.clear()
+            self.model.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch)
+            self._plan_key = plan_key
+            eng = self.model
+        else:  # same schedule constants as the parent's current plan: a slot suffices
+            eng = self.model.make_slot()
+            eng.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch)
+        self._engines[key] = eng
+        return eng
 
     # `VideoSDPipeline.remote(**config)` -> awaitable handle (replaces the Ray actor API, server.py:320-321)
     @classmethod
