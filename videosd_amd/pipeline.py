@@ -75,6 +75,10 @@ class VideoSDPipeline:
 
         ops = HipOps(int(self.device))
         dev = ops.device
+        # per-shape kernel configurations found on an MI355X (shapes not in the table are timed at `prepare`)
+        tuning = os.environ.get("VSD_TUNING") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                              "profiles", "tuning_mi355x.json")
+        ops.load_tuning(tuning)
         wu = load_or_synthesize(W.unet_spec(C.SD15_UNET), "unet.", "unet.safetensors", dev)
         wc = load_or_synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", "controlnet.safetensors", dev)
         wv = load_or_synthesize(W.taesd_spec(C.TAESD), "vae.", "taesd.safetensors", dev)
