@@ -37,3 +37,29 @@ for name, H, Wd, steps, cn, scale in [("config1 256x256 1-step +CN", 256, 256, 1
     fps3 = n / (time.perf_counter() - t)
     row = {"config": name, "p50_latency_ms_1_in_flight": round(sorted(lat)[6], 2), "fps_3_in_flight": round(fps3, 1)}
     print(json.dumps(row), flush=True)
+
+# ---- BASELINE configs[3]: SDXL 1024x1024 LCM 4-step (UNet only path: no ControlNet), 1 frame per launch
+del slots, eng, wu, wc
+torch.cuda.empty_cache()
+wx = W.synthesize(W.unet_spec(C.SDXL_UNET), "sdxl.", device="cuda")
+xl = Engine(ops, C.SDXL_UNET, None, C.TAESD, wx, None, wv)
+g = torch.Generator().manual_seed(11)
+xl.set_text_embeds((torch.randn(77, 2048, generator=g) * 0.5).half())
+xl.set_added_cond((torch.randn(1280, generator=g) * 0.5).half(), (1024, 1024, 0, 0, 1024, 1024))
+xl.prepare(1024, 1024, 4, 0.6, use_controlnet=False)
+f = np.random.default_rng(0).integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
+lat = []
+for i in range(8):
+    t = time.perf_counter(); xl.infer_u8(f); lat.append((time.perf_counter() - t) * 1e3)
+s2 = xl.make_slot(); s2.prepare(1024, 1024, 4, 0.6, use_controlnet=False)
+for e in (xl, s2):
+    e.ops.upload(e.frame_u8, torch.from_numpy(f))
+for i in range(4): (xl, s2)[i % 2].launch()
+for e in (xl, s2): e.ops.synchronize()
+t = time.perf_counter()
+for i in range(12): (xl, s2)[i % 2].launch()
+for e in (xl, s2): e.ops.synchronize()
+fps2 = 12 / (time.perf_counter() - t)
+ops.save_tuning(os.path.join("gpurun_out", "tuning_with_sdxl.json"))
+print(json.dumps({"config": "config4 SDXL 1024x1024 4-step (27.0 TFLOP/frame)", "p50_latency_ms_1_in_flight": round(sorted(lat)[4], 2),
+                  "fps_2_in_flight": round(fps2, 2), "mfma_frac_at_that_fps": round(27.04 * fps2 / 2500.0, 4)}), flush=True)

@@ -207,6 +207,17 @@ def test_dispatcher_depth_keeps_several_frames_per_worker():
             p.close()
 
 
+def test_frame_loop_example_with_a_stand_in_worker():
+    """examples/frame_loop.py (the reference's recv/diffuse loop with a synthetic camera) end to end on a fake worker."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import frame_loop
+
+    out = frame_loop.main(["--factory", FAKE, "--gpus", "2", "--fps", "40", "--seconds", "1.5", "--batch", "2", "--mode", "in_order",
+                           "--height", "12", "--width", "16", "--worker-config", '{"delay": 0.02}'])
+    assert out["offered"] >= 40 and out["processed"] + out["dropped"] == out["offered"]
+    assert out["shown"] == out["processed"] and out["output_fps"] > 20 and out["p50_latency_ms"] < 500
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -84,3 +84,24 @@ def test_remote_handle_across_a_process_boundary(pipe):
         assert all(o.size == (256, 192) for o in three)
     finally:
         h.close()
+
+
+def test_sdxl_model_name_selects_the_sdxl_engine():
+    """Extension: `model` containing "xl" -> SDXL-base UNet, no ControlNet; same `infer` surface (BASELINE configs[3])."""
+    from oracle.pipeline import OraclePipeline
+    from videosd_amd import config as C
+    from videosd_amd import weights as W
+    from videosd_amd.pipeline import VideoSDPipeline
+
+    p = VideoSDPipeline(model="latent-consistency/lcm-sdxl", controlnet="none")
+    img = _photo(300, 200, 9)
+    opts = dict(prompt="an oil painting", height=128, width=192, strength=0.6, steps=2)
+    got = p.infer(img, **opts)
+    assert got.size == (192, 128)
+    wu = W.synthesize(W.unet_spec(C.SDXL_UNET), "sdxl.", device="cuda")
+    wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda")
+    orc = OraclePipeline(C.SDXL_UNET, None, _cpu(wu), None, _cpu(wv))
+    ref = orc.infer(img, p.encode_prompt(opts["prompt"])[None].float(), height=128, width=192, strength=0.6, steps=2,
+                    use_controlnet=False, pooled=p.encode_pooled(opts["prompt"]))
+    a, b = np.asarray(got), np.asarray(ref)
+    assert np.abs(a.astype(int) - b.astype(int)).mean() <= 1.5 and _psnr(a, b) >= 38.0

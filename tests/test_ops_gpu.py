@@ -300,7 +300,10 @@ def test_qkv_transposed_output_and_dual_output(ops):
 
 @pytest.mark.parametrize("c0,c1,hw,silu,eps", [(320, 0, 4096, True, 1e-5), (1280, 640, 256, True, 1e-5),
                                                 (2560, 0, 64, False, 1e-6), (64, 0, 100, True, 1e-5),
-                                                (128, 64, 35, False, 1e-5), (640, 320, 1024, True, 1e-5)])
+                                                (128, 64, 35, False, 1e-5), (640, 320, 1024, True, 1e-5),
+                                                # one-launch form (hw <= 1024, 8- or 16-byte aligned groups)
+                                                (640, 0, 1024, True, 1e-5), (1280, 0, 256, True, 1e-5), (1280, 1280, 70, True, 1e-5),
+                                                (128, 0, 1000, False, 1e-6), (256, 128, 300, True, 1e-5), (1280, 0, 1, True, 1e-5)])
 def test_groupnorm(ops, c0, c1, hw, silu, eps):
     c = c0 + c1
     a = rnd(hw, c0, seed=1) * 2 + 0.5

@@ -7,6 +7,7 @@
 // (+SiLU).  The input may be the channel concat of two tensors (UNet up blocks) and the output is the
 // concatenated, normalised tensor.  Algorithmic bytes: 2 reads + 1 write of hw*C fp16.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -191,6 +192,131 @@ __global__ void gn_apply_kernel(const GnParams p) {
   }
 }
 
+// ------------------------------------------------------------------ one-launch GroupNorm for small images
+// One workgroup per (image, group): the group's cpg channels of every pixel (a cpg*2-byte piece of each NHWC row) are
+// loaded ONCE into registers, reduced (wave shuffles + a fixed-order LDS fold: deterministic), normalised from the
+// registers and stored.  The two-launch form above spends ~9 + ~6 us on these few-hundred-KB tensors, all of it launch
+// and memory latency; this is one launch and one round trip.  VW = halfs per vector load (the alignment cpg allows),
+// NV = vectors per row piece (cpg / VW), RMAX rows per thread.
+template <int VW, int NV, int RMAX>
+__global__ void gn_fused_kernel(const GnParams p) {
+  typedef _Float16 vec_t __attribute__((ext_vector_type(VW)));
+  __shared__ float red[2 * 16 + 2];
+  const int t = threadIdx.x, T = blockDim.x;
+  const int g = blockIdx.x;
+  const size_t img0 = (size_t)blockIdx.y * p.hw;
+  const int ch0 = g * p.cpg;
+  vec_t x[RMAX][NV];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    const int row = t + r * T;
+    if (row < p.hw) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = ch0 + v * VW;  // a vector never straddles the two concat sources (c0 % VW == 0, host check)
+        const half_t* src = (c < p.c0) ? p.src0 + (img0 + row) * p.c0 + c : p.src1 + (img0 + row) * p.c1 + (c - p.c0);
+        x[r][v] = *reinterpret_cast<const vec_t*>(src);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    const int row = t + r * T;
+    if (row < p.hw) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+          const float f = (float)x[r][v][i];
+          s += f;
+          q += f * f;
+        }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  const int wave = t >> 6, nw = T >> 6;
+  if ((t & 63) == 0) {
+    red[2 * wave] = s;
+    red[2 * wave + 1] = q;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float S = 0.f, Q = 0.f;
+    for (int w = 0; w < nw; ++w) {
+      S += red[2 * w];
+      Q += red[2 * w + 1];
+    }
+    const float n = (float)p.hw * (float)p.cpg;
+    const float mean = S / n;
+    const float var = fmaxf(Q / n - mean * mean, 0.f);
+    red[32] = mean;
+    red[33] = rsqrtf(var + p.eps);
+  }
+  __syncthreads();
+  const float mean = red[32], rstd = red[33];
+  float a[NV][VW], b[NV][VW];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const vec_t ga = *reinterpret_cast<const vec_t*>(p.gamma + ch0 + v * VW);
+    const vec_t be = *reinterpret_cast<const vec_t*>(p.beta + ch0 + v * VW);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+      a[v][i] = rstd * (float)ga[i];
+      b[v][i] = (float)be[i] - mean * a[v][i];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    const int row = t + r * T;
+    if (row < p.hw) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        vec_t y;
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+          float f = (float)x[r][v][i] * a[v][i] + b[v][i];
+          if (p.silu) f = silu_f(f);
+          y[i] = (half_t)f;
+        }
+        *reinterpret_cast<vec_t*>(p.out + (img0 + row) * p.c + ch0 + v * VW) = y;
+      }
+    }
+  }
+}
+
+// launches the one-kernel form when the shape fits it (dry: only says whether it would); returns false otherwise
+static bool gn_try_fused(const GnParams& p, int batch, hipStream_t s, bool dry) {
+  if (p.hw > 1024 || p.chan0 || getenv("VSD_GN_NO_FUSED")) return false;
+  const int threads = p.hw <= 64 ? 64 : (p.hw <= 128 ? 128 : 256);
+  const int rows = (p.hw + threads - 1) / threads;  // <= 4
+  dim3 grid(p.groups, batch), block(threads);
+  const bool a8 = p.cpg % 8 == 0 && p.c0 % 8 == 0 && p.c1 % 8 == 0;
+  const bool a4 = p.cpg % 4 == 0 && p.c0 % 4 == 0 && p.c1 % 4 == 0;
+#define GN_GO(VW_, NV_)                                                                           \
+  {                                                                                               \
+    if (dry) return true;                                                                         \
+    if (rows <= 1) hipLaunchKernelGGL((gn_fused_kernel<VW_, NV_, 1>), grid, block, 0, s, p);      \
+    else if (rows <= 2) hipLaunchKernelGGL((gn_fused_kernel<VW_, NV_, 2>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((gn_fused_kernel<VW_, NV_, 4>), grid, block, 0, s, p);                \
+    return true;                                                                                  \
+  }
+  if (a8 && p.cpg == 40) GN_GO(8, 5)
+  if (a8 && p.cpg == 80) GN_GO(8, 10)
+  if (a8 && p.cpg == 8) GN_GO(8, 1)
+  if (a8 && p.cpg == 16) GN_GO(8, 2)
+  if (a4 && p.cpg == 20) GN_GO(4, 5)
+  if (a4 && p.cpg == 60) GN_GO(4, 15)
+  if (a4 && p.cpg == 4) GN_GO(4, 1)
+  if (a4 && p.cpg == 12) GN_GO(4, 3)
+#undef GN_GO
+  return false;
+}
+
 // ------------------------------------------------------------------ LayerNorm: one wave per row
 template <int NCH>  // 16-byte chunks per lane
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, int rows, int c, const half_t* gamma,
@@ -286,6 +412,11 @@ extern "C" int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void*
   if (nblk < 1) nblk = 1;
   p.nblk = nblk;
   hipStream_t s = (hipStream_t)stream;
+  if (gn_try_fused(p, batch, s, true)) {
+    LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
+    gn_try_fused(p, batch, s, false);
+    return ls.finish();
+  }
   const size_t smem = (size_t)groups * 2 * 5 * sizeof(float);
   {
     const size_t smem_stats = (size_t)p.rpp * p.c * 2 * sizeof(float);

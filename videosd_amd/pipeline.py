@@ -79,6 +79,17 @@ class VideoSDPipeline:
         tuning = os.environ.get("VSD_TUNING") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                               "profiles", "tuning_mi355x.json")
         ops.load_tuning(tuning)
+        # Extension (BASELINE.json configs[3]; the reference only knows SD1.5): a model name containing "xl" selects the
+        # SDXL-base UNet topology (LCM-SDXL weights as `unet_sdxl.safetensors`, TAESD-XL as `taesdxl.safetensors`),
+        # without a ControlNet tower; prompts then need 2048-wide embeddings + a 1280-wide pooled vector.
+        self.is_xl = "xl" in str(model_name).lower()
+        self.unet_cfg = C.SDXL_UNET if self.is_xl else C.SD15_UNET
+        if self.is_xl:
+            wu = load_or_synthesize(W.unet_spec(C.SDXL_UNET), "sdxl.", "unet_sdxl.safetensors", dev)
+            wv = load_or_synthesize(W.taesd_spec(C.TAESD), "vae.", "taesdxl.safetensors", dev)
+            self.model = Engine(ops, C.SDXL_UNET, None, C.TAESD, wu, None, wv)
+            self.text_encoder = None
+            return self.model
         wu = load_or_synthesize(W.unet_spec(C.SD15_UNET), "unet.", "unet.safetensors", dev)
         wc = load_or_synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", "controlnet.safetensors", dev)
         wv = load_or_synthesize(W.taesd_spec(C.TAESD), "vae.", "taesd.safetensors", dev)
@@ -104,7 +115,14 @@ class VideoSDPipeline:
         if self.text_encoder is not None and self.text_encoder.has_tokenizer:
             return self.text_encoder.encode(text)
         g = torch.Generator().manual_seed(zlib.crc32(text.encode()))
-        return (torch.randn(77, C.SD15_UNET.cross_dim, generator=g) * 0.5).half()
+        return (torch.randn(77, self.unet_cfg.cross_dim, generator=g) * 0.5).half()
+
+    def encode_pooled(self, prompt: Union[str, List[str]]) -> torch.Tensor:
+        """SDXL only: the pooled text embedding [1280] (stand-in seeded by the prompt text; the two SDXL text encoders
+        are outside this path)."""
+        text = prompt if isinstance(prompt, str) else " ".join(prompt)
+        g = torch.Generator().manual_seed(zlib.crc32(("pooled:" + text).encode()))
+        return (torch.randn(self.unet_cfg.add_pooled_dim, generator=g) * 0.5).half()
 
     def set_prompt_embeds(self, embeds: torch.Tensor, key=None):
         """Install embeddings produced elsewhere (rank 0 broadcasts them over RCCL, dispatch.py)."""
@@ -145,7 +163,13 @@ class VideoSDPipeline:
         if pkey != self._prompt_key:
             self.model.set_text_embeds(self.encode_prompt(prompt))
             self._prompt_key = pkey  # (the cross-attention K / V^T caches are rewritten in place: captured graphs stay valid)
-        use_cn = bool(controlnet) if self.honor_controlnet_flag else True
+            if self.is_xl:
+                self._pooled = self.encode_pooled(prompt)
+                self._engines.clear()  # the added conditioning is baked into the time embeddings at `prepare`
+                self._plan_key = None
+        if self.is_xl:  # micro-conditioning: original size = target size = the frame size, no crop
+            self.model.set_added_cond(self._pooled, (height, width, 0, 0, height, width))
+        use_cn = False if self.is_xl else (bool(controlnet) if self.honor_controlnet_flag else True)
         plan_key = (height, width, int(steps), float(strength), float(controlnet_scale), use_cn)
         eng = self._engine_for(plan_key, len(imgs))
         np.random.seed(seed)  # kept for parity with videopipeline.py:112 (nothing downstream consumes it)
