@@ -128,11 +128,29 @@ class RemotePipeline:
         self._lock = threading.Lock()
         self._next = 0
         self._pending: Dict[int, Any] = {}
+        # Requests leave through a writer thread: a frame is ~0.8 MB, far more than the pipe buffers, so a `send` in the
+        # caller's thread would block the event loop while the worker is busy -- and while holding the lock the reader
+        # needs to hand back the worker's (equally large) result, which is a deadlock.
+        import queue
+
+        self._outbox: "queue.Queue" = queue.Queue()
+        self._writer = threading.Thread(target=self._write_loop, daemon=True)
+        self._writer.start()
         self._reader = threading.Thread(target=self._read_loop, daemon=True)
         self._reader.start()
         self.infer = _RemoteMethod(self, "infer")
         self.compile_model = _RemoteMethod(self, "compile_model")
         self.set_prompt_embeds = _RemoteMethod(self, "set_prompt_embeds")
+
+    def _write_loop(self):
+        while True:
+            msg = self._outbox.get()
+            try:
+                self._conn.send(msg)
+            except (OSError, ValueError, BrokenPipeError):
+                return
+            if msg is None:
+                return
 
     def _read_loop(self):
         while True:
@@ -159,7 +177,7 @@ class RemotePipeline:
             rid = self._next
             self._next += 1
             self._pending[rid] = (target, loop)
-            self._conn.send((rid, name, args, kwargs))
+        self._outbox.put((rid, name, args, kwargs))
 
     def _submit(self, name, args, kwargs):
         try:
@@ -181,7 +199,11 @@ class RemotePipeline:
 
     def close(self):
         try:
-            self._conn.send(None)
+            if hasattr(self, "_outbox"):
+                self._outbox.put(None)
+                self._writer.join(timeout=2)
+            else:
+                self._conn.send(None)
         except Exception:
             pass
         if self._proc.is_alive():
