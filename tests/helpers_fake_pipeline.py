@@ -37,6 +37,25 @@ class FakePipeline:
             outs.append(Image.fromarray(a.astype(np.uint8), "RGB"))
         return outs
 
+    # two-phase form (what the pipelined worker loop uses): the 'GPU work' is a timer started at submit
+    def submit_batch(self, imgs, lane=0, **opts):
+        if opts.get("strength", 0.4) < 0:
+            raise ValueError("negative strength")
+        self.lanes_used = getattr(self, "lanes_used", set()) | {lane}
+        return (time.time() + self.delay, imgs, opts, lane)
+
+    def collect_batch(self, handle):
+        ready, imgs, opts, lane = handle
+        time.sleep(max(0.0, ready - time.time()))
+        outs = []
+        for img in imgs:
+            a = 255 - np.asarray(img.convert("RGB").resize((opts.get("width", 640), opts.get("height", 360))))
+            a[0, 0, 0] = self.device
+            a[0, 0, 1] = len(imgs)
+            a[0, 0, 2] = lane
+            outs.append(Image.fromarray(a.astype(np.uint8), "RGB"))
+        return outs
+
     def compile_model(self):
         return Image.new("RGB", (8, 8))
 

@@ -168,7 +168,9 @@ def test_worker_coalesces_queued_frames_into_batched_launches():
         sizes = [t if t <= 3 else 1 for t in (int(np.asarray(o)[0, 0, 1]) for o in outs)]
         # frame 0 was taken alone or with whatever had already arrived; later ones were coalesced (never more than 3)
         assert max(sizes) <= 3 and sum(1 for s_ in sizes if s_ > 1) >= 2, sizes
-        assert int(np.asarray(other)[1, 1, 0]) == 165 and int(np.asarray(other)[0, 0, 1]) == 165  # untagged: the plain single-frame `infer`
+        assert int(np.asarray(other)[1, 1, 0]) == 165 and int(np.asarray(other)[0, 0, 1]) in (1, 165)  # a launch of its own
+        # two launches in flight: consecutive launches alternate between the two engine lanes
+        assert {int(np.asarray(o)[0, 0, 2]) for o in outs} == {0, 1}
         # an error inside a batched launch reaches every caller of that launch
         async def bad():
             a = p.infer.remote(_img(1), strength=-1.0)

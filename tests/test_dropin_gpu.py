@@ -61,7 +61,7 @@ def test_infer_batch_gives_every_frame_its_single_frame_result(pipe):
         assert a.shape == b.shape and np.abs(a.astype(int) - b.astype(int)).mean() < 0.5
     # both plans stay prepared: going back to single frames replays the first graph bit-exactly
     assert np.array_equal(np.asarray(pipe.infer(imgs[0], **OPTS)), single[0])
-    assert len(pipe._engines) == 2
+    assert len(pipe._engines) == 2  # (options, 1, lane 0) and (options, 3, lane 0)
 
 
 def test_remote_handle_across_a_process_boundary(pipe):

@@ -57,23 +57,44 @@ def _resolve(path: str) -> Callable:
 
 
 def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1):
-    """Serve calls one at a time, like a Ray actor.  With max_batch > 1, `infer` calls that are ALREADY queued behind
-    the one being taken (frames of other sessions, or of the same stream submitted ahead) and carry the same options
-    are coalesced into one `infer_batch` launch: no waiting for a batch to fill, so a lone frame is never delayed."""
+    """Serve calls in order, like a Ray actor.  With max_batch > 1, `infer` calls that are ALREADY queued behind the one
+    being taken (frames of other sessions, or of the same stream submitted ahead) and carry the same options are
+    coalesced into one `infer_batch` launch: no waiting for a batch to fill, so a lone frame is never delayed.  When
+    the pipeline has `submit_batch` / `collect_batch`, up to two launches are kept in flight (two engine lanes): while
+    the GPU works on one, this process crops / resizes / uploads the next and converts / sends the previous one.
+    Results always go back in request order."""
     try:
         pipe = _resolve(factory)(**config)
         conn.send(("ready", None))
     except BaseException as e:  # construction errors travel to the parent (the reference re-raises KeyError)
         conn.send(("error", (type(e).__name__, str(e))))
         return
-    backlog = []
+    pipelined = max_batch > 1 and hasattr(pipe, "submit_batch") and hasattr(pipe, "collect_batch")
+    backlog, inflight, lane = [], [], 0
+
+    def fail(group, e):
+        for r, _ in group:
+            conn.send((r, False, (type(e).__name__, str(e))))
+
+    def finish_oldest():
+        group, handle = inflight.pop(0)
+        try:
+            for (r, _), o in zip(group, pipe.collect_batch(handle)):
+                conn.send((r, True, o))
+        except BaseException as e:
+            fail(group, e)
+
     while True:
+        if inflight and not backlog and not conn.poll(0):  # nothing new to start: hand back the oldest launch
+            finish_oldest()
+            continue
         msg = backlog.pop(0) if backlog else conn.recv()
         if msg is None:
             break
         rid, method, args, kwargs = msg
         group = [(rid, args)]
-        if max_batch > 1 and method == "infer" and len(args) == 1 and hasattr(pipe, "infer_batch"):
+        batchable = max_batch > 1 and method == "infer" and len(args) == 1 and hasattr(pipe, "infer_batch")
+        if batchable:
             while len(group) < max_batch and (backlog or conn.poll(0)):
                 nxt = backlog.pop(0) if backlog else conn.recv()
                 if nxt is not None and nxt[1] == "infer" and len(nxt[2]) == 1 and nxt[3] == kwargs:
@@ -81,6 +102,21 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1)
                 else:  # different options / another method / shutdown: serve it next, stop growing this batch
                     backlog.insert(0, nxt)
                     break
+        if batchable and pipelined:
+            try:
+                handle = pipe.submit_batch([a[0] for _, a in group], lane=lane, **kwargs)
+            except BaseException as e:
+                while inflight:
+                    finish_oldest()
+                fail(group, e)
+                continue
+            lane ^= 1
+            inflight.append((group, handle))
+            if len(inflight) > 1:
+                finish_oldest()
+            continue
+        while inflight:  # anything else runs alone, after what is in flight
+            finish_oldest()
         try:
             if len(group) > 1:
                 outs = pipe.infer_batch([a[0] for _, a in group], **kwargs)
@@ -89,8 +125,9 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1)
             else:
                 conn.send((rid, True, getattr(pipe, method)(*args, **kwargs)))
         except BaseException as e:
-            for r, _ in group:
-                conn.send((r, False, (type(e).__name__, str(e))))
+            fail(group, e)
+    while inflight:
+        finish_oldest()
 
 
 class _RemoteMethod:

@@ -63,7 +63,7 @@ class VideoSDPipeline:
         self._prompt_key = None
         self._plan_key = None
         self._engines = {}  # (plan_key, batch) -> prepared engine (the first one is self.model, the others are its slots)
-        self.max_plans = int(kwargs.get("max_plans", 4))
+        self.max_plans = int(kwargs.get("max_plans", 8))
 
     # ------------------------------------------------------------------ model loading
     def load_model(self, model_name, controlnet_model="lllyasviel/control_v11p_sd15_canny"):
@@ -158,6 +158,16 @@ class VideoSDPipeline:
         one batched launch: same result per frame as `infer` (frames are denoised independently), one pass over the
         weights for all of them.  Extension of the reference surface; `RemotePipeline(batch=B)` coalesces queued
         `infer` calls into this."""
+        return self.collect_batch(self.submit_batch(imgs, prompt=prompt, height=height, width=width, strength=strength,
+                                                    steps=steps, guidance_scale=guidance_scale, ref=ref,
+                                                    style_fidelity=style_fidelity, controlnet=controlnet, seed=seed,
+                                                    controlnet_scale=controlnet_scale))
+
+    def submit_batch(self, imgs, lane: int = 0, prompt=["pixar, cg"], height=360, width=640, strength=0.4, steps=20,
+                     guidance_scale=7.5, ref=False, style_fidelity=0.0, controlnet=False, seed=42, controlnet_scale=1):
+        """First half of `infer_batch`: crop / resize, upload, enqueue -- returns a handle for `collect_batch` without
+        waiting for the GPU.  `lane` picks one of the prepared engines of that (options, batch size): two lanes keep two
+        launches in flight while the host works on the frames around them (the worker loop of dispatch.py does that)."""
         imgs = [center_crop_resize(im, width, height) for im in imgs]
         pkey = prompt if isinstance(prompt, str) else tuple(prompt)
         if pkey != self._prompt_key:
@@ -171,17 +181,22 @@ class VideoSDPipeline:
             self.model.set_added_cond(self._pooled, (height, width, 0, 0, height, width))
         use_cn = False if self.is_xl else (bool(controlnet) if self.honor_controlnet_flag else True)
         plan_key = (height, width, int(steps), float(strength), float(controlnet_scale), use_cn)
-        eng = self._engine_for(plan_key, len(imgs))
+        eng = self._engine_for(plan_key, len(imgs), lane)
         np.random.seed(seed)  # kept for parity with videopipeline.py:112 (nothing downstream consumes it)
         frames = np.stack([np.asarray(im.convert("RGB"), dtype=np.uint8) for im in imgs])
-        out = eng.infer_u8(frames[0] if len(imgs) == 1 else frames)
-        out = out[None] if len(imgs) == 1 else out
+        eng.submit_u8(frames[0] if len(imgs) == 1 else frames)
+        return (eng, len(imgs))
+
+    def collect_batch(self, handle):
+        eng, n = handle
+        out = eng.collect_u8()
+        out = out[None] if n == 1 else out
         return [Image.fromarray(o, mode="RGB") for o in out]
 
-    def _engine_for(self, plan_key, batch: int):
-        """A prepared engine per (options, batch size): the parent engine serves the first plan, slots (shared
+    def _engine_for(self, plan_key, batch: int, lane: int = 0):
+        """A prepared engine per (options, batch size, lane): the parent engine serves the first plan, slots (shared
         weights, own arena / graph) serve the others, so switching between batch sizes costs nothing per frame."""
-        key = (plan_key, batch)
+        key = (plan_key, batch, lane)
         eng = self._engines.get(key)
         if eng is not None:
             return eng
