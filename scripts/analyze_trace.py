@@ -4,7 +4,7 @@ import collections, csv, json, sys
 
 trace, opsf = sys.argv[1], sys.argv[2]
 ops = json.load(open(opsf))
-ours = ("conv_gemm_kernel", "splitk_reduce", "gn_stats", "gn_apply", "layernorm_kernel", "attention_kernel",
+ours = ("conv_gemm_kernel", "splitk_reduce", "gn_stats", "gn_apply", "gn_fused", "layernorm_kernel", "attention_kernel",
         "preprocess_rgb", "sobel_max", "sobel_apply", "add_noise", "lcm_step", "postprocess")
 rows = [r for r in csv.DictReader(open(trace)) if any(o in r["Kernel_Name"] for o in ours)]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -20,7 +20,7 @@ for m in ops:
     if m["op"] == "conv" and pos + 1 < len(last) and "splitk_reduce" in last[pos + 1]["Kernel_Name"]:
         n = 2
     if m["op"] == "groupnorm" and "gn_stats" not in last[pos]["Kernel_Name"]:
-        n = 1  # statistics fused into the producer
+        n = 1  # one-launch form (small images), or statistics fused into the producer
     ks = last[pos:pos + n]
     pos += n
     total += n

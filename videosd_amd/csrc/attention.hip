@@ -110,24 +110,26 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
   const bool ones_row = d < DV;
 
   // ---- per-thread staging coordinates (fixed for the whole kernel)
-  int kg[KCH], kl[KCH], krow[KCH];
+  unsigned kg[KCH];
+  int kl[KCH], krow[KCH];
 #pragma unroll
   for (int i = 0; i < KCH; ++i) {
     int c = gtid + i * NTG;
     bool ok = c < 64 * dch;
     int kr = ok ? c / dch : 0, kc = ok ? c - kr * dch : 0;
     krow[i] = ok ? kr : 1 << 28;  // never < sk
-    kg[i] = kr * p.ldk + head * d + kc * 8;
+    kg[i] = ok ? (unsigned)(kr * p.ldk + head * d + kc * 8) : 0u;  // (idle threads load a valid address they never store)
     kl[i] = kr * KS + kc * 8;
   }
-  int vg[VCH], vl[VCH];
+  unsigned vg[VCH];
+  int vl[VCH];
   bool vok[VCH];
 #pragma unroll
   for (int i = 0; i < VCH; ++i) {
     int c = gtid + i * NTG;
     vok[i] = c < d * 8;
     int vr = vok[i] ? c >> 3 : 0, vc = c & 7;
-    vg[i] = (head * d + vr) * p.ldvt + vc * 8;
+    vg[i] = vok[i] ? (unsigned)((head * d + vr) * p.ldvt + vc * 8) : 0u;
     // keys 8vc..8vc+7 of the tile; inside every 16-key step the LDS order is [0-3, 8-11, 4-7, 12-15] (the order in
     // which the S^T accumulator registers hold the keys): first half -> +0 (vc even) / +4 (odd), second -> +8 / +12
     vl[i] = vr * VS + (vc >> 1) * 16 + (vc & 1) * 4;
@@ -136,19 +138,23 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
   // slot.  One tile of look-ahead is not enough here: a tile's math is ~1k cycles, a K / V^T fetch that misses the
   // XCD's L2 takes 2-4k (the kernel was running at that latency per tile).
   u32x4 kreg[2][KCH], vreg[2][VCH];
+// The tile's base addresses are wave-uniform (scalar); each thread adds a fixed unsigned 32-bit offset, so a load costs
+// no per-tile address arithmetic.  Rows past the last key (ragged last tile only) re-read row 0 (a valid address), NOT
+// zeroed by a select: a select on the loaded value makes the wave wait for the load on the spot (a whole memory latency
+// per tile); those keys are masked to -inf in the score tile anyway.
 #define ATT_LOAD(SET_, KEY0_)                                                                       \
   {                                                                                                 \
-    /* rows past the last key are re-reads of the last valid row block (clamped address), NOT zeroed by a select:   \
-       a select on the loaded value makes the wave wait for the load right here (the whole memory latency, every    \
-       tile); those keys are masked to -inf in the score tile anyway */                                             \
-    _Pragma("unroll") for (int i = 0; i < KCH; ++i) {                                               \
-      bool ok = (KEY0_) + krow[i] < p.sk;                                                           \
-      kreg[SET_][i] = *reinterpret_cast<const u32x4*>(p.k + (ok ? (size_t)(KEY0_) * p.ldk + kg[i] : 0)); \
+    const half_t* kb_ = p.k + (size_t)(KEY0_) * p.ldk;                                              \
+    const half_t* vb_ = p.vt + (KEY0_);                                                             \
+    if ((KEY0_) + 64 <= p.sk) {                                                                     \
+      _Pragma("unroll") for (int i = 0; i < KCH; ++i) kreg[SET_][i] = *reinterpret_cast<const u32x4*>(kb_ + kg[i]); \
+    } else {                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < KCH; ++i) {                                             \
+        const bool ok = (KEY0_) + krow[i] < p.sk;                                                   \
+        kreg[SET_][i] = *reinterpret_cast<const u32x4*>(ok ? kb_ + kg[i] : p.k);                    \
+      }                                                                                             \
     }                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < VCH; ++i) {                                               \
-      u32x4 v = *reinterpret_cast<const u32x4*>(p.vt + (vok[i] ? (size_t)vg[i] + (KEY0_) : 0));     \
-      vreg[SET_][i] = v;                                                                            \
-    }                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < VCH; ++i) vreg[SET_][i] = *reinterpret_cast<const u32x4*>(vb_ + vg[i]); \
   }
 #define ATT_STORE(SET_, BUF_)                                                                       \
   {                                                                                                 \

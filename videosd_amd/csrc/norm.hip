@@ -291,8 +291,11 @@ __global__ void gn_fused_kernel(const GnParams p) {
 
 // launches the one-kernel form when the shape fits it (dry: only says whether it would); returns false otherwise
 static bool gn_try_fused(const GnParams& p, int batch, hipStream_t s, bool dry) {
-  if (p.hw > 1024 || p.chan0 || getenv("VSD_GN_NO_FUSED")) return false;
-  const int threads = p.hw <= 64 ? 64 : (p.hw <= 128 ? 128 : 256);
+  if (p.chan0 || getenv("VSD_GN_NO_FUSED")) return false;
+  // measured on MI355X (us, one launch vs two): 8x8x1280 5.5 vs 14.5; 16x16x1280 6.3 vs 14.2; 32x32x640 11.5 vs 13.6;
+  // it loses with more registers per thread (32x32x1920: 133 vs 14) and with 20-byte row pieces at 64x64 (31 vs 15)
+  if (!((p.hw <= 256 && p.cpg <= 40) || (p.hw <= 1024 && p.cpg <= 20))) return false;
+  const int threads = p.hw <= 64 ? 64 : (p.hw <= 128 ? 128 : (p.hw <= 256 ? 256 : 1024));
   const int rows = (p.hw + threads - 1) / threads;  // <= 4
   dim3 grid(p.groups, batch), block(threads);
   const bool a8 = p.cpg % 8 == 0 && p.c0 % 8 == 0 && p.c1 % 8 == 0;
@@ -313,6 +316,9 @@ static bool gn_try_fused(const GnParams& p, int batch, hipStream_t s, bool dry) 
   if (a4 && p.cpg == 60) GN_GO(4, 15)
   if (a4 && p.cpg == 4) GN_GO(4, 1)
   if (a4 && p.cpg == 12) GN_GO(4, 3)
+  if (p.cpg == 10 && p.c0 % 2 == 0 && p.c1 % 2 == 0) GN_GO(2, 5)
+  if (p.cpg == 2 && p.c0 % 2 == 0 && p.c1 % 2 == 0) GN_GO(2, 1)
+  if (p.cpg == 6 && p.c0 % 2 == 0 && p.c1 % 2 == 0) GN_GO(2, 3)
 #undef GN_GO
   return false;
 }
