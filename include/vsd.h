@@ -94,7 +94,10 @@ typedef struct vsd_conv_desc {
   void* workspace;
   int32_t pipeline;       /* main-loop form: 0 = register-staged double buffer; 3 or 4 = direct-to-LDS ring with
                              that many stages (global_load_lds, counted vmcnt); 5 / 6 = the 3- / 4-stage ring with the
-                             DMA issues interleaved between the MFMAs (single-basic-block iterations) */
+                             DMA issues interleaved between the MFMAs (single-basic-block iterations); 7 = halo patch:
+                             3x3 stride-1 convs only (Cin % 64 == 0 per source, tile 128x128 or 128x64, plain
+                             epilogue): the (8+2)x(16+2) input patch of a 64-channel block is
+                             staged in LDS once and serves all nine taps */
   void* rowstat_out;      /* optional fp32 [M][n/64][2]: per output row, (sum, sum of squares) of the fp16 outputs over
                              each 64-column group -- the LayerNorm statistics of the NEXT layer, for free */
   void* chanstat_out;     /* optional fp32 [n][2]: per output CHANNEL, (sum, sum of squares) of the fp16 outputs over all M

@@ -1129,6 +1129,273 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
   }
 }
 
+// ---------------------------------------------------------------- 3x3 conv with an LDS halo patch
+// The implicit-GEMM kernel above fetches every input pixel nine times per output-channel tile (once per tap), and at
+// these tile sizes it is the L2 -> LDS fill path that binds.  Here a workgroup's 128 output pixels are an 8 x 16 PATCH
+// of one image; for each 64-channel block the (8+2) x (16+2) input patch is staged in LDS ONCE and all nine taps read
+// it at shifted row indices (a tap is an LDS address offset, not a memory fetch): input traffic / 6.4, LDS-DMA issues
+// for the input / 6 (6 per wave per channel block instead of 4 per wave per tap).  Only the weight tiles stream per tap
+// (3-slot ring, counted vmcnt).  Zero padding = out-of-range buffer offsets, as in the FAST path.
+// K order inside a workgroup: channel block outer, tap inner (weights stay [N][(ky,kx,c)]).  Split-K over channel
+// blocks writes fp32 slabs for splitk_reduce_kernel.  Epilogue: bias + time vector, activation, one residual.
+// Eligible: ksize 3, stride 1, pad 1, no resize, Cin % 64 == 0 (each concat source); patches hanging over the right /
+// bottom edge compute but do not store their outside pixels.
+template <int BN>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
+  constexpr int BM = 128, PW = 16, PH = 8, HW_ = PW + 2;  // halo row length 18
+  constexpr int HROWS = 192;                               // (PH+2)*(PW+2) = 180 rows, padded to 24 wave-instructions
+  constexpr int AI = 6, BR = BN / 32;
+  constexpr int TM = 64, TN = BN / 2, FM = TM / 16, FN = TN / 16;
+  constexpr int BNP = BN + 4;
+  constexpr int A_HALFS = HROWS * BK, B_HALFS = BN * BK;
+  constexpr int STAGE_BYTES = (2 * A_HALFS + 3 * B_HALFS) * 2;
+  constexpr int EPI_BYTES = BM * BNP * 4;
+  constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  half_t* Abuf = reinterpret_cast<half_t*>(smem);
+  half_t* Bbuf = Abuf + 2 * A_HALFS;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  constexpr int OOB = (int)0x80000000;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  int tile_m, grp;
+  {  // XCD-aware order, as in conv_gemm_kernel
+    const int bid = blockIdx.x;
+    const int G = p.tiles_n * p.split_k;
+    const int full = (G >> 3) << 3;
+    if (bid < full * p.tiles_m) {
+      const int span = 8 * p.tiles_m;
+      const int chunk = bid / span, r = bid - chunk * span;
+      grp = chunk * 8 + (r & 7);
+      tile_m = r >> 3;
+    } else {
+      const int rem = bid - full * p.tiles_m;
+      grp = full + rem / p.tiles_m;
+      tile_m = rem % p.tiles_m;
+    }
+  }
+  const int tile_n = grp % p.tiles_n;
+  const int split = grp / p.tiles_n;
+  const int n0 = tile_n * BN;
+  // tile -> (image, patch origin)
+  const int ppr = (p.wo + PW - 1) / PW, tpi = ((p.ho + PH - 1) / PH) * ppr;  // patches may hang over the right / bottom edge
+  const int img = tile_m / tpi, trem = tile_m - img * tpi;
+  const int y0 = (trem / ppr) * PH, x0 = (trem % ppr) * PW;
+  const int pix0 = img * p.img_in;  // first pixel of the image (hs == ho, ws == wo)
+  auto row_ok = [&](int r) { return y0 + (r >> 4) < p.ho && x0 + (r & 15) < p.wo; };
+  auto row_m = [&](int r) { return pix0 + (y0 + (r >> 4)) * p.wo + x0 + (r & 15); };
+
+  // channel blocks of this split
+  const int ncb_all = p.cin / BK;
+  const int cb_begin = split * p.kt_per_split;  // (kt_per_split counts channel blocks here)
+  const int cb_end = min(ncb_all, cb_begin + p.kt_per_split);
+  const int T = (cb_end - cb_begin) * 9;
+
+  // ---- A patch DMA: this wave's instructions j = wave + 4q cover halo rows 8j..8j+7; lane -> (row, 16-byte slot)
+  int apx[AI], alc[AI];
+#pragma unroll
+  for (int q = 0; q < AI; ++q) {
+    const int row = 8 * (wave + 4 * q) + (lane >> 3);
+    const int hy = row / HW_, hx = row - hy * HW_;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool in = row < (PH + 2) * HW_ && (unsigned)y < (unsigned)p.hi && (unsigned)x < (unsigned)p.wi;
+    apx[q] = in ? pix0 + y * p.ws + x : -1;
+    alc[q] = (((lane & 7) ^ (row & 7)) << 4);
+  }
+  int bvoff[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    const int r = 8 * wave + 32 * i + (lane >> 3);
+    const int n = n0 + r;
+    bvoff[i] = n < p.N ? n * p.Kp * 2 + (((lane & 7) ^ (r & 7)) << 4) : OOB;
+  }
+  const int anr0 = (int)((size_t)p.batch * p.img_in * p.c0 * 2), anr1 = (int)((size_t)p.batch * p.img_in * p.c1 * 2);
+  const int bnr = (int)((size_t)p.N * p.Kp * 2);
+
+#define HALO_ISSUE_A(CB_, BUF_)                                                                         \
+  {                                                                                                     \
+    const int ch_ = (CB_) * BK;                                                                         \
+    const bool second_ = ch_ >= p.c0;                                                                   \
+    const int cs2_ = (second_ ? p.c1 : p.c0) * 2;                                                       \
+    const int soff_ = (second_ ? ch_ - p.c0 : ch_) * 2;                                                 \
+    const __amdgpu_buffer_rsrc_t rs_ =                                                                  \
+        __builtin_amdgcn_make_buffer_rsrc((void*)(second_ ? p.src1 : p.src0), 0, second_ ? anr1 : anr0, 0x00020000); \
+    half_t* dst_ = Abuf + (BUF_) * A_HALFS;                                                             \
+    _Pragma("unroll") for (int q = 0; q < AI; ++q) {                                                    \
+      const int vo_ = apx[q] >= 0 ? __mul24(apx[q], cs2_) + alc[q] : OOB;                               \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)(dst_ + 8 * (wave_s + 4 * q) * BK), 16, vo_, soff_, 0, 0); \
+    }                                                                                                   \
+  }
+#define HALO_ISSUE_B(TAP_, CB_, SLOT_)                                                                  \
+  {                                                                                                     \
+    const int soff_ = ((TAP_) * p.cin + (CB_) * BK) * 2;                                                \
+    const __amdgpu_buffer_rsrc_t rsb_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, bnr, 0x00020000); \
+    half_t* dst_ = Bbuf + (SLOT_) * B_HALFS;                                                            \
+    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                    \
+      const int bv_ = bvoff[i] + 0;                                                                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb_, (lds_ptr_t)(dst_ + (8 * wave_s + 32 * i) * BK), 16, bv_, soff_, 0, 0); \
+    }                                                                                                   \
+  }
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment bases: A halo row of this lane's pixel for tap (0,0); B row
+  int hr0[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) hr0[i] = (wm * (TM / PW) + i) * HW_ + fr;
+
+  if (T > 0) {
+    HALO_ISSUE_A(cb_begin, 0)
+    HALO_ISSUE_B(0, cb_begin, 0)
+    if (T > 1) HALO_ISSUE_B(1, cb_begin, 1)
+  }
+  int tap = 0, cb = cb_begin, slot = 0;     // of iteration t
+  int tap2 = 2 % 9, cb2 = cb_begin + 2 / 9;  // of the tile fetched in iteration t (t + 2)
+  bool prev_a = false;                       // iteration t-1 issued an A patch
+  for (int t = 0; t < T; ++t) {
+    // tile t has landed once everything but the operations issued after it (iteration t-1's) is done
+    const bool prev_b = t + 1 < T;
+    if (prev_a && prev_b) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BR) : "memory");
+    else if (prev_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI) : "memory");
+    else if (prev_b) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BR) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    prev_a = false;
+    if (tap == 0 && cb + 1 < cb_end) {  // next channel block's patch: nine tiles of lead
+      HALO_ISSUE_A(cb + 1, (cb + 1 - cb_begin) & 1)
+      prev_a = true;
+    }
+    if (t + 2 < T) {
+      int ns = slot + 2;
+      if (ns >= 3) ns -= 3;
+      HALO_ISSUE_B(tap2, cb2, ns)
+    }
+    const half_t* a = Abuf + ((cb - cb_begin) & 1) * A_HALFS;
+    const half_t* b = Bbuf + slot * B_HALFS;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int toff = ky * HW_ + kx;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 af[FM], bf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int hr = hr0[i] + toff;
+        af[i] = *reinterpret_cast<const half8*>(a + hr * BK + (((ks * 4 + fq) ^ (hr & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int r = wn * TN + j * 16 + fr;
+        bf[j] = *reinterpret_cast<const half8*>(b + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (++slot == 3) slot = 0;
+    if (++tap == 9) { tap = 0; ++cb; }
+    if (++tap2 == 9) { tap2 = 0; ++cb2; }
+  }
+#undef HALO_ISSUE_A
+#undef HALO_ISSUE_B
+  __syncthreads();  // every wave is done reading the tiles before the epilogue reuses the LDS
+
+  // ---- epilogue.  Residual and bias + time vector are loaded before the accumulator transpose (and any store).
+  constexpr int CH = BN / 8;
+  constexpr int NIT = BM * CH / 256;
+  half8 rpre[NIT];
+  float brv[8];
+  const int pre_n = n0 + (tid % CH) * 8;
+  const bool ncol_ok = pre_n + 8 <= p.N;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) brv[i] = 0.f;
+  if (p.split_k == 1) {
+    if (ncol_ok && p.bias) {
+      half8 v = *reinterpret_cast<const half8*>(p.bias + pre_n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) brv[i] += (float)v[i];
+    }
+    if (ncol_ok && p.rowvec) {
+      half8 v = *reinterpret_cast<const half8*>(p.rowvec + pre_n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) brv[i] += (float)v[i];
+    }
+    if (p.residual) {
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const int q = tid + j * 256;
+        const int r = q / CH;
+        rpre[j] = *reinterpret_cast<const half8*>(p.residual + (ncol_ok && row_ok(r) ? (size_t)row_m(r) * p.ldr + pre_n : 0));
+      }
+    }
+  }
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = wn * TN + j * 16 + fr;
+      const int row = wm * TM + i * 16 + fq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[(row + r) * BNP + col] = acc[i][j][r];
+    }
+  __syncthreads();
+  if (p.split_k > 1) {  // fp32 slab of this split; splitk_reduce_kernel applies the epilogue
+    float* slab = p.ws_partial + (size_t)split * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int q = tid + j * 256;
+      const int r = q / CH, c8 = (q - r * CH) * 8;
+      const int n = n0 + c8;
+      if (n + 8 <= p.N && row_ok(r)) {
+        float* d = slab + (size_t)row_m(r) * p.N + n;
+        *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8);
+        *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8 + 4);
+      }
+    }
+    return;
+  }
+  const int act = p.act & 0xff;
+  const bool post = (p.act & VSD_ACT_POST) != 0;
+  auto finish = [&](auto act_tag) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_tag)::value;  // 0 none, 1 relu, 2 silu, 3 relu after the residual
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int q = tid + j * 256;
+      const int r = q / CH, c8 = (q - r * CH) * 8;
+      const int n = n0 + c8;
+      if (n + 8 <= p.N && row_ok(r)) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8 + 4);
+        const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        half8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float x = v[i] + brv[i];
+          if (ACT == 1) x = fmaxf(x, 0.f);
+          if (ACT == 2) x = silu_f(x);
+          if (p.residual) x += (float)rpre[j][i];
+          if (ACT == 3) x = fmaxf(x, 0.f);
+          o[i] = (half_t)x;
+        }
+        *reinterpret_cast<half8*>(p.out + (size_t)row_m(r) * p.ldo + n) = o;
+      }
+    }
+  };
+  if (act == VSD_ACT_RELU && post) finish(std::integral_constant<int, 3>{});
+  else if (act == VSD_ACT_RELU) finish(std::integral_constant<int, 1>{});
+  else if (act == VSD_ACT_SILU) finish(std::integral_constant<int, 2>{});
+  else finish(std::integral_constant<int, 0>{});
+}
+
 // the FAST form exists for the direct-to-LDS rings only (STAGES >= 3)
 template <int BM, int BN, int STAGES, bool ILV>
 struct FastLaunch {
@@ -1227,7 +1494,8 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.ln_s = (const float*)d->ln_s;
   p.ln_t = (const float*)d->ln_t;
   const int stages = d->pipeline;
-  if (stages != 0 && (stages < 3 || stages > 6)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3, 4, 5 or 6)", stages);
+  if (stages != 0 && (stages < 3 || stages > 7)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3, 4, 5, 6 or 7)", stages);
+  const bool halo = stages == 7;
 
   if (!p.src0 || !p.w || !p.out) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: null src/weight/out");
   if (p.M <= 0 || p.N <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: empty problem M=%d N=%d", p.M, p.N);
@@ -1259,6 +1527,14 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     case VSD_TILE_256x128: BM = 256; BN = 128; break;
     default: return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: tile %d", d->tile);
   }
+  if (halo) {
+    const bool simple_epi = !p.out2 && !p.residual2 && !p.out_t && !p.rowstat_out && !p.chanstat_out && !p.ln_part &&
+                            p.out_scale == 1.0f && (p.act & 0xff) != VSD_ACT_GEGLU && (p.act & 0xff) != VSD_ACT_QUICKGELU &&
+                            !((p.act & VSD_ACT_POST) && (p.act & 0xff) != VSD_ACT_RELU);
+    if (!p.fast || p.ksize != 3 || p.stride != 1 || p.pad != 1 || BM != 128 || p.N % 8 || p.c0 % 64 || p.c1 % 64 || !simple_epi)
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the halo-patch form (pipeline 7) needs a 3x3 stride-1 conv, Cin %% 64 == 0 per "
+                      "source, a 128-row tile and the plain epilogue");
+  }
   if (BM == 256 && (!p.fast || (stages != 3 && stages != 5)))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 256x128 tile exists for the buffer-load path (Cin %% 64 == 0, no resize) "
                     "with the 3-stage ring (pipeline 3 or 5) only");
@@ -1267,19 +1543,22 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: GEGLU needs BN=128, N %% 128 == 0, bias, no split-K");
   }
   if (p.out_t && (p.t_col0 % BN)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: t_col0 must be a multiple of BN");
-  p.tiles_m = cdiv(p.M, BM);
+  p.tiles_m = halo ? p.batch * cdiv(p.ho, 8) * cdiv(p.wo, 16) : cdiv(p.M, BM);  // halo: 8 x 16 pixel patches per image
   p.tiles_n = cdiv(p.N, BN);
-  const int KT = p.Kp / BK;
+  const int KT = halo ? p.cin / BK : p.Kp / BK;  // the halo form splits over channel blocks (each = 9 K tiles)
   if (p.split_k > KT) p.split_k = KT;
   p.kt_per_split = cdiv(KT, p.split_k);
   p.split_k = cdiv(KT, p.kt_per_split);
-  if (p.split_k == 1) p.counters = nullptr;
+  if (p.split_k == 1 || halo) p.counters = nullptr;  // (halo: always the reducer kernel)
   if (p.counters && p.tiles_m * p.tiles_n > VSD_SPLITK_MAX_TILES)
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: %d tiles exceed the split-K counter buffer", p.tiles_m * p.tiles_n);
   const int grid = p.tiles_m * p.tiles_n * p.split_k;
   {
     LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
-    if (BM == 256) {  // 2x2 waves of 128x64: 85 FLOP per byte staged through LDS (128x128: 64, 64x64: 32)
+    if (halo) {
+      if (BN == 128) hipLaunchKernelGGL((conv_halo_kernel<128>), dim3(grid), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((conv_halo_kernel<64>), dim3(grid), dim3(256), 0, s, p);
+    } else if (BM == 256) {  // 2x2 waves of 128x64: 85 FLOP per byte staged through LDS (128x128: 64, 64x64: 32)
       if (stages == 3) FastLaunch<256, 128, 3, false>::go(p, grid, s);
       else FastLaunch<256, 128, 3, true>::go(p, grid, s);
     } else if (BM == 128 && BN == 128) launch<128, 128>(p, grid, stages, s);

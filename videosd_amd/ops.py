@@ -251,6 +251,11 @@ class HipOps:
         big_ok = w.cin % 64 == 0 and (g.hi, g.wi) == (g.hs, g.ws) and g.m >= 1024
         if big_ok:
             tiles = tiles + [L.TILE_256x128]
+        plain_epi = all(kwargs.get(k) is None for k in ("out2", "residual2", "out_t", "rowstat_out", "chanstat_out", "ln_part"))
+        act = kwargs.get("act", L.ACT_NONE)
+        halo_ok = (not w.geglu and g.ksize == 3 and g.stride == 1 and (g.hi, g.wi) == (g.hs, g.ws) and w.cin % 64 == 0 and
+                   (kwargs.get("c1", 0) or 0) % 64 == 0 and w.n % 8 == 0 and plain_epi and
+                   kwargs.get("out_scale", 1.0) == 1.0 and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_SILU, L.ACT_RELU | L.ACT_POST))
         cands = []
         for t in tiles:
             bm, bn = L.TILE_DIMS[t]
@@ -259,6 +264,12 @@ class HipOps:
             blocks = -(-g.m // bm) * -(-w.n // bn)
             for pl in ((3, 5) if t == L.TILE_256x128 else (0, 3, 4, 5, 6)):
                 cands.append((t, 1, False, pl))
+            if halo_ok and bm == 128:  # LDS halo patch (pipeline 7); split-K (over channel blocks) = the two-kernel form
+                hblocks = g.batch * -(-g.ho // 8) * -(-g.wo // 16) * -(-w.n // bn)
+                for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20):
+                    if sp > w.cin // 64 or (sp > 1 and hblocks * sp > 1536):
+                        break
+                    cands.append((t, sp, False, 7))
             if w.geglu or blocks >= 384:
                 continue
             for sp in (2, 3, 4, 6, 8, 12, 16, 24):
@@ -296,11 +307,22 @@ class HipOps:
 
     # ---- tuning table persistence (the "find" results are per device generation and shape)
     def save_tuning(self, path: str):
+        """Write this process's choices INTO the table at `path` (entries of other shapes -- other batch sizes, other
+        frame sizes -- are kept)."""
         import json
+        import os
 
+        merged = {}
+        if os.path.exists(path):
+            try:
+                for k, v in json.load(open(path)).get("table", []):
+                    merged[tuple(bool(x) if isinstance(x, bool) else x for x in k)] = tuple(v)
+            except Exception:
+                merged = {}
+        merged.update(self.tile_override)
         with open(path, "w") as f:
             json.dump({"device": torch.cuda.get_device_name(self.device),
-                       "table": [[list(k), list(v)] for k, v in sorted(self.tile_override.items(), key=str)]}, f, indent=0)
+                       "table": [[list(k), list(v)] for k, v in sorted(merged.items(), key=str)]}, f, indent=0)
 
     def load_tuning(self, path: str) -> int:
         import json
