@@ -38,7 +38,8 @@ enum vsd_act { VSD_ACT_NONE = 0, VSD_ACT_RELU = 1, VSD_ACT_SILU = 2, VSD_ACT_GEG
 
 /* tile shapes of the implicit-GEMM kernel (BM x BN output tile per 256-thread workgroup) */
 enum vsd_tile { VSD_TILE_128x128 = 0, VSD_TILE_128x64 = 1, VSD_TILE_64x64 = 2, VSD_TILE_64x128 = 3,
-                VSD_TILE_256x128 = 4 /* Cin % 64 == 0, no resize, pipeline 3 or 5 only */ };
+                VSD_TILE_256x128 = 4 /* Cin % 64 == 0, no resize, pipeline 3, 5 or 7 only */,
+                VSD_TILE_256x64 = 5 /* pipeline 7 (halo patch) only */ };
 
 /* kernel families for vsd_stage_times */
 enum vsd_family {
@@ -95,8 +96,8 @@ typedef struct vsd_conv_desc {
   int32_t pipeline;       /* main-loop form: 0 = register-staged double buffer; 3 or 4 = direct-to-LDS ring with
                              that many stages (global_load_lds, counted vmcnt); 5 / 6 = the 3- / 4-stage ring with the
                              DMA issues interleaved between the MFMAs (single-basic-block iterations); 7 = halo patch:
-                             3x3 stride-1 convs only (Cin % 64 == 0 per source, tile 128x128 or 128x64, plain
-                             epilogue): the (8+2)x(16+2) input patch of a 64-channel block is
+                             3x3 stride-1 convs only (Cin % 64 == 0 per source, tile 128x128, 128x64, 256x128 or
+                             256x64, plain epilogue): the (8+2)x(16+2) input patch of a 64-channel block is
                              staged in LDS once and serves all nine taps */
   void* rowstat_out;      /* optional fp32 [M][n/64][2]: per output row, (sum, sum of squares) of the fp16 outputs over
                              each 64-column group -- the LayerNorm statistics of the NEXT layer, for free */

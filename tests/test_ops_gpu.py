@@ -642,7 +642,10 @@ def test_conv_256x128_tile(ops, pipeline, split_k):
                                                             (64, 64, 64, 0, 64, 1, 1, 1 | 256),
                                                             # patches hanging over the image edge (27x48, 7x12, 8x8 latents)
                                                             (27, 48, 128, 0, 128, 1, 1, 2), (7, 12, 128, 128, 72, 1, 2, 0),
-                                                            (8, 8, 1280, 0, 128, 0, 5, 0)])
+                                                            (8, 8, 1280, 0, 128, 0, 5, 0),
+                                                            # 16x16 patches, 8 waves (tiles 256x128 = 4, 256x64 = 5)
+                                                            (32, 32, 128, 0, 192, 4, 1, 2), (16, 48, 64, 64, 200, 5, 1, 0),
+                                                            (27, 48, 128, 0, 128, 5, 2, 1), (64, 64, 64, 0, 64, 5, 1, 1 | 256)])
 def test_conv3x3_halo_patch(ops, h, w, c0, c1, cout, tile, split, act):
     """pipeline 7: the (8+2)x(16+2) input patch of each 64-channel block staged in LDS once for all nine taps; image
     borders (zero padding) at every patch edge, concat sources, split-K over channel blocks, fused epilogue."""

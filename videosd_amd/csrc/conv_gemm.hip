@@ -1140,15 +1140,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
 // blocks writes fp32 slabs for splitk_reduce_kernel.  Epilogue: bias + time vector, activation, one residual.
 // Eligible: ksize 3, stride 1, pad 1, no resize, Cin % 64 == 0 (each concat source); patches hanging over the right /
 // bottom edge compute but do not store their outside pixels.
-template <int BN>
-__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
-  constexpr int BM = 128, PW = 16, PH = 8, HW_ = PW + 2;  // halo row length 18
-  constexpr int HROWS = 192;                               // (PH+2)*(PW+2) = 180 rows, padded to 24 wave-instructions
-  constexpr int AI = 6, BR = BN / 32;
+// WMN = waves along M (2: 128-pixel 8x16 patch, 256 threads; 4: 256-pixel 16x16 patch, 512 threads -- the weight tile
+// is then shared by twice the pixels: half the weight traffic per FLOP, two waves per SIMD at one workgroup per CU).
+// NSB = slots of the weight-tile ring (lead = NSB - 1 tiles).
+template <int BN, int WMN, int NSB>
+__global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p) {
+  constexpr int NW = 2 * WMN, NT = 64 * NW;
+  constexpr int BM = 64 * WMN, PW = 16, PH = 4 * WMN, HW_ = PW + 2;  // halo row length 18
+  constexpr int HUSED = (PH + 2) * HW_;                                // 180 / 324 halo rows
+  constexpr int HROWS = (HUSED + 8 * NW - 1) / (8 * NW) * (8 * NW);    // padded to whole wave-instructions per wave: 192 / 384
+  constexpr int AI = HROWS / (8 * NW), BR = BN / (8 * NW);
+  static_assert(BR >= 1, "tile too narrow for this many waves");
   constexpr int TM = 64, TN = BN / 2, FM = TM / 16, FN = TN / 16;
   constexpr int BNP = BN + 4;
   constexpr int A_HALFS = HROWS * BK, B_HALFS = BN * BK;
-  constexpr int STAGE_BYTES = (2 * A_HALFS + 3 * B_HALFS) * 2;
+  constexpr int STAGE_BYTES = (2 * A_HALFS + NSB * B_HALFS) * 2;
   constexpr int EPI_BYTES = BM * BNP * 4;
   constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
@@ -1199,17 +1205,17 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
   int apx[AI], alc[AI];
 #pragma unroll
   for (int q = 0; q < AI; ++q) {
-    const int row = 8 * (wave + 4 * q) + (lane >> 3);
+    const int row = 8 * (wave + NW * q) + (lane >> 3);
     const int hy = row / HW_, hx = row - hy * HW_;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-    const bool in = row < (PH + 2) * HW_ && (unsigned)y < (unsigned)p.hi && (unsigned)x < (unsigned)p.wi;
+    const bool in = row < HUSED && (unsigned)y < (unsigned)p.hi && (unsigned)x < (unsigned)p.wi;
     apx[q] = in ? pix0 + y * p.ws + x : -1;
     alc[q] = (((lane & 7) ^ (row & 7)) << 4);
   }
   int bvoff[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
-    const int r = 8 * wave + 32 * i + (lane >> 3);
+    const int r = 8 * (wave + NW * i) + (lane >> 3);
     const int n = n0 + r;
     bvoff[i] = n < p.N ? n * p.Kp * 2 + (((lane & 7) ^ (r & 7)) << 4) : OOB;
   }
@@ -1227,8 +1233,29 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
     half_t* dst_ = Abuf + (BUF_) * A_HALFS;                                                             \
     _Pragma("unroll") for (int q = 0; q < AI; ++q) {                                                    \
       const int vo_ = apx[q] >= 0 ? __mul24(apx[q], cs2_) + alc[q] : OOB;                               \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)(dst_ + 8 * (wave_s + 4 * q) * BK), 16, vo_, soff_, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)(dst_ + 8 * (wave_s + NW * q) * BK), 16, vo_, soff_, 0, 0); \
     }                                                                                                   \
+  }
+/* one wave-instruction (8 halo rows per wave) of the patch of channel block CB_: piece Q_ of AI */                     \
+/* (vmcnt retires in order: a whole patch issued at once would have to land within the two tiles of lead the weight   \
+   ring has; one piece per tap gives every piece that lead and the patch six taps of slack) */
+#define HALO_ISSUE_A_PIECE(CB_, BUF_, Q_)                                                               \
+  {                                                                                                     \
+    const int ch_ = (CB_) * BK;                                                                         \
+    const bool second_ = ch_ >= p.c0;                                                                   \
+    const int cs2_ = (second_ ? p.c1 : p.c0) * 2;                                                       \
+    const int soff_ = (second_ ? ch_ - p.c0 : ch_) * 2;                                                 \
+    const __amdgpu_buffer_rsrc_t rs_ =                                                                  \
+        __builtin_amdgcn_make_buffer_rsrc((void*)(second_ ? p.src1 : p.src0), 0, second_ ? anr1 : anr0, 0x00020000); \
+    half_t* dst_ = Abuf + (BUF_) * A_HALFS;                                                             \
+    int apx_ = apx[0], alc_ = alc[0];                                                                   \
+    _Pragma("unroll") for (int q = 1; q < AI; ++q)                                                      \
+      if (q == (Q_)) {                                                                                  \
+        apx_ = apx[q];                                                                                  \
+        alc_ = alc[q];                                                                                  \
+      }                                                                                                 \
+    const int vo_ = apx_ >= 0 ? __mul24(apx_, cs2_) + alc_ : OOB;                                       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)(dst_ + 8 * (wave_s + NW * (Q_)) * BK), 16, vo_, soff_, 0, 0); \
   }
 #define HALO_ISSUE_B(TAP_, CB_, SLOT_)                                                                  \
   {                                                                                                     \
@@ -1237,10 +1264,14 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
     half_t* dst_ = Bbuf + (SLOT_) * B_HALFS;                                                            \
     _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                    \
       const int bv_ = bvoff[i] + 0;                                                                     \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb_, (lds_ptr_t)(dst_ + (8 * wave_s + 32 * i) * BK), 16, bv_, soff_, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb_, (lds_ptr_t)(dst_ + 8 * (wave_s + NW * i) * BK), 16, bv_, soff_, 0, 0); \
     }                                                                                                   \
   }
 
+#ifdef VSD_CONV_PROBE
+  long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long plast = __builtin_readcyclecounter();
+#endif
   f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -1254,63 +1285,80 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
 
   if (T > 0) {
     HALO_ISSUE_A(cb_begin, 0)
-    HALO_ISSUE_B(0, cb_begin, 0)
-    if (T > 1) HALO_ISSUE_B(1, cb_begin, 1)
+#pragma unroll
+    for (int st = 0; st < NSB - 1; ++st)
+      if (st < T) HALO_ISSUE_B(st % 9, cb_begin + st / 9, st)
   }
-  int tap = 0, cb = cb_begin, slot = 0;     // of iteration t
-  int tap2 = 2 % 9, cb2 = cb_begin + 2 / 9;  // of the tile fetched in iteration t (t + 2)
-  bool prev_a = false;                       // iteration t-1 issued an A patch
+  constexpr int LEAD = NSB - 1;
+  int tap = 0, cb = cb_begin, slot = 0;                 // of iteration t
+  int tap2 = LEAD % 9, cb2 = cb_begin + LEAD / 9;        // of the tile fetched in iteration t (t + LEAD)
+  // An iteration issues [weight tile t+LEAD, then one piece of the next patch].  vmcnt retires in order, so "tile t has
+  // landed" = all but the operations issued after it are done: the pieces of iterations t-LEAD .. t-1 and the weight
+  // tiles t+1 .. t+LEAD-1.  (Counted waits need immediates: the steady-state values are exact, the tail over-waits.)
+  int hist = 0;  // bit i: iteration t-1-i issued a patch piece
+  CPROBE(0)
   for (int t = 0; t < T; ++t) {
-    // tile t has landed once everything but the operations issued after it (iteration t-1's) is done
-    const bool prev_b = t + 1 < T;
-    if (prev_a && prev_b) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BR) : "memory");
-    else if (prev_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI) : "memory");
-    else if (prev_b) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BR) : "memory");
+    const int later_b = min(LEAD - 1, T - 1 - t) * BR;
+    const int nwait = later_b + __builtin_popcount(hist & ((1 << LEAD) - 1));
+    if (nwait >= (LEAD - 1) * BR + LEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LEAD - 1) * BR + LEAD) : "memory");
+    else if (nwait >= (LEAD - 1) * BR + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LEAD - 1) * BR + 1) : "memory");
+    else if (nwait >= (LEAD - 1) * BR) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LEAD - 1) * BR) : "memory");
+    else if (nwait >= BR) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BR) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CPROBE(1)
     __builtin_amdgcn_s_barrier();
-    prev_a = false;
-    if (tap == 0 && cb + 1 < cb_end) {  // next channel block's patch: nine tiles of lead
-      HALO_ISSUE_A(cb + 1, (cb + 1 - cb_begin) & 1)
-      prev_a = true;
-    }
-    if (t + 2 < T) {
-      int ns = slot + 2;
-      if (ns >= 3) ns -= 3;
+    CPROBE(2)
+    if (t + LEAD < T) {
+      int ns = slot + LEAD;
+      if (ns >= NSB) ns -= NSB;
       HALO_ISSUE_B(tap2, cb2, ns)
     }
+    hist <<= 1;
+    if (tap < AI && cb + 1 < cb_end) {  // next channel block's patch, one piece per tap (taps 0..AI-1)
+      HALO_ISSUE_A_PIECE(cb + 1, (cb + 1 - cb_begin) & 1, tap)
+      hist |= 1;
+    }
+    CPROBE(3)
     const half_t* a = Abuf + ((cb - cb_begin) & 1) * A_HALFS;
     const half_t* b = Bbuf + slot * B_HALFS;
     const int ky = tap / 3, kx = tap - ky * 3;
     const int toff = ky * HW_ + kx;
+    // all fragment reads of the tile first (both k-steps), then the MFMAs: one LDS latency per tile instead of two
+    half8 af[2][FM], bf[2][FN];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8 af[FM], bf[FN];
+    for (int i = 0; i < FM; ++i) {
+      const int hr = hr0[i] + toff;
+      const half_t* row = a + hr * BK;
+      const int sw = hr & 7;
+      af[0][i] = *reinterpret_cast<const half8*>(row + ((fq ^ sw) << 3));
+      af[1][i] = *reinterpret_cast<const half8*>(row + (((4 + fq) ^ sw) << 3));
+    }
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int hr = hr0[i] + toff;
-        af[i] = *reinterpret_cast<const half8*>(a + hr * BK + (((ks * 4 + fq) ^ (hr & 7)) << 3));
-      }
+    for (int j = 0; j < FN; ++j) {
+      const int r = wn * TN + j * 16 + fr;
+      const half_t* row = b + r * BK;
+      bf[0][j] = *reinterpret_cast<const half8*>(row + ((fq ^ (r & 7)) << 3));
+      bf[1][j] = *reinterpret_cast<const half8*>(row + (((4 + fq) ^ (r & 7)) << 3));
+    }
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int r = wn * TN + j * 16 + fr;
-        bf[j] = *reinterpret_cast<const half8*>(b + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
-      }
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-    if (++slot == 3) slot = 0;
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+    CPROBE(4)
+    if (++slot == NSB) slot = 0;
     if (++tap == 9) { tap = 0; ++cb; }
     if (++tap2 == 9) { tap2 = 0; ++cb2; }
   }
 #undef HALO_ISSUE_A
+#undef HALO_ISSUE_A_PIECE
 #undef HALO_ISSUE_B
   __syncthreads();  // every wave is done reading the tiles before the epilogue reuses the LDS
 
   // ---- epilogue.  Residual and bias + time vector are loaded before the accumulator transpose (and any store).
   constexpr int CH = BN / 8;
-  constexpr int NIT = BM * CH / 256;
+  constexpr int NIT = BM * CH / NT;
   half8 rpre[NIT];
   float brv[8];
   const int pre_n = n0 + (tid % CH) * 8;
@@ -1331,7 +1379,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
     if (p.residual) {
 #pragma unroll
       for (int j = 0; j < NIT; ++j) {
-        const int q = tid + j * 256;
+        const int q = tid + j * NT;
         const int r = q / CH;
         rpre[j] = *reinterpret_cast<const half8*>(p.residual + (ncol_ok && row_ok(r) ? (size_t)row_m(r) * p.ldr + pre_n : 0));
       }
@@ -1348,11 +1396,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
       for (int r = 0; r < 4; ++r) Cs[(row + r) * BNP + col] = acc[i][j][r];
     }
   __syncthreads();
+  CPROBE(5)
   if (p.split_k > 1) {  // fp32 slab of this split; splitk_reduce_kernel applies the epilogue
     float* slab = p.ws_partial + (size_t)split * p.M * p.N;
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
-      const int q = tid + j * 256;
+      const int q = tid + j * NT;
       const int r = q / CH, c8 = (q - r * CH) * 8;
       const int n = n0 + c8;
       if (n + 8 <= p.N && row_ok(r)) {
@@ -1369,7 +1418,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
     constexpr int ACT = decltype(act_tag)::value;  // 0 none, 1 relu, 2 silu, 3 relu after the residual
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
-      const int q = tid + j * 256;
+      const int q = tid + j * NT;
       const int r = q / CH, c8 = (q - r * CH) * 8;
       const int n = n0 + c8;
       if (n + 8 <= p.N && row_ok(r)) {
@@ -1394,6 +1443,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvParams p) {
   else if (act == VSD_ACT_RELU) finish(std::integral_constant<int, 1>{});
   else if (act == VSD_ACT_SILU) finish(std::integral_constant<int, 2>{});
   else finish(std::integral_constant<int, 0>{});
+  CPROBE(6)
+  CPROBE_OUT()
 }
 
 // the FAST form exists for the direct-to-LDS rings only (STAGES >= 3)
@@ -1525,17 +1576,18 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     case VSD_TILE_64x64: BM = 64; BN = 64; break;
     case VSD_TILE_64x128: BM = 64; BN = 128; break;
     case VSD_TILE_256x128: BM = 256; BN = 128; break;
+    case VSD_TILE_256x64: BM = 256; BN = 64; break;
     default: return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: tile %d", d->tile);
   }
   if (halo) {
     const bool simple_epi = !p.out2 && !p.residual2 && !p.out_t && !p.rowstat_out && !p.chanstat_out && !p.ln_part &&
                             p.out_scale == 1.0f && (p.act & 0xff) != VSD_ACT_GEGLU && (p.act & 0xff) != VSD_ACT_QUICKGELU &&
                             !((p.act & VSD_ACT_POST) && (p.act & 0xff) != VSD_ACT_RELU);
-    if (!p.fast || p.ksize != 3 || p.stride != 1 || p.pad != 1 || BM != 128 || p.N % 8 || p.c0 % 64 || p.c1 % 64 || !simple_epi)
+    if (!p.fast || p.ksize != 3 || p.stride != 1 || p.pad != 1 || BM < 128 || p.N % 8 || p.c0 % 64 || p.c1 % 64 || !simple_epi)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the halo-patch form (pipeline 7) needs a 3x3 stride-1 conv, Cin %% 64 == 0 per "
-                      "source, a 128-row tile and the plain epilogue");
+                      "source, a 128- or 256-row tile and the plain epilogue");
   }
-  if (BM == 256 && (!p.fast || (stages != 3 && stages != 5)))
+  if (!halo && BM == 256 && (BN != 128 || !p.fast || (stages != 3 && stages != 5)))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 256x128 tile exists for the buffer-load path (Cin %% 64 == 0, no resize) "
                     "with the 3-stage ring (pipeline 3 or 5) only");
   if ((p.act & 0xff) == VSD_ACT_GEGLU) {
@@ -1543,7 +1595,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: GEGLU needs BN=128, N %% 128 == 0, bias, no split-K");
   }
   if (p.out_t && (p.t_col0 % BN)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: t_col0 must be a multiple of BN");
-  p.tiles_m = halo ? p.batch * cdiv(p.ho, 8) * cdiv(p.wo, 16) : cdiv(p.M, BM);  // halo: 8 x 16 pixel patches per image
+  p.tiles_m = halo ? p.batch * cdiv(p.ho, BM / 16) * cdiv(p.wo, 16) : cdiv(p.M, BM);  // halo: 8x16 / 16x16 pixel patches
   p.tiles_n = cdiv(p.N, BN);
   const int KT = halo ? p.cin / BK : p.Kp / BK;  // the halo form splits over channel blocks (each = 9 K tiles)
   if (p.split_k > KT) p.split_k = KT;
@@ -1556,8 +1608,11 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   {
     LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
     if (halo) {
-      if (BN == 128) hipLaunchKernelGGL((conv_halo_kernel<128>), dim3(grid), dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((conv_halo_kernel<64>), dim3(grid), dim3(256), 0, s, p);
+      // (a 4-slot weight ring measured the same as 3 slots: the wait per tile is fill throughput, not lead)
+      if (BM == 256 && BN == 128) hipLaunchKernelGGL((conv_halo_kernel<128, 4, 3>), dim3(grid), dim3(512), 0, s, p);
+      else if (BM == 256) hipLaunchKernelGGL((conv_halo_kernel<64, 4, 3>), dim3(grid), dim3(512), 0, s, p);
+      else if (BN == 128) hipLaunchKernelGGL((conv_halo_kernel<128, 2, 3>), dim3(grid), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((conv_halo_kernel<64, 2, 3>), dim3(grid), dim3(256), 0, s, p);
     } else if (BM == 256) {  // 2x2 waves of 128x64: 85 FLOP per byte staged through LDS (128x128: 64, 64x64: 32)
       if (stages == 3) FastLaunch<256, 128, 3, false>::go(p, grid, s);
       else FastLaunch<256, 128, 3, true>::go(p, grid, s);

@@ -9,9 +9,9 @@ LIB_PATH = os.path.join(HERE, "libvsd.so")
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_QUICKGELU = range(5)
 ACT_POST = 256
 SPLITK_MAX_TILES = 16384
-TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128, TILE_256x128 = range(5)
+TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128, TILE_256x128, TILE_256x64 = range(6)
 TILE_DIMS = {TILE_128x128: (128, 128), TILE_128x64: (128, 64), TILE_64x64: (64, 64), TILE_64x128: (64, 128),
-             TILE_256x128: (256, 128)}
+             TILE_256x128: (256, 128), TILE_256x64: (256, 64)}
 FAMILIES = ["conv_gemm", "splitk_reduce", "groupnorm", "layernorm", "attention", "elementwise"]
 
 

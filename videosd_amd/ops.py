@@ -279,6 +279,14 @@ class HipOps:
                     if kwargs.get("rowstat_out") is None and kwargs.get("chanstat_out") is None:
                         cands.append((t, sp, False, pl))
                     cands.append((t, sp, True, pl))
+        if halo_ok:  # 16x16 patches (8 waves): half the weight traffic of the 8x16 patch
+            for t in (L.TILE_256x128, L.TILE_256x64):
+                bn = L.TILE_DIMS[t][1]
+                hblocks = g.batch * -(-g.ho // 16) * -(-g.wo // 16) * -(-w.n // bn)
+                for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20):
+                    if sp > w.cin // 64 or (sp > 1 and hblocks * sp > 1536):
+                        break
+                    cands.append((t, sp, False, 7))
         kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline")}
         table = []
         saved = self.tile_override.pop(key, None)
