@@ -4,7 +4,7 @@ import collections, csv, json, sys
 
 trace, opsf = sys.argv[1], sys.argv[2]
 ops = json.load(open(opsf))
-ours = ("conv_gemm_kernel", "splitk_reduce", "gn_stats", "gn_apply", "gn_fused", "layernorm_kernel", "attention_kernel",
+ours = ("conv_gemm_kernel", "conv_halo_kernel", "splitk_reduce", "gn_stats", "gn_apply", "gn_fused", "layernorm_kernel", "attention_kernel",
         "preprocess_rgb", "sobel_max", "sobel_apply", "add_noise", "lcm_step", "postprocess")
 rows = [r for r in csv.DictReader(open(trace)) if any(o in r["Kernel_Name"] for o in ours)]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -28,7 +28,7 @@ for m in ops:
     busy += sum(dur)
     if m["op"] == "conv":
         key = ("conv", m["M"], m["N"], m["K"], m["ks"], m["tile"], m["split"])
-        assert "conv_gemm" in ks[0]["Kernel_Name"], (m, ks[0]["Kernel_Name"][:60])
+        assert "conv_gemm" in ks[0]["Kernel_Name"] or "conv_halo" in ks[0]["Kernel_Name"], (m, ks[0]["Kernel_Name"][:60])
     elif m["op"] == "groupnorm":
         key = ("gn", m["hw"], m["C"])
     elif m["op"] == "layernorm":

@@ -8,7 +8,7 @@ import csv, json, sys
 
 
 def last_frame(path, counter, n_conv):
-    rows = [r for r in csv.DictReader(open(path)) if r.get("Counter_Name") == counter and "conv_gemm_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if r.get("Counter_Name") == counter and ("conv_gemm_kernel" in r["Kernel_Name"] or "conv_halo_kernel" in r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     per = {}
     for r in rows:  # several rows per dispatch (one per counter instance) are summed

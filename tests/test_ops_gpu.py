@@ -672,6 +672,15 @@ def test_conv3x3_halo_patch(ops, h, w, c0, c1, cout, tile, split, act):
     check(got, ref, f"halo conv {h}x{w} {cin}->{cout} tile={tile} split={split}")
 
 
+@pytest.mark.parametrize("hs,ws,up,tile,split", [(8, 8, (16, 16), 1, 1), (14, 24, (27, 48), 5, 2), (16, 16, (32, 32), 0, 1)])
+def test_conv3x3_halo_patch_with_folded_upsample(ops, hs, ws, up, tile, split):
+    cin, cout = 128, 64
+    x = rnd(1, cin, hs, ws, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
+    got, ref = run_conv(ops, [x], hs, ws, wt, rnd(cout, seed=3, scale=0.1), ksize=3, up_to=up, tile=tile, split_k=split, pipeline=7)
+    check(got, ref, f"halo conv with upsample {hs}x{ws}->{up}")
+
+
 def test_conv3x3_halo_patch_batched(ops):
     from videosd_amd.ops import Geom
     from videosd_amd.packing import pack_conv

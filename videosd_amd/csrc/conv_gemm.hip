@@ -34,6 +34,7 @@ struct ConvParams {
   int rshift;
   int generic;  // cin % 64 != 0: per-chunk tap computation
   int fast;     // buffer-load address path usable: !generic, no resize, every operand < 2 GB
+  int halo_ok;  // the same without the "no resize" condition (the halo kernel folds the nearest resize into its patch fetch)
   const half_t* w;
   int M, N, K, Kp;
   const half_t* bias;
@@ -1138,8 +1139,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
 // (3-slot ring, counted vmcnt).  Zero padding = out-of-range buffer offsets, as in the FAST path.
 // K order inside a workgroup: channel block outer, tap inner (weights stay [N][(ky,kx,c)]).  Split-K over channel
 // blocks writes fp32 slabs for splitk_reduce_kernel.  Epilogue: bias + time vector, activation, one residual.
-// Eligible: ksize 3, stride 1, pad 1, no resize, Cin % 64 == 0 (each concat source); patches hanging over the right /
-// bottom edge compute but do not store their outside pixels.
+// Eligible: ksize 3, stride 1, pad 1, Cin % 64 == 0 (each concat source), with or without the folded nearest resize
+// (Upsample2D + conv: the patch fetch reads each source pixel into the halo rows that show it); patches hanging over the
+// right / bottom edge compute but do not store their outside pixels.
 // WMN = waves along M (2: 128-pixel 8x16 patch, 256 threads; 4: 256-pixel 16x16 patch, 512 threads -- the weight tile
 // is then shared by twice the pixels: half the weight traffic per FLOP, two waves per SIMD at one workgroup per CU).
 // NSB = slots of the weight-tile ring (lead = NSB - 1 tiles).
@@ -1191,9 +1193,10 @@ __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p
   const int ppr = (p.wo + PW - 1) / PW, tpi = ((p.ho + PH - 1) / PH) * ppr;  // patches may hang over the right / bottom edge
   const int img = tile_m / tpi, trem = tile_m - img * tpi;
   const int y0 = (trem / ppr) * PH, x0 = (trem % ppr) * PW;
-  const int pix0 = img * p.img_in;  // first pixel of the image (hs == ho, ws == wo)
+  const int pix0 = img * p.img_in;   // first SOURCE pixel of the image (hs x ws; nearest-resized to hi x wi = ho x wo on the fly)
+  const int opix0 = img * p.hw_out;  // first output row of the image
   auto row_ok = [&](int r) { return y0 + (r >> 4) < p.ho && x0 + (r & 15) < p.wo; };
-  auto row_m = [&](int r) { return pix0 + (y0 + (r >> 4)) * p.wo + x0 + (r & 15); };
+  auto row_m = [&](int r) { return opix0 + (y0 + (r >> 4)) * p.wo + x0 + (r & 15); };
 
   // channel blocks of this split
   const int ncb_all = p.cin / BK;
@@ -1209,7 +1212,9 @@ __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p
     const int hy = row / HW_, hx = row - hy * HW_;
     const int y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool in = row < HUSED && (unsigned)y < (unsigned)p.hi && (unsigned)x < (unsigned)p.wi;
-    apx[q] = in ? pix0 + y * p.ws + x : -1;
+    // nearest resize folded in: several halo rows may show the same source pixel (fixed-point floor(y * hs / hi))
+    const int sy = (int)(((unsigned)y * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)x * p.rmul_x) >> p.rshift);
+    apx[q] = in ? pix0 + sy * p.ws + sx : -1;
     alc[q] = (((lane & 7) ^ (row & 7)) << 4);
   }
   int bvoff[BR];
@@ -1508,6 +1513,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   {
     const size_t a_pix = (size_t)(d->batch < 1 ? 1 : d->batch) * d->hs * d->ws + (size_t)d->pad * d->ws + d->pad;
     const size_t cmax = (size_t)(d->c0 > d->c1 ? d->c0 : d->c1);
+    p.halo_ok = !p.generic && a_pix < (1u << 24) && a_pix * cmax * 2 < 0x7fffffffull && (size_t)d->n * d->kp * 2 < 0x7fffffffull;
     p.fast = !p.generic && !p.resize && a_pix < (1u << 24) && a_pix * cmax * 2 < 0x7fffffffull && (size_t)d->n * d->kp * 2 < 0x7fffffffull &&
              d->ksize * d->ksize <= 32 && !getenv("VSD_CONV_NO_FAST");
   }
@@ -1583,7 +1589,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     const bool simple_epi = !p.out2 && !p.residual2 && !p.out_t && !p.rowstat_out && !p.chanstat_out && !p.ln_part &&
                             p.out_scale == 1.0f && (p.act & 0xff) != VSD_ACT_GEGLU && (p.act & 0xff) != VSD_ACT_QUICKGELU &&
                             !((p.act & VSD_ACT_POST) && (p.act & 0xff) != VSD_ACT_RELU);
-    if (!p.fast || p.ksize != 3 || p.stride != 1 || p.pad != 1 || BM < 128 || p.N % 8 || p.c0 % 64 || p.c1 % 64 || !simple_epi)
+    if (!p.halo_ok || p.ksize != 3 || p.stride != 1 || p.pad != 1 || BM < 128 || p.N % 8 || p.c0 % 64 || p.c1 % 64 || !simple_epi)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the halo-patch form (pipeline 7) needs a 3x3 stride-1 conv, Cin %% 64 == 0 per "
                       "source, a 128- or 256-row tile and the plain epilogue");
   }

@@ -253,7 +253,7 @@ class HipOps:
             tiles = tiles + [L.TILE_256x128]
         plain_epi = all(kwargs.get(k) is None for k in ("out2", "residual2", "out_t", "rowstat_out", "chanstat_out", "ln_part"))
         act = kwargs.get("act", L.ACT_NONE)
-        halo_ok = (not w.geglu and g.ksize == 3 and g.stride == 1 and (g.hi, g.wi) == (g.hs, g.ws) and w.cin % 64 == 0 and
+        halo_ok = (not w.geglu and g.ksize == 3 and g.stride == 1 and w.cin % 64 == 0 and
                    (kwargs.get("c1", 0) or 0) % 64 == 0 and w.n % 8 == 0 and plain_epi and
                    kwargs.get("out_scale", 1.0) == 1.0 and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_SILU, L.ACT_RELU | L.ACT_POST))
         cands = []
