@@ -98,7 +98,8 @@ typedef struct vsd_conv_desc {
                              DMA issues interleaved between the MFMAs (single-basic-block iterations); 7 = halo patch:
                              3x3 stride-1 convs only (Cin % 64 == 0 per source, tile 128x128, 128x64, 256x128 or
                              256x64, plain epilogue): the (8+2)x(16+2) input patch of a 64-channel block is
-                             staged in LDS once and serves all nine taps */
+                             staged in LDS once and serves all nine taps; 8 = 8-stage direct-to-LDS ring (64x64 tile, Cin %
+                             64 == 0, no resize): 112 KB in flight per workgroup for the weight-streaming layers */
   void* rowstat_out;      /* optional fp32 [M][n/64][2]: per output row, (sum, sum of squares) of the fp16 outputs over
                              each 64-column group -- the LayerNorm statistics of the NEXT layer, for free */
   void* chanstat_out;     /* optional fp32 [n][2]: per output CHANNEL, (sum, sum of squares) of the fp16 outputs over all M

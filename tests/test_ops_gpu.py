@@ -696,3 +696,23 @@ def test_conv3x3_halo_patch_batched(ops):
     ops.synchronize()
     ref = F.silu(F.conv2d(xs.float(), wt.float(), bias.float(), padding=1)).permute(0, 2, 3, 1).reshape(g.m, cout)
     check(out, ref, "batched halo conv")
+
+
+@pytest.mark.parametrize("split_k,inkernel", [(1, True), (3, True), (3, False)])
+def test_conv_deep_ring_pipeline8(ops, split_k, inkernel):
+    """pipeline 8: 8-stage direct-to-LDS ring (64x64 tile) for the tiny-M / deep-K weight-streaming layers."""
+    h, w, cin, cout = 8, 8, 1280, 200  # K = 11520 (180 tiles), M = 64
+    x = rnd(1, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
+    res = rnd(h * w, cout, seed=5)
+    ops.inkernel_splitk = inkernel
+    got, ref = run_conv(ops, [x], h, w, wt, rnd(cout, seed=3, scale=0.1), ksize=3, tile=2, split_k=split_k, pipeline=8, residual=res, act=2)
+    base, _ = run_conv(ops, [x], h, w, wt, rnd(cout, seed=3, scale=0.1), ksize=3, tile=2, split_k=split_k, pipeline=3, residual=res, act=2)
+    ops.inkernel_splitk = True
+    check(got, ref, f"deep ring split={split_k}")
+    assert torch.equal(got, base)  # same tile order, same summation order as the 3-stage ring
+    # short K (fewer tiles than stages)
+    x2 = rnd(1, 128, 5, 7, seed=7)
+    w2 = rnd(72, 128, 3, 3, seed=8, scale=(128 * 9) ** -0.5)
+    got, ref = run_conv(ops, [x2], 5, 7, w2, None, ksize=3, tile=2, split_k=1, pipeline=8)
+    check(got, ref, "deep ring short K")

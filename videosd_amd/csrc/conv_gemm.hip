@@ -604,7 +604,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       for (int t = 0; t < nt; ++t) {
         // tile t has landed once all but the younger tiles' loads are done; then everyone's has (barrier)
         const int rem = min(STAGES - 2, nt - 1 - t);
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        if (STAGES > 4 && rem >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+        else if (STAGES > 4 && rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");  // (tail: over-waits a little)
+        else if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CPROBE(1)
@@ -1551,7 +1553,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.ln_s = (const float*)d->ln_s;
   p.ln_t = (const float*)d->ln_t;
   const int stages = d->pipeline;
-  if (stages != 0 && (stages < 3 || stages > 7)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3, 4, 5, 6 or 7)", stages);
+  if (stages != 0 && (stages < 3 || stages > 8)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..8)", stages);
   const bool halo = stages == 7;
 
   if (!p.src0 || !p.w || !p.out) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: null src/weight/out");
@@ -1593,6 +1595,8 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the halo-patch form (pipeline 7) needs a 3x3 stride-1 conv, Cin %% 64 == 0 per "
                       "source, a 128- or 256-row tile and the plain epilogue");
   }
+  if (stages == 8 && (d->tile != VSD_TILE_64x64 || !p.fast))
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 8-stage ring (pipeline 8) exists for the 64x64 tile on the buffer-load path only");
   if (!halo && BM == 256 && (BN != 128 || !p.fast || (stages != 3 && stages != 5)))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 256x128 tile exists for the buffer-load path (Cin %% 64 == 0, no resize) "
                     "with the 3-stage ring (pipeline 3 or 5) only");
@@ -1619,6 +1623,8 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
       else if (BM == 256) hipLaunchKernelGGL((conv_halo_kernel<64, 4, 3>), dim3(grid), dim3(512), 0, s, p);
       else if (BN == 128) hipLaunchKernelGGL((conv_halo_kernel<128, 2, 3>), dim3(grid), dim3(256), 0, s, p);
       else hipLaunchKernelGGL((conv_halo_kernel<64, 2, 3>), dim3(grid), dim3(256), 0, s, p);
+    } else if (stages == 8) {  // weight-streaming layers (tiny M, deep K): 7 tiles of 16 KB in flight per workgroup
+      FastLaunch<64, 64, 8, false>::go(p, grid, s);
     } else if (BM == 256) {  // 2x2 waves of 128x64: 85 FLOP per byte staged through LDS (128x128: 64, 64x64: 32)
       if (stages == 3) FastLaunch<256, 128, 3, false>::go(p, grid, s);
       else FastLaunch<256, 128, 3, true>::go(p, grid, s);

@@ -251,6 +251,7 @@ class HipOps:
         big_ok = w.cin % 64 == 0 and (g.hi, g.wi) == (g.hs, g.ws) and g.m >= 1024
         if big_ok:
             tiles = tiles + [L.TILE_256x128]
+
         plain_epi = all(kwargs.get(k) is None for k in ("out2", "residual2", "out_t", "rowstat_out", "chanstat_out", "ln_part"))
         act = kwargs.get("act", L.ACT_NONE)
         halo_ok = (not w.geglu and g.ksize == 3 and g.stride == 1 and w.cin % 64 == 0 and
@@ -264,6 +265,8 @@ class HipOps:
             blocks = -(-g.m // bm) * -(-w.n // bn)
             for pl in ((3, 5) if t == L.TILE_256x128 else (0, 3, 4, 5, 6)):
                 cands.append((t, 1, False, pl))
+            # (pipeline 8, the 8-stage ring, is not a candidate: measured 25.1 vs 23.9 us on 64 x 1280 x 11520 -- more
+            #  tiles in flight do not help, the per-wave LDS-DMA issue rate is what limits these layers)
             if halo_ok and bm == 128:  # LDS halo patch (pipeline 7); split-K (over channel blocks) = the two-kernel form
                 hblocks = g.batch * -(-g.ho // 8) * -(-g.wo // 16) * -(-w.n // bn)
                 for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20):
