@@ -8,15 +8,18 @@
 //   MFMA (k index = key, permuted inside each 16-key step exactly as the accumulator rows are), so P
 //   never touches LDS.  V arrives pre-transposed ([d][keys], written by the QKV GEMM epilogue); its LDS image
 //   stores the keys of every 16-key step in that same permuted order so that a fragment is ONE ds_read_b128.
-// What bounds it at head_dim 40..80: per 32x64 score block a wave spends 14-18 MFMAs (~0.5k cycles) but also ~150
-// VALU issues (max, sub, exp2, cvt; ~0.6k cycles) and reads the whole K and V^T tile from LDS (22 KB; the CU's four
-// SIMDs share one 128 B/clk LDS pipe).  Hence:
-//   QB = 2   every K / V^T fragment read from LDS feeds two query blocks (halves the LDS bytes per FLOP);
+// What bounds it at head_dim 40..80 (in-kernel cycle probe, scripts/attn_probe.cpp): per 32x64 score block a wave spends
+// 14-18 MFMAs (~0.45k cycles) but ~150 VALU issues for the softmax (max, sub, exp2, cvt: ~0.8k cycles with the MFMA
+// drain), plus ~0.3k each for issuing the next tile's fetch and parking it in LDS.  Hence:
 //   KSP = 2  a workgroup holds two wave groups that take alternate key tiles of the SAME queries and merge their
 //            (max, sum, O) at the end: two waves per SIMD even when the grid is only one workgroup per CU, so one
-//            wave's softmax VALU runs under the other's MFMAs / LDS waits;
+//            wave's softmax VALU runs under the other's MFMAs / LDS waits (4096 keys, d = 40: 87 -> 55 us);
+//   tiles are fetched two ahead through two register sets (one ahead exposed an L2-miss latency per tile), from
+//   wave-uniform tile bases, and never through a select on the loaded value;
 //   the row sums come out of the PV MFMA (a row of ones in the V^T padding) when head_dim leaves a padded row;
-//   the O rescale is skipped when no query of the wave raised its running maximum.
+//   the O rescale is skipped when no query of the wave raised its running maximum;
+//   QB = 2 (two query blocks per wave sharing every K / V^T fragment read) is implemented but not instantiated: it
+//   measured 1.3x slower everywhere (> 256 VGPRs -> one wave per SIMD; the kernel is issue-bound, not LDS-bound).
 // head_dim d (multiple of 8, <= 160) is zero-padded to NQK*16 for QK^T and NPV*32 for PV.
 // Algorithmic FLOPs per launch: 4*sq*sk*heads*d (per image).
 #include <stdarg.h>
