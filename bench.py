@@ -108,8 +108,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("VSD_SHARE_GPU"):
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # RCCL over xGMI.  VSD_DIST_BACKEND=gloo + VSD_SHARE_GPU=1 exist only to walk this multi-rank code path on a
+        # single-GPU box (both ranks on cuda:0, collectives on host copies); the driver never sets them.
+        backend = os.environ.get("VSD_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     eng, ops, weights = build_engine(local)
     tuning = os.path.join(ROOT, "profiles", "tuning_mi355x.json")
     if not args.retune:
@@ -121,7 +129,12 @@ def main():
         text.copy_((torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half()[0])
     if dist is not None:
         torch.cuda.current_stream().synchronize()
-        dist.broadcast(text, src=0)
+        if dist.get_backend() == "nccl":
+            dist.broadcast(text, src=0)
+        else:
+            host = text.cpu()
+            dist.broadcast(host, src=0)
+            text.copy_(host)
         torch.cuda.current_stream().synchronize()
     eng.set_text_embeds(text)
     # throughput configuration: several frames in flight, one stream each (with >= 3 frames in flight the GPU's
@@ -172,7 +185,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=ops.device)
+        t = torch.tensor([dt], dtype=torch.float64, device=ops.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fps = world * args.steps / dt

@@ -197,6 +197,12 @@ class HipOps:
                 tile, sk = choose_tile(m, w.n, w.kp, w.geglu, t_col0 if out_t is not None else 0)
                 split_k = sk if split_k is None else split_k
         split_k = split_k or 1
+        if pipeline == 7 and not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out, chanstat_out,
+                                                   ln_part):
+            # a tuning-table entry found for another call of the same shape: this one needs the general epilogue
+            pipeline = 3
+            tile = {L.TILE_256x128: L.TILE_128x128, L.TILE_256x64: L.TILE_128x64}.get(tile, tile)
+            inkernel = True
         d = L.ConvDesc()
         d.src0, d.src1 = self._p(src0), self._p(src1)
         d.c0, d.c1 = c0, c1
@@ -233,6 +239,13 @@ class HipOps:
             if inkernel:
                 d.counters = self._p(self._counters[self._sidx])
         self.ctx.call("vsd_conv_gemm", C.byref(d), self.s)
+
+    @staticmethod
+    def _halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part) -> bool:
+        """What vsd_conv_gemm's halo-patch form (pipeline 7) accepts: a 3x3 stride-1 conv with the plain epilogue."""
+        plain = all(x is None for x in (residual2, out2, out_t, rowstat_out, chanstat_out, ln_part))
+        return (plain and not w.geglu and g.ksize == 3 and g.stride == 1 and w.cin % 64 == 0 and (c1 or 0) % 64 == 0 and
+                w.n % 8 == 0 and out_scale == 1.0 and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_SILU, L.ACT_RELU | L.ACT_POST))
 
     @staticmethod
     def conv_key(g: Geom, w: PackedConv, t_col0: int = 0, rowstat: bool = False):
