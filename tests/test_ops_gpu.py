@@ -447,6 +447,30 @@ def test_sobel_control_matches_oracle(ops):
     assert (ctrl[:, 0] == ctrl[:, 2]).all() and (ctrl[:, 3:] == 0).all()
 
 
+@pytest.mark.parametrize("h,w,skew", [(8, 8, 0), (24, 40, 0), (16, 264, 0), (40, 520, 0), (24, 40, 3), (16, 264, 7), (9, 257, 1)])
+def test_sobel_control_ragged_and_unaligned(ops, h, w, skew):
+    """Row tiles of 256 pixels with 16-byte aligned loads: widths that are not a multiple of the tile, tiles that end
+    inside a 16-byte piece, one-pixel-wide last tiles, and a frame that does not start on a 16-byte boundary."""
+    from PIL import Image
+
+    from oracle.pipeline import sobel_edges
+
+    rng = np.random.default_rng(h * 1000 + w + skew)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    ref = np.asarray(sobel_edges(Image.fromarray(img, "RGB"), 0.11, 0.8))
+    holder = torch.full((skew + h * w * 3 + 64,), 255, dtype=torch.uint8, device="cuda")  # 255s around: leaks would show
+    frame = holder[skew:skew + h * w * 3]
+    frame.copy_(torch.from_numpy(img).reshape(-1))
+    edge = torch.zeros(h * w, dtype=torch.uint8, device="cuda")
+    ctrl = torch.zeros(h * w, 8, dtype=torch.float16, device="cuda")
+    ops.sobel_control(frame, h, w, 0.11, 0.8, edge, ctrl)
+    ops.synchronize()
+    got = edge.cpu().numpy().reshape(h, w)
+    diff = np.abs(got.astype(int) - ref.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01, (diff.max(), (diff > 0).mean())
+    assert torch.equal(ctrl[:, 0].float().cpu(), torch.from_numpy(got.reshape(-1).astype(np.float32) / 255.0).half().float())
+
+
 def test_scheduler_kernels_match_oracle(ops):
     from oracle.scheduler import LCMSchedulerOracle
     from videosd_amd.lcm import LCMSchedule

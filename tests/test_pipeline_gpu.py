@@ -204,3 +204,18 @@ def test_clip_text_encoder_matches_oracle(cfg_name):
     ref = nets.clip_text_forward({k: v.cpu() for k, v in w.items()}, cfg, ids[None])[0]
     rel = float((got - ref).norm() / ref.norm())
     assert torch.isfinite(got).all() and rel <= 1e-2, rel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 3])
+def test_soak_two_launches_in_flight_full_size_bit_identical(batch):
+    """The bench configuration at full size (512x512, 4 steps, ControlNet), two launches in flight, replayed: every result
+    bit-identical to the sequential one (scripts/soak.py; this is the test that caught the per-pixel gather Sobel)."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location(
+        "vsd_soak", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "soak.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    assert soak.run(n=60 if batch == 1 else 30, batch=batch, verbose=False) == 0

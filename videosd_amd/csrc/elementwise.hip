@@ -22,50 +22,108 @@ __global__ void preprocess_rgb_kernel(const unsigned char* __restrict__ rgb, int
   *reinterpret_cast<half8*>(out + (size_t)i * 8) = o;
 }
 
-__device__ __forceinline__ float gray01(const unsigned char* rgb, int h, int w, int y, int x) {
-  if ((unsigned)y >= (unsigned)h || (unsigned)x >= (unsigned)w) return 0.f;
-  const unsigned char* p = rgb + ((size_t)y * w + x) * 3;
-  unsigned l = (p[0] * 19595u + p[1] * 38470u + p[2] * 7471u + 0x8000u) >> 16;  // PIL convert("L")
-  return (float)l / 255.0f;                                                      // ToTensor
-}
+// ---- Sobel control image ---------------------------------------------------------------------------------------------
+// One workgroup = SOBEL_TW pixels of one image row. The bytes of rows y-1..y+1 (one pixel of apron either side) come in with
+// 16-byte aligned loads, one per lane, into LDS; the gray values (PIL convert("L"), ToTensor) are formed once per pixel
+// there; the 3x3 taps are LDS reads.
+constexpr int SOBEL_TW = 256;
+constexpr int SOBEL_RAW16 = 52;  // 16-byte pieces per row: (SOBEL_TW + 2) * 3 bytes + up to 15 of alignment slack, rounded up
 
-__device__ __forceinline__ float sobel_mag(const unsigned char* rgb, int h, int w, int y, int x) {
-  float a = gray01(rgb, h, w, y - 1, x - 1), b = gray01(rgb, h, w, y - 1, x), c = gray01(rgb, h, w, y - 1, x + 1);
-  float d = gray01(rgb, h, w, y, x - 1), f = gray01(rgb, h, w, y, x + 1);
-  float g = gray01(rgb, h, w, y + 1, x - 1), hh = gray01(rgb, h, w, y + 1, x), i = gray01(rgb, h, w, y + 1, x + 1);
-  float ex = (c - a) + 2.0f * (f - d) + (i - g);
-  float ey = (g - a) + 2.0f * (hh - b) + (i - c);
+struct SobelTile {
+  uint4 raw[3][SOBEL_RAW16];
+  float g[3][SOBEL_TW + 2];
+};
+
+__device__ __forceinline__ float sobel_mag_tile(const unsigned char* __restrict__ rgb, int h, int w, int y, int x0,
+                                                SobelTile& t) {
+  const int tid = threadIdx.x;
+  const unsigned char* end = rgb + (size_t)h * w * 3;
+  const int xs = x0 > 0 ? x0 - 1 : 0, xe = min(x0 + SOBEL_TW + 1, w);  // pixel columns [xs, xe) this tile needs
+  // phase 1: raw bytes
+  if (tid < 3 * 64) {
+    const int r = tid >> 6, j = tid & 63, yy = y + r - 1;
+    if ((unsigned)yy < (unsigned)h) {
+      const unsigned char* b0 = rgb + ((size_t)yy * w + xs) * 3;
+      const unsigned char* b1 = rgb + ((size_t)yy * w + xe) * 3;
+      const unsigned char* a0 = reinterpret_cast<const unsigned char*>(reinterpret_cast<uintptr_t>(b0) & ~(uintptr_t)15);
+      const unsigned char* q = a0 + 16 * j;
+      if (q < b1 && j < SOBEL_RAW16) {
+        uint4 v;
+        if (q >= rgb && q + 16 <= end) {
+          v = *reinterpret_cast<const uint4*>(q);
+        } else {  // first / last piece of the frame: stay inside the buffer
+          unsigned char tmp[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) tmp[k] = (q + k >= rgb && q + k < end) ? q[k] : (unsigned char)0;
+          v = *reinterpret_cast<const uint4*>(tmp);
+        }
+        t.raw[r][j] = v;
+      }
+    }
+  }
+  __syncthreads();
+  // phase 2: gray value of every pixel of the 3 x (SOBEL_TW + 2) patch; zero outside the image (conv2d padding=1)
+  for (int q = tid; q < 3 * (SOBEL_TW + 2); q += blockDim.x) {
+    const int r = q / (SOBEL_TW + 2), c = q - r * (SOBEL_TW + 2);
+    const int yy = y + r - 1, px = x0 - 1 + c;
+    float gv = 0.f;
+    if ((unsigned)yy < (unsigned)h && (unsigned)px < (unsigned)w) {
+      const unsigned char* b0 = rgb + ((size_t)yy * w + xs) * 3;
+      const int skew = (int)(reinterpret_cast<uintptr_t>(b0) & 15);
+      const unsigned char* rb = reinterpret_cast<const unsigned char*>(t.raw[r]) + skew + (px - xs) * 3;
+      unsigned l = (rb[0] * 19595u + rb[1] * 38470u + rb[2] * 7471u + 0x8000u) >> 16;  // PIL convert("L")
+      gv = (float)l / 255.0f;                                                          // ToTensor
+    }
+    t.g[r][c] = gv;
+  }
+  __syncthreads();
+  if (x0 + tid >= w) return 0.f;
+  const float a = t.g[0][tid], b = t.g[0][tid + 1], c = t.g[0][tid + 2];
+  const float d = t.g[1][tid], f = t.g[1][tid + 2];
+  const float g = t.g[2][tid], hh = t.g[2][tid + 1], i = t.g[2][tid + 2];
+  const float ex = (c - a) + 2.0f * (f - d) + (i - g);
+  const float ey = (g - a) + 2.0f * (hh - b) + (i - c);
   return sqrtf(ex * ex + ey * ey);
 }
 
-__global__ void sobel_max_kernel(const unsigned char* __restrict__ rgb, int h, int w, unsigned* gmax) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  float m = 0.f;
-  if (i < h * w) m = sobel_mag(rgb, h, w, i / w, i % w);
+// Global maximum in two plain steps, no atomics and no memset node: every block of sobel_max stores ITS maximum (one
+// float per block); every block of sobel_apply folds those (a few KB, L2 resident).
+__global__ void __launch_bounds__(SOBEL_TW) sobel_max_kernel(const unsigned char* __restrict__ rgb, int h, int w,
+                                                              float* __restrict__ blockmax) {
+  __shared__ SobelTile t;
+  __shared__ float wm[SOBEL_TW / 64];
+  float m = sobel_mag_tile(rgb, h, w, blockIdx.y, blockIdx.x * SOBEL_TW, t);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  __shared__ float wm[4];
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    atomicMax(gmax, __float_as_uint(m));  // magnitudes are >= 0: uint order == float order; max is order independent
-  }
+  if (threadIdx.x == 0)
+    blockmax[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));  // order independent
 }
 
-__global__ void sobel_apply_kernel(const unsigned char* __restrict__ rgb, int h, int w, float low, float high,
-                                   const unsigned* gmax, unsigned char* __restrict__ edge, half_t* __restrict__ ctrl) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= h * w) return;
-  float mx = __uint_as_float(*gmax);
-  float e = sobel_mag(rgb, h, w, i / w, i % w) / mx;  // 0/0 -> NaN on an all-black frame, like the reference
+__global__ void __launch_bounds__(SOBEL_TW) sobel_apply_kernel(const unsigned char* __restrict__ rgb, int h, int w, float low,
+                                                                float high, const float* __restrict__ blockmax, int nblk,
+                                                                unsigned char* __restrict__ edge, half_t* __restrict__ ctrl) {
+  __shared__ SobelTile t;
+  __shared__ float wm[SOBEL_TW / 64];
+  float mx = 0.f;
+  for (int j = threadIdx.x; j < nblk; j += blockDim.x) mx = fmaxf(mx, blockmax[j]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mx;
+  const int y = blockIdx.y, x = blockIdx.x * SOBEL_TW + threadIdx.x;
+  const float mag = sobel_mag_tile(rgb, h, w, y, blockIdx.x * SOBEL_TW, t);  // its barriers also publish wm
+  mx = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+  if (x >= w) return;
+  float e = mag / mx;  // 0/0 -> NaN on an all-black frame, like the reference
   if (e >= high) e = 1.0f;
   if (e <= low) e = 0.0f;
   float s = e * 255.0f;
   unsigned char u = (s == s) ? (unsigned char)(int)s : 0;  // .byte() truncation; NaN -> 0
+  const size_t i = (size_t)y * w + x;
   edge[i] = u;
   half_t v = (half_t)((float)u / 255.0f);
-  *reinterpret_cast<half8*>(ctrl + (size_t)i * 8) = (half8){v, v, v, 0, 0, 0, 0, 0};
+  *reinterpret_cast<half8*>(ctrl + i * 8) = (half8){v, v, v, 0, 0, 0, 0, 0};
 }
 
 __global__ void add_noise_kernel(const half_t* __restrict__ x0, const float* __restrict__ noise, float sa, float sb, int hw,
@@ -142,23 +200,25 @@ extern "C" int vsd_preprocess_rgb(vsd_ctx* ctx, const void* rgb_u8, int h, int w
   return ls.finish();
 }
 
+extern "C" int64_t vsd_sobel_workspace_bytes(int h, int w) { return (int64_t)cdiv(w, SOBEL_TW) * h * sizeof(float); }
+
 extern "C" int vsd_sobel_control(vsd_ctx* ctx, const void* rgb_u8, int h, int w, float low, float high, void* edge_u8,
                                  void* control_out, void* workspace, void* stream) {
   if (!ctx) return VSD_ERR_ARG;
   if (!rgb_u8 || !edge_u8 || !control_out || !workspace || h <= 0 || w <= 0)
     return vsd_fail(ctx, VSD_ERR_ARG, "sobel_control: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  VSD_HIP(ctx, hipMemsetAsync(workspace, 0, 16, s));
+  const dim3 grid(cdiv(w, SOBEL_TW), h);
+  const int nblk = (int)(grid.x * grid.y);
   {
     LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
-    hipLaunchKernelGGL(sobel_max_kernel, dim3(cdiv(h * w, 256)), dim3(256), 0, s, (const unsigned char*)rgb_u8, h, w,
-                       (unsigned*)workspace);
+    hipLaunchKernelGGL(sobel_max_kernel, grid, dim3(SOBEL_TW), 0, s, (const unsigned char*)rgb_u8, h, w, (float*)workspace);
     int rc = ls.finish();
     if (rc) return rc;
   }
   LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
-  hipLaunchKernelGGL(sobel_apply_kernel, dim3(cdiv(h * w, 256)), dim3(256), 0, s, (const unsigned char*)rgb_u8, h, w, low,
-                     high, (const unsigned*)workspace, (unsigned char*)edge_u8, (half_t*)control_out);
+  hipLaunchKernelGGL(sobel_apply_kernel, grid, dim3(SOBEL_TW), 0, s, (const unsigned char*)rgb_u8, h, w, low, high,
+                     (const float*)workspace, nblk, (unsigned char*)edge_u8, (half_t*)control_out);
   return ls.finish();
 }
 

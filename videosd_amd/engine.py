@@ -752,6 +752,7 @@ class Engine:
             for b in range(B):  # the edge map is normalised by ITS frame's maximum (canny_gpu.py:39)
                 r.sobel_control(frame_b[b], H, W, 0.11, 0.8, img(self.edge_u8, b, H * W), img(ctrl, b, H * W))  # videopipeline.py:109
             cond_emb = self._cond_embedding(r, ctrl, H, W)
+            self.buffers["control"], self.buffers["cond_emb"] = ctrl, cond_emb
         self._encode(r, enc_in, H, W, x0)
         sa, sb = sched.add_noise_coef()
         for b in range(B):  # every frame gets the same draws: the reference resets its RNG per frame

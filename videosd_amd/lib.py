@@ -65,6 +65,7 @@ SIGNATURES = {
     "vsd_groupnorm_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsd_preprocess_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vsd_sobel_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "vsd_sobel_control": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsd_add_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p,

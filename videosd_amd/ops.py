@@ -94,6 +94,7 @@ class HipOps:
         self._ws = {}
         self.tile_override = {} if tile_override is None else tile_override
         self.inkernel_splitk = True
+        self.no_halo = bool(__import__("os").environ.get("VSD_NO_HALO"))  # debugging: run halo-tuned shapes on the generic ring
         self.default_pipeline = 3
         with torch.cuda.stream(self.stream):
             self._counters = [torch.zeros(L.SPLITK_MAX_TILES, dtype=torch.int32, device=self.device) for _ in range(2)]
@@ -197,8 +198,8 @@ class HipOps:
                 tile, sk = choose_tile(m, w.n, w.kp, w.geglu, t_col0 if out_t is not None else 0)
                 split_k = sk if split_k is None else split_k
         split_k = split_k or 1
-        if pipeline == 7 and not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out, chanstat_out,
-                                                   ln_part):
+        if pipeline == 7 and (self.no_halo or not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out,
+                                                                     chanstat_out, ln_part)):
             # a tuning-table entry found for another call of the same shape: this one needs the general epilogue
             pipeline = 3
             tile = {L.TILE_256x128: L.TILE_128x128, L.TILE_256x64: L.TILE_128x64}.get(tile, tile)
@@ -396,7 +397,7 @@ class HipOps:
         self.ctx.call("vsd_preprocess_rgb", self._p(rgb_u8), h, w, self._p(out), self.s)
 
     def sobel_control(self, rgb_u8, h, w, low, high, edge_u8, control_out):
-        ws = self.workspace("sobel", 256)
+        ws = self.workspace("sobel", int(self.ctx.lib.vsd_sobel_workspace_bytes(h, w)))
         self.ctx.call("vsd_sobel_control", self._p(rgb_u8), h, w, low, high, self._p(edge_u8), self._p(control_out),
                       self._p(ws), self.s)
 
