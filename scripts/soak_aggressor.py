@@ -36,13 +36,13 @@ if kind.startswith("conv"):   # conv:<pipeline>:<h>:<cin>:<cout>:<ksize>
                            split_k=(1 if tl is not None else None))
 rng = np.random.default_rng(0)
 inputs = [rng.integers(0, 256, (512, 512, 3), dtype=np.uint8) for _ in range(4)]
-ref_ctrl = []
+ref_ctrl, ref_x0, ref_out = [], [], []
 for x in inputs:
-    eng.infer_u8(x); ref_ctrl.append(eng.buffers["control"].clone())
+    ref_out.append(eng.infer_u8(x).copy()); ref_ctrl.append(eng.buffers["control"].clone()); ref_x0.append(eng.buffers["x0"].clone())
 side = torch.cuda.Stream()
 a = torch.randn(4096, 4096, device="cuda", dtype=torch.half); b = torch.randn(4096, 4096, device="cuda", dtype=torch.half)
 v = torch.randn(64 << 20, device="cuda")
-bad = 0
+bad = bad_x0 = bad_out = 0
 for i in range(n):
     k = i % 4
     if kind == "mm":
@@ -55,9 +55,11 @@ for i in range(n):
         conv_job()
     elif other is not None:
         other.submit_u8(inputs[(k + 1) % 4])
-    eng.submit_u8(inputs[k]); eng.collect_u8()
+    eng.submit_u8(inputs[k]); out_k = eng.collect_u8()
     if other is not None and conv_job is None: other.collect_u8()
     if conv_job is not None: other.ops.synchronize() if hasattr(other.ops, "synchronize") else torch.cuda.synchronize()
     if not torch.equal(eng.buffers["control"], ref_ctrl[k]): bad += 1
+    if not torch.equal(eng.buffers["x0"], ref_x0[k]): bad_x0 += 1
+    if not np.array_equal(out_k, ref_out[k]): bad_out += 1
 torch.cuda.synchronize()
-print(f"aggressor={kind}: {bad} of {n} launches had a wrong control image", flush=True)
+print(f"aggressor={kind}: of {n} launches, wrong control image {bad}, wrong encoded latent {bad_x0}, wrong output frame {bad_out}", flush=True)
