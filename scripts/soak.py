@@ -1,7 +1,7 @@
 """Concurrency soak: the bench configuration (SOAK_BATCH frames per launch, 2 launches in flight on two engine slots)
 replayed a few hundred times; every result must be bit-identical to the sequential result of the same input (no
 interference between the slots, no state leaking across replays). On a mismatch the first differing stage buffer is
-named. Exit code 1 on any mismatch.   python scripts/soak.py [launches]   env: SOAK_BATCH (3), SOAK_NO_CN, SOAK_EAGER"""
+named. Exit code 1 on any mismatch.   python scripts/soak.py [launches]   env: SOAK_BATCH (3), SOAK_SIZE (512), SOAK_NO_CN, SOAK_EAGER"""
 import collections, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -71,4 +71,5 @@ def run(n=300, batch=3, controlnet=True, use_graph=True, size=512, verbose=True)
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    sys.exit(1 if run(n, int(os.environ.get("SOAK_BATCH", "3")), not os.environ.get("SOAK_NO_CN"), not os.environ.get("SOAK_EAGER")) else 0)
+    sys.exit(1 if run(n, int(os.environ.get("SOAK_BATCH", "3")), not os.environ.get("SOAK_NO_CN"), not os.environ.get("SOAK_EAGER"),
+                      size=int(os.environ.get("SOAK_SIZE", "512"))) else 0)

@@ -44,3 +44,19 @@ def test_conv_desc_struct_matches_header_field_order():
     got = [(n, issubclass(t, ctypes.c_void_p) or t is ctypes.c_void_p) for n, t in L.ConvDesc._fields_]
     assert [f[0] for f in fields] == [g[0] for g in got]
     assert fields == got
+
+
+def test_one_hip_runtime_in_the_process_whatever_the_import_order():
+    """libvsd.so opened before torch used to bind /opt/rocm's libamdhip64 while torch brought its own: two runtimes,
+    vsd_create() found no device (build() followed by smoke() in one process). lib.load() imports torch first."""
+    import re
+    import subprocess
+    import sys
+
+    code = ("from videosd_amd import lib; lib.load(); import torch, re; "
+            "print(sorted(set(re.findall(r'/\\S*libamdhip64\\S*', open('/proc/self/maps').read()))))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         cwd=__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    libs = re.findall(r"'([^']+)'", out.stdout.strip().splitlines()[-1])
+    assert len(libs) == 1, libs

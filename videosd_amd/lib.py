@@ -95,6 +95,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not found: build it with `python -m videosd_amd.build` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # torch first: libvsd.so and torch must share ONE HIP runtime in the process. torch ships its own libamdhip64; if
+    # libvsd.so is opened before it, the loader binds /opt/rocm's copy instead, torch then brings a second runtime and
+    # vsd_create() sees no device (the streams / device pointers torch hands over belong to the other runtime).
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
