@@ -177,7 +177,8 @@ int vsd_preprocess_rgb(vsd_ctx* ctx, const void* rgb_u8, int h, int w, void* out
 /* Sobel "canny" of the reference (canny_gpu.py:27-44) on device: L conversion, two 3x3 filters,
  * magnitude, division by the global max, thresholds, byte truncation.  Writes the u8 edge map (h*w) and
  * the ControlNet conditioning tensor fp16 [h*w][8] (edge/255 in channels 0..2).
- * workspace: >= vsd_sobel_workspace_bytes(h, w) bytes (one partial maximum per workgroup)   .                   */
+ * workspace: >= vsd_sobel_workspace_bytes(h, w) bytes (one partial maximum per workgroup; no atomics, no
+ * memset: two launches on the stream).                                                              */
 int64_t vsd_sobel_workspace_bytes(int h, int w);
 int vsd_sobel_control(vsd_ctx* ctx, const void* rgb_u8, int h, int w, float low, float high, void* edge_u8,
                       void* control_out, void* workspace, void* stream);
