@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: frames/sec of the per-frame SD1.5 LCM denoising path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
 
 A "step" is one frame through the whole hot path (BASELINE.json config 2, reference-faithful: u8 512x512
 frame resident in HBM -> Sobel/ControlNet conditioning -> TAESD encode -> 4 x (ControlNet + UNet + LCM step)
@@ -9,9 +9,14 @@ frame resident in HBM -> Sobel/ControlNet conditioning -> TAESD encode -> 4 x (C
 takes `--batch` of them per hipGraph replay (stacked along the GEMM M dimension: one pass over the 2.45 GB of weights
 serves all of them; every frame keeps its own GroupNorm statistics / attention / Sobel maximum) and keeps `--slots`
 replays in flight on separate streams; K frames = ceil(K / batch) replays.  `--batch 1 --slots 1` is one frame at a
-time; the single-frame latency (`p50_latency_ms`) is always measured that way.  With N GPUs the frames are
-sharded round-robin (frame k -> rank k mod N, no data-path collective; the prompt embeddings are broadcast
-once from rank 0 over RCCL), every rank does K frames (weak scaling) and value = N*K / max-over-ranks time.
+time; the single-frame latency (`p50_latency_ms`) is always measured that way.
+
+N GPUs: one process per GPU.  `--gpus N` without WORLD_SIZE in the environment makes THIS process a launcher that never
+touches the GPU: it starts N fresh children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one rank per
+GPU), waits for them and relays rank 0's JSON line; under `python -m torch.distributed.run ... bench.py --gpus N` (the
+driver's form) the environment is already there and this process is a rank.  Frames are sharded round-robin
+(frame k -> rank k mod N, no data-path collective; the prompt embeddings are broadcast once from rank 0 over RCCL), every
+rank does K frames (weak scaling) and value = N*K / max-over-ranks time.
 
 Weights are seeded synthetic tensors of the SD1.5 / ControlNet / TAESD architectures (no network for
 checkpoints), inputs are synthetic frames: data = "synthetic".
@@ -19,12 +24,11 @@ checkpoints), inputs are synthetic frames: data = "synthetic".
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,10 +37,60 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MIC
 H = W = 512
 LCM_STEPS = 4
 STRENGTH = 0.6
+METRIC = "frames/sec (whole node) + p50 per-frame latency, SD1.5 512x512 LCM 4-step"
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--slots", type=int, default=2, help="launches in flight per GPU (independent frames, one graph each)")
+    ap.add_argument("--batch", type=int, default=3, help="frames per launch (stacked along the GEMM M dimension); "
+                    "--batch 1 --slots 3 is the one-frame-per-launch configuration of the first bench lines")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the leg through VideoSDPipeline.remote(...).infer.remote")
+    ap.add_argument("--no-extras", action="store_true", help="headline, latency and roofline only")
+    ap.add_argument("--retune", action="store_true", help="ignore profiles/tuning_mi355x.json and time all kernel configs again")
+    ap.add_argument("--save-tuning", action="store_true", help="write the tuning table back to profiles/tuning_mi355x.json")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: walk the launch / rendezvous / broadcast / timing "
+                    "protocol with a sleep as the step (CPU test of the multi-rank plumbing; the line says dry_run)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------ launcher (no GPU here)
+def launch_ranks(args, argv):
+    """Start `--gpus` ranks of this script as fresh child processes and relay rank 0's line.  This process must not
+    initialise HIP (a process that has cannot be replaced or forked safely; the children are separate interpreters)."""
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is None or any(rcs):
+        sys.stderr.write(out0 or "")
+        raise SystemExit(f"bench.py: ranks exited with {rcs}" + ("" if line else " and rank 0 printed no result line"))
+    print(line, flush=True)
+
+
+# ------------------------------------------------------------------------------------------ rank
 def synthetic_frames(n, h, w):
     """seeded noise blended 50% with a moving gradient (Sobel max != 0)."""
+    import numpy as np
+
     rng = np.random.default_rng(1234)
     base = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
     yy, xx = np.mgrid[0:h, 0:w]
@@ -63,7 +117,10 @@ def build_engine(device_id):
 
 
 def cpu_baseline(weights, text, frame, budget_s=20.0):
-    """The oracle (CPU fp32 restatement of the reference algorithm) on the host cores, same workload."""
+    """The oracle (CPU fp32 restatement of the reference algorithm) on the host cores, same workload.  Returns the
+    baseline record and the oracle's frame (the parity stamp compares the engine's output with it)."""
+    import numpy as np
+    import torch
     from PIL import Image
 
     from oracle.pipeline import OraclePipeline
@@ -74,50 +131,116 @@ def cpu_baseline(weights, text, frame, budget_s=20.0):
     img = Image.fromarray(frame, "RGB")
     times = []
     t_all = time.time()
+    ref = None
     while len(times) < 3 and (time.time() - t_all) < budget_s:
         t0 = time.time()
-        orc.infer(img, text[None].float(), height=H, width=W, strength=STRENGTH, steps=LCM_STEPS, seed=23,
-                  controlnet_scale=1.0, use_controlnet=True)
+        ref = orc.infer(img, text[None].float(), height=H, width=W, strength=STRENGTH, steps=LCM_STEPS, seed=23,
+                        controlnet_scale=1.0, use_controlnet=True)
         times.append(time.time() - t0)
     best = min(times)
-    return {"value": 1.0 / best, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} frame(s) of the same 512x512 4-step ControlNet workload, best of {len(times)}: "
-                      f"{best:.2f} s/frame"}
+    rec = {"value": 1.0 / best, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{len(times)} frame(s) of the same 512x512 4-step ControlNet workload, best of {len(times)}: "
+                     f"{best:.2f} s/frame"}
+    return rec, np.asarray(ref)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--slots", type=int, default=2, help="launches in flight per GPU (independent frames, one graph each)")
-    ap.add_argument("--batch", type=int, default=3, help="frames per launch (stacked along the GEMM M dimension); "
-                    "--batch 1 --slots 3 is the one-frame-per-launch configuration of the first bench lines")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--retune", action="store_true", help="ignore profiles/tuning_mi355x.json and time all kernel configs again")
-    ap.add_argument("--save-tuning", action="store_true", help="write the tuning table back to profiles/tuning_mi355x.json")
-    args = ap.parse_args()
+def image_parity(got, ref):
+    import numpy as np
+
+    d = got.astype(np.float64) - ref.astype(np.float64)
+    mse = float((d * d).mean())
+    return {"mad_lsb": round(float(np.abs(d).mean()), 4), "max_lsb": int(np.abs(d).max()),
+            "psnr_db": round(10.0 * np.log10(255.0 ** 2 / max(mse, 1e-12)), 2),
+            "against": "oracle (CPU fp32 restatement), same frame / weights / noise, 512x512 4-step ControlNet; "
+                       "tolerance: mad <= 1.5 LSB, PSNR >= 38 dB"}
+
+
+def api_leg(frames_host, n_frames=48):
+    """The drop-in class end to end: PIL in -> worker process -> PIL out through `VideoSDPipeline.remote(...)`
+    (what diffusert/server.py:108 awaits), one frame at a time and as a stream the worker may coalesce."""
+    import asyncio
+
+    from PIL import Image
+
+    from videosd_amd.pipeline import VideoSDPipeline
+
+    opts = dict(prompt="pixar, cg", height=H, width=W, strength=STRENGTH, steps=LCM_STEPS, controlnet_scale=1.0, seed=23)
+    imgs = [Image.fromarray(f, "RGB") for f in frames_host]
+    w = VideoSDPipeline.remote(model="SimianLuo/LCM_Dreamshaper_v7", controlnet="lllyasviel/control_v11p_sd15_canny",
+                               device=0, batch=3, call_timeout=600.0)
+    try:
+        for b in (1, 2, 3):  # plans + graphs of the batch sizes the stream will use
+            futs = [w.infer.remote(imgs[i % len(imgs)], **opts) for i in range(b)]
+            for f in futs:
+                f.result()
+        lat = []
+        for i in range(16):
+            t0 = time.perf_counter()
+            w.infer(imgs[i % len(imgs)], **opts)
+            lat.append((time.perf_counter() - t0) * 1e3)
+
+        async def stream(depth=6):
+            sem = asyncio.Semaphore(depth)
+            done = 0
+
+            async def one(i):
+                nonlocal done
+                async with sem:
+                    await w.infer.remote(imgs[i % len(imgs)], **opts)
+                    done += 1
+
+            t0 = time.perf_counter()
+            await asyncio.gather(*[one(i) for i in range(n_frames)])
+            return n_frames / (time.perf_counter() - t0)
+
+        fps_stream = asyncio.run(stream())
+        m = w.metrics()
+        p50 = statistics.median(lat)
+        return {"api_fps": round(fps_stream, 2), "api_p50_ms": round(p50, 2), "api_fps_one_at_a_time": round(1e3 / p50, 2),
+                "api_stage_ms_p50": m.get("pipeline", {}).get("stage_ms_p50"),
+                "api_note": "PIL 512x512 in -> VideoSDPipeline.remote worker process (shared-memory frame slots) -> PIL out; "
+                            "api_fps: 6 frames outstanding, the worker coalesces up to 3 per launch, 2 launches in flight"}
+    finally:
+        w.close()
+
+
+def run_rank(args):
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if args.gpus != world and "WORLD_SIZE" in os.environ and rank == 0:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}\n")
+    if not args.dry_run and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     dist = None
+    backend = os.environ.get("VSD_DIST_BACKEND", "gloo" if args.dry_run else "nccl")
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("VSD_SHARE_GPU"):
             local = 0
-        torch.cuda.set_device(local)
         # RCCL over xGMI.  VSD_DIST_BACKEND=gloo + VSD_SHARE_GPU=1 exist only to walk this multi-rank code path on a
         # single-GPU box (both ranks on cuda:0, collectives on host copies); the driver never sets them.
-        backend = os.environ.get("VSD_DIST_BACKEND", "nccl")
         if backend == "nccl":
+            torch.cuda.set_device(local)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
+            if not args.dry_run:
+                torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world)
+    ranks_seen = 1
+    if dist is not None:
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, local))
+        ranks_seen = len({r for r, _ in seen})
+
+    if args.dry_run:
+        return dry_run(args, dist, rank, world, ranks_seen)
+
     eng, ops, weights = build_engine(local)
     tuning = os.path.join(ROOT, "profiles", "tuning_mi355x.json")
     if not args.retune:
@@ -128,12 +251,14 @@ def main():
     if rank == 0:
         text.copy_((torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half()[0])
     if dist is not None:
+        from videosd_amd.dispatch import broadcast_prompt
+
         torch.cuda.current_stream().synchronize()
-        if dist.get_backend() == "nccl":
-            dist.broadcast(text, src=0)
+        hdr = {"epoch": 1, "height": H, "width": W, "steps": LCM_STEPS, "strength": STRENGTH, "controlnet_scale": 1.0, "seed": 23}
+        if backend == "nccl":
+            text, _ = broadcast_prompt(text if rank == 0 else None, hdr, src=0, device=ops.device)
         else:
-            host = text.cpu()
-            dist.broadcast(host, src=0)
+            host, _ = broadcast_prompt(text.cpu() if rank == 0 else None, hdr, src=0, device=torch.device("cpu"))
             text.copy_(host)
         torch.cuda.current_stream().synchronize()
     eng.set_text_embeds(text)
@@ -142,7 +267,9 @@ def main():
     # the single-frame latency below is measured with it on)
     B = max(1, args.batch)
     eng.overlap_controlnet = args.slots < 3
+    t_prep = time.perf_counter()
     plan = eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=B)
+    prepare_ms = (time.perf_counter() - t_prep) * 1e3
     # frames are independent (the reference resets its RNG per frame): keep `slots` of them in flight per GPU,
     # each with its own buffers, streams and hipGraph, sharing the weight replica
     engines = [eng]
@@ -165,8 +292,8 @@ def main():
         e.ops.copy_(e.frame_u8, (frames_dev[k:k + nb] if k + nb <= nres else frames_dev[:nb]).view_as(e.frame_u8))
         e.launch()
 
-    def sync_all():
-        for e in engines:
+    def sync_all(pool=None):
+        for e in (pool or engines):
             e.ops.synchronize()
 
     n_launch = -(-args.steps // B)  # K frames = ceil(K / B) launches (a ragged last launch still does B frames of work)
@@ -185,7 +312,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=ops.device if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=ops.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fps = world * args.steps / dt
@@ -195,6 +322,24 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+
+    extras = not args.no_extras and world == 1
+    # ---- end to end: host u8 in -> host u8 out INSIDE the timed region (pinned staging, H2D / D2H on the launch's own
+    #      stream), same frames per launch and launches in flight.  PCIe inclusive: reported beside `value`, never as it.
+    fps_e2e = None
+    if extras:
+        nl = max(2 * len(engines), n_launch)
+        fb = [np.ascontiguousarray(frames_host[(i * B) % (nres - B + 1):(i * B) % (nres - B + 1) + B]) for i in range(4)]
+        for i in range(len(engines)):
+            engines[i].submit_u8(fb[i % 4] if B > 1 else fb[i % 4][0])
+        t1 = time.perf_counter()
+        for i in range(nl):
+            e = engines[i % len(engines)]
+            e.collect_u8()
+            e.submit_u8(fb[i % 4] if B > 1 else fb[i % 4][0])
+        fps_e2e = nl * B / (time.perf_counter() - t1)
+        for e in engines:
+            e.collect_u8()
 
     # ---- p50 per-frame latency: host u8 in -> host u8 out (PCIe inclusive), (a) one frame in flight,
     #      (b) under the benchmark's load (`slots` frames in flight): submit -> that frame's u8 on the host
@@ -213,13 +358,39 @@ def main():
                 e.launch()
         sync_all()
     eng.overlap_controlnet = True
-    eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
+    plan1 = eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
     lat = []
+    got0 = None
     for i in range(min(30, max(5, args.steps))):
         t1 = time.perf_counter()
-        eng.infer_u8(frames_host[i % nres])
+        o = eng.infer_u8(frames_host[i % nres])
         lat.append((time.perf_counter() - t1) * 1e3)
+        if i % nres == 0:
+            got0 = o
     p50 = statistics.median(lat)
+
+    # ---- one frame per launch, three launches in flight (the configuration of round 1's first bench lines)
+    fps_b1 = None
+    if extras:
+        eng.overlap_controlnet = False
+        pool1 = [eng]
+        eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
+        for e in engines[1:]:
+            e.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
+            pool1.append(e)
+        while len(pool1) < 3:
+            sl = eng.make_slot()
+            sl.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
+            pool1.append(sl)
+        for i in range(6):
+            one_frame(i, pool1)
+        sync_all(pool1)
+        t1 = time.perf_counter()
+        nn = max(12, args.steps // 2)
+        for i in range(nn):
+            one_frame(i, pool1)
+        sync_all(pool1)
+        fps_b1 = nn / (time.perf_counter() - t1)
 
     # ---- the same graph without the ControlNet tower (engine extension)
     eng.overlap_controlnet = args.slots < 3
@@ -268,25 +439,38 @@ def main():
                 "families_ms_per_pass": {k: round(v["ms"], 3) for k, v in st.items()}}
 
     out = {
-        "metric": "frames/sec (whole node) + p50 per-frame latency, SD1.5 512x512 LCM 4-step",
+        "metric": METRIC,
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f16 (fp32 accumulate)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f16 (fp32 accumulate)", "data": "synthetic", "ranks_seen": ranks_seen,
         "config": {"workload": "SD1.5 512x512 LCM 4-step img2img, batch=1 per frame (each frame denoised independently), "
                                "ControlNet-canny + TAESD (BASELINE configs[1], reference-faithful: the reference always "
                                "runs ControlNet); frames of the stream are coalesced frames_per_launch at a time",
                    "frames_per_rank": args.steps, "sharding": f"round-robin frames over {world} GPU(s)",
                    "frames_per_launch": B, "launches_in_flight_per_gpu": len(engines),
-                   "timesteps": plan["timesteps"], "kernels_per_frame": plan["n_ops"]},
+                   "timesteps": plan["timesteps"], "kernel_launches_per_graph_replay": plan["n_ops"],
+                   "kernel_launches_per_single_frame_graph": plan1["n_ops"]},
         "p50_latency_ms": round(p50, 3),
         "p50_latency_ms_under_load": round(statistics.median(lat_loaded), 3) if lat_loaded else None,
+        "fps_one_frame_per_launch": round(fps_b1, 3) if fps_b1 else None,
+        "fps_end_to_end": round(fps_e2e, 3) if fps_e2e else None,
         "fps_without_controlnet": round(fps_nocn, 3),
+        "prepare_ms": round(prepare_ms, 1),
         "frame_roofline": {"algorithmic_tflop_per_frame": 4.623, "mfma_frac": round(4.623 * fps / world / MFMA_PEAK_TFLOPS, 4)},
         "roofline": roofline,
     }
+    if extras and not args.no_api:
+        # drop the bench's own engines first: the API worker is a second process with its own weight replica
+        try:
+            out.update(api_leg(frames_host))
+        except Exception as e:  # reporting only; never lose the measured line
+            out["api_fps"] = None
+            out["api_note"] = f"failed: {type(e).__name__}: {e}"
     if not args.no_cpu_baseline and world == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline(weights, text.cpu(), frames_host[0])
+            out["cpu_baseline"], ref0 = cpu_baseline(weights, text.cpu(), frames_host[0])
+            if got0 is not None:
+                out["parity"] = image_parity(got0, ref0)
         except Exception as e:  # the baseline is reporting only; never lose the measured line
             out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"failed: {e}"}
@@ -294,6 +478,48 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def dry_run(args, dist, rank, world, ranks_seen):
+    """The multi-rank protocol of `run_rank` with the GPU taken out: rank 0's prompt is broadcast, every rank 'does' K
+    frames, barrier + max-over-ranks timing, rank 0 prints the line.  CPU test of the plumbing only."""
+    import torch
+
+    from videosd_amd.dispatch import broadcast_prompt
+
+    text = (torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half() if rank == 0 else None
+    checksum = None
+    if dist is not None:
+        buf, hdr = broadcast_prompt(text, {"epoch": 1, "steps": LCM_STEPS}, src=0, device=torch.device("cpu"))
+        sums = [None] * world
+        dist.all_gather_object(sums, float(buf.float().sum()))
+        checksum = sums
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "dry_run": True, "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "ranks_seen": ranks_seen, "prompt_checksums": checksum, "scaling": "weak"}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":

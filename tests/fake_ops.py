@@ -53,6 +53,9 @@ class FakeOps:
     def download(self, src):
         return src.clone()
 
+    def download_into(self, dst_cpu, src):
+        dst_cpu.view(src.shape).copy_(src)
+
     @staticmethod
     def _nhwc(t, h, w, c, b=1):
         """[b*h*w][>=c] buffer (possibly a strided view) -> NCHW fp32"""

@@ -1,7 +1,10 @@
 """TEST-ONLY pipeline stand-ins used to exercise videosd_amd.dispatch without a GPU."""
+import os
 import time
+import zlib
 
 import numpy as np
+import torch
 from PIL import Image
 
 
@@ -14,11 +17,38 @@ class FakePipeline:
         self.device = config.get("device", 0)
         self.delay = float(config.get("delay", 0.0))
         self.prompt = None
+        self.prompt_key = None
+        self.prompt_shape = (77, 32)
+        self.encodes = 0
+        # fault injection: a frame whose first pixel's red value equals `crash_on` kills the process mid-frame
+        # (a HIP fault / OOM kill looks like this from outside), `hang_on` makes it never answer (a hung GPU)
+        self.crash_on = config.get("crash_on")
+        self.hang_on = config.get("hang_on")
+
+    def _faults(self, img):
+        v = int(np.asarray(img.convert("RGB"))[0, 0, 0])
+        if self.crash_on is not None and v == self.crash_on:
+            os._exit(17)
+        if self.hang_on is not None and v == self.hang_on:
+            time.sleep(3600)
+
+    def encode_prompt(self, prompt):
+        """Deterministic stand-in embeddings; counts calls so tests can see WHICH rank encoded."""
+        self.encodes += 1
+        text = prompt if isinstance(prompt, str) else " ".join(prompt)
+        g = torch.Generator().manual_seed(zlib.crc32(text.encode()))
+        return torch.randn(*self.prompt_shape, generator=g).half()
+
+    def prompt_state(self):
+        return {"checksum": self.prompt, "key": self.prompt_key, "encodes": self.encodes}
 
     def infer(self, img, prompt=["pixar, cg"], height=360, width=640, strength=0.4, steps=20, guidance_scale=7.5, ref=False,
               style_fidelity=0.0, controlnet=False, seed=42, controlnet_scale=1):
         if strength < 0:
             raise ValueError("negative strength")
+        if steps == 99:
+            raise RuntimeError("HIP error: simulated device fault")
+        self._faults(img)
         time.sleep(self.delay)
         a = 255 - np.asarray(img.convert("RGB").resize((width, height)))
         a[0, 0, 0] = self.device  # tag the worker that produced the frame
@@ -41,7 +71,10 @@ class FakePipeline:
     def submit_batch(self, imgs, lane=0, **opts):
         if opts.get("strength", 0.4) < 0:
             raise ValueError("negative strength")
+        for im in imgs:
+            self._faults(im)
         self.lanes_used = getattr(self, "lanes_used", set()) | {lane}
+        imgs = [im.copy() for im in imgs]  # (the real pipeline has uploaded the pixels when submit returns)
         return (time.time() + self.delay, imgs, opts, lane)
 
     def collect_batch(self, handle):
@@ -61,4 +94,25 @@ class FakePipeline:
 
     def set_prompt_embeds(self, embeds, key=None):
         self.prompt = float(embeds.float().sum())
+        self.prompt_key = key
         return self.prompt
+
+
+class OrderCheckingPipeline(FakePipeline):
+    """Raises if a launch with new options is submitted while a launch with other options is still uncollected --
+    what VideoSDPipeline's `_require_idle` enforces on the real engine."""
+
+    def __init__(self, **config):
+        super().__init__(**config)
+        self.live = []
+
+    def submit_batch(self, imgs, lane=0, **opts):
+        key = (opts.get("strength"), opts.get("prompt"))
+        if any(k != key for k in self.live):
+            raise RuntimeError("options changed under a launch in flight")
+        self.live.append(key)
+        return super().submit_batch(imgs, lane=lane, **opts)
+
+    def collect_batch(self, handle):
+        self.live.pop(0)
+        return super().collect_batch(handle)

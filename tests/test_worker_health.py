@@ -1,0 +1,183 @@
+"""Worker health, prompt broadcast through the product's worker processes, shared-memory frame transport and the
+JSON-lines metrics of videosd_amd.dispatch -- on CPU with the stand-in pipeline (tests/helpers_fake_pipeline.py) and gloo
+standing in for RCCL.  Reference behaviour being replaced: server.py:107-111 (`finally: generating[gpu] = False`),
+:317-321 (one actor per GPU), :323-349 (watchdog dump)."""
+import asyncio
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from videosd_amd.dispatch import (CallTimeout, FrameDispatcher, RemoteCallError, RemotePipeline, WorkerDied, is_caller_error,
+                                  spawn_workers)
+
+FAKE = "helpers_fake_pipeline:FakePipeline"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+os.environ["PYTHONPATH"] = os.path.dirname(os.path.abspath(__file__)) + os.pathsep + os.environ.get("PYTHONPATH", "")
+OPTS = dict(height=12, width=16)
+
+
+def _img(v, size=(16, 12)):
+    return Image.fromarray(np.full((size[1], size[0], 3), v, dtype=np.uint8), "RGB")
+
+
+def test_caller_errors_keep_their_type_and_the_worker_in_rotation():
+    """A bad option (ValueError in the worker) comes back as a ValueError and does not cost the session its GPU
+    (round 1 marked the GPU unhealthy forever on any exception)."""
+    p = RemotePipeline(factory=FAKE, model="m", controlnet="c")
+    try:
+        async def go():
+            d = FrameDispatcher([p])
+            assert d.submit(_img(1), strength=-1.0, **OPTS) == 0
+            t, e = await d.next_result()
+            assert isinstance(e, ValueError) and isinstance(e, RemoteCallError) and "negative strength" in str(e)
+            assert is_caller_error(e) and d.healthy == [True] and d.caller_errors == 1 and d.worker_faults == 0
+            assert d.submit(_img(10), bogus_option=1, **OPTS) == 1            # unknown kwarg -> TypeError, as in Python
+            t, e = await d.next_result()
+            assert isinstance(e, TypeError) and d.healthy == [True]
+            assert d.submit(_img(10), **OPTS) == 2                            # ... and the worker still serves frames
+            t, img = await d.next_result()
+            assert int(np.asarray(img)[1, 1, 0]) == 245
+            # a runtime fault reported by the worker (HIP error) is NOT the caller's: the worker leaves the rotation
+            assert d.submit(_img(10), steps=99, **OPTS) == 3
+            t, e = await d.next_result()
+            assert isinstance(e, RuntimeError) and not is_caller_error(e) and d.healthy == [False] and d.worker_faults == 1
+            assert d.submit(_img(10), **OPTS) is None and d.dropped == 1
+            return True
+
+        assert asyncio.run(go())
+    finally:
+        p.close()
+
+
+def test_a_worker_dying_mid_frame_fails_its_callers_and_is_replaced_by_a_fresh_process():
+    """crash mid-frame: pending futures fail with WorkerDied (round 1: they hung forever), the dispatcher drops the GPU
+    from the rotation, starts a FRESH child, and that one serves frames again."""
+    ps = [RemotePipeline(factory=FAKE, model="m", controlnet="c", device=i, crash_on=66, delay=0.05) for i in range(2)]
+    first_pid = ps[0]._proc.pid
+    try:
+        async def go():
+            d = FrameDispatcher(ps, respawn=True, depth=2, warm_options=dict(OPTS))
+            assert d.submit(_img(66), **OPTS) == 0      # worker 0 dies on this one
+            assert d.submit(_img(10), **OPTS) == 1      # worker 1 is fine
+            assert d.submit(_img(20), **OPTS) == 2      # queued behind the fatal frame on worker 0: must fail too, not hang
+            out = [await asyncio.wait_for(d.next_result(), timeout=60) for _ in range(3)]
+            assert isinstance(out[0][1], WorkerDied) and isinstance(out[2][1], WorkerDied)
+            assert int(np.asarray(out[1][1])[1, 1, 0]) == 245
+            assert d.busy == [0, 0] and d.worker_faults >= 1
+            for _ in range(400):                         # the replacement joins when it is ready
+                if d.healthy[0]:
+                    break
+                await asyncio.sleep(0.05)
+            assert d.healthy == [True, True] and d.respawns == 1
+            assert d.pipelines[0]._proc.pid != first_pid and d.pipelines[0]._proc.is_alive()
+            # round-robin continues over both workers
+            tk = [d.submit(_img(30 + k), **OPTS) for k in range(2)]
+            res = [await asyncio.wait_for(d.next_result(), timeout=60) for _ in tk]
+            assert sorted(int(np.asarray(r[1])[0, 0, 0]) for r in res) == [0, 1]
+            return True
+
+        assert asyncio.run(go())
+    finally:
+        for p in ps:
+            p.close()
+
+
+def test_dead_handle_raises_at_once():
+    p = RemotePipeline(factory=FAKE, model="m", controlnet="c", crash_on=66)
+    try:
+        with pytest.raises(WorkerDied):
+            p.infer(_img(66), **OPTS)
+        assert p.dead
+        with pytest.raises(WorkerDied):
+            p.infer.remote(_img(1), **OPTS)
+    finally:
+        p.close()
+
+
+def test_a_hung_worker_is_killed_after_the_call_timeout():
+    p = RemotePipeline(factory=FAKE, model="m", controlnet="c", hang_on=77, call_timeout=1.0)
+    try:
+        assert int(np.asarray(p.infer(_img(10), **OPTS))[1, 1, 0]) == 245
+        t0 = time.time()
+        with pytest.raises(CallTimeout):
+            p.infer(_img(77), **OPTS)
+        assert time.time() - t0 < 10 and p.dead and not p._proc.is_alive()
+        q = p.respawn()
+        try:
+            assert int(np.asarray(q.infer(_img(10), **OPTS))[1, 1, 0]) == 245
+        finally:
+            q.close()
+    finally:
+        p.close()
+
+
+def test_frames_travel_through_shared_memory_and_fall_back_to_pickling():
+    p = RemotePipeline(factory=FAKE, model="m", controlnet="c", shm_slots=2, shm_slot_bytes=64 * 64 * 3, batch=2, delay=0.02)
+    try:
+        async def go():
+            small = [p.infer.remote(_img(10 + k, size=(32, 24)), height=24, width=32) for k in range(6)]  # > 2 slots: some pickle
+            big = p.infer.remote(_img(50, size=(128, 128)), height=128, width=128)                        # does not fit a slot
+            return [await f for f in small], await big
+
+        outs, big = asyncio.run(go())
+        assert [int(np.asarray(o)[5, 5, 0]) for o in outs] == [245 - k for k in range(6)]
+        assert big.size == (128, 128) and int(np.asarray(big)[5, 5, 0]) == 205
+        assert sorted(p._free_slots) == [0, 1]  # every slot came back
+        # the returned image owns its pixels (the slot is reused by the next frame)
+        again = p.infer(_img(99, size=(32, 24)), height=24, width=32)
+        assert int(np.asarray(outs[0])[5, 5, 0]) == 245 and int(np.asarray(again)[5, 5, 0]) == 156
+    finally:
+        p.close()
+
+
+def test_prompt_is_encoded_on_rank0_and_broadcast_to_the_other_workers():
+    """SURVEY 8e / north_star: the product's workers form a process group (gloo here, RCCL on the GPU box); a new prompt is
+    encoded by rank 0 only and installed everywhere by one broadcast; frames then find it cached."""
+    ws = spawn_workers(2, factory=FAKE, backend="gloo", model="m", controlnet="c", delay=0.01)
+    try:
+        assert [w.group["rank"] for w in ws] == [0, 1]
+
+        async def go():
+            d = FrameDispatcher(ws, depth=4)
+            assert d.group_ok
+            for k in range(4):
+                d.submit(_img(10 + k), prompt="a red fox", **OPTS)
+            d.submit(_img(20), prompt="a blue whale", **OPTS)
+            d.submit(_img(21), prompt="a blue whale", **OPTS)
+            res = [await asyncio.wait_for(d.next_result(), timeout=60) for _ in range(6)]
+            assert all(not isinstance(r[1], Exception) for r in res)
+            st = [await w.method("prompt_state").remote() for w in ws]
+            lines = await d.metrics_lines()
+            return d.prompt_syncs, st, lines
+
+        syncs, st, lines = asyncio.run(go())
+        assert syncs == 2
+        assert st[0]["encodes"] == 2 and st[1]["encodes"] == 0          # rank 1 never ran the text encoder
+        assert st[0]["checksum"] == st[1]["checksum"] and st[0]["key"] == st[1]["key"] == "a blue whale"
+        recs = [json.loads(x) for x in lines]
+        assert [r["kind"] for r in recs] == ["worker", "worker", "dispatcher"]
+        assert sum(r["frames"] for r in recs[:2]) == 6 and all(r["p50_ms"] is not None and r["world"] == 2 for r in recs[:2])
+        assert recs[2]["prompt_syncs"] == 2 and recs[2]["group"] is True
+    finally:
+        for w in ws:
+            w.close()
+
+
+def test_changing_options_waits_for_the_launches_in_flight():
+    """a request with other options must not re-prepare the engine a running launch still uses.  The worker
+    collects what is in flight before it submits a frame with different kwargs."""
+    p = RemotePipeline(factory="helpers_fake_pipeline:OrderCheckingPipeline", model="m", controlnet="c", batch=2, delay=0.05)
+    try:
+        async def go():
+            futs = [p.infer.remote(_img(10 + k), strength=0.5 if k < 4 else 0.7, **OPTS) for k in range(8)]
+            return [await f for f in futs]
+
+        outs = asyncio.run(go())
+        assert [int(np.asarray(o)[1, 1, 0]) for o in outs] == [245 - k for k in range(8)]
+    finally:
+        p.close()

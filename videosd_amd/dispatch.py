@@ -6,13 +6,26 @@ Replaces the reference's Ray fan-out (/root/reference/diffusert/server.py:104-14
     so `img = await pipelines[gpu].infer.remote(frame.to_image(), **self.options)` (server.py:108) works as is;
   * `generating[gpu]` / first-idle scan -> `FrameDispatcher`: frame k goes to worker k mod N; a frame arriving
     while its worker is busy is dropped (server.py:132-137 drops while all are busy); completed frames are
-    released in submission order ("in_order") or newest-wins ("latest", what server.py:117 effectively shows).
-Frames never cross xGMI: each worker receives its frame from host memory and returns RGB to the host.
+    released in submission order ("in_order") or newest-wins ("latest", what server.py:117 effectively shows);
+  * `for i in range(gpu_num): pipelines[i] = VideoSDPipeline.remote(**config)` (server.py:320-321) -> `spawn_workers`,
+    which also puts the N workers into one process group: a new prompt is CLIP-encoded on rank 0 only and reaches the
+    other ranks as one RCCL broadcast over xGMI (the reference re-encodes it on every GPU for every frame,
+    lcm_controlnet.py:449-454);
+  * `try/finally: generating[gpu] = False` + watchdog (server.py:107-111, 323-349) -> worker health: a caller's bad
+    option comes back as the caller's exception and leaves the worker in rotation; a worker that dies or does not
+    answer within `call_timeout` fails its pending calls, leaves the rotation and is replaced by a FRESH child process
+    (never a re-exec of a process that touched the GPU); JSON-lines metrics per worker (`metrics_lines`).
+Frames never cross xGMI: each worker receives its frame from host memory and returns RGB to the host (by default
+through shared-memory slots, not pickled through the pipe).
 """
 import asyncio
 import importlib
+import json
 import multiprocessing as mp
 import os
+import queue
+import socket
+import statistics
 import threading
 import time
 from typing import Any, Callable, Dict, List, Optional
@@ -30,14 +43,51 @@ def owner_of(frame_index: int, world: int) -> int:
     return frame_index % world
 
 
+# ----------------------------------------------------------------------------------------- errors
+class RemoteCallError(RuntimeError):
+    """An exception raised inside the worker by the call itself (the worker stays healthy)."""
+
+
+class WorkerDied(RuntimeError):
+    """The worker process is gone (HIP fault, OOM kill, ...): every pending call fails with this."""
+
+
+class CallTimeout(WorkerDied):
+    """The worker did not answer within `call_timeout`; it is killed (a hung GPU cannot be trusted)."""
+
+
+# Errors of the CALLER (bad option values, unknown kwargs): they travel back as the same builtin type (as Ray's
+# RayTaskError does for the reference) and do not count against the worker.
+_CALLER_TYPES = {"ValueError": ValueError, "TypeError": TypeError, "KeyError": KeyError}
+_remote_classes: Dict[str, type] = {}
+
+
+def _remote_exception(type_name: str, text: str) -> Exception:
+    base = _CALLER_TYPES.get(type_name)
+    if base is None:
+        return RemoteCallError(f"{type_name}: {text}")
+    cls = _remote_classes.get(type_name)
+    if cls is None:
+        cls = type("Remote" + type_name, (RemoteCallError, base), {"__str__": RuntimeError.__str__})
+        _remote_classes[type_name] = cls
+    return cls(f"{type_name}: {text}")
+
+
+def is_caller_error(e: BaseException) -> bool:
+    return isinstance(e, tuple(_CALLER_TYPES.values())) and not isinstance(e, WorkerDied)
+
+
 # ----------------------------------------------------------------------------------------- collective
+PROMPT_HEADER_KEYS = ["epoch", "height", "width", "steps", "strength", "controlnet_scale", "seed"]
+
+
 def broadcast_prompt(embeds: Optional[torch.Tensor], header: Optional[Dict[str, float]] = None, src: int = 0,
                      device: Optional[torch.device] = None, shape=(77, 768)):
     """Rank `src` passes the prompt embeddings [77, cross_dim] (and an options header); every rank returns them.
     One small header broadcast + one 118 KB payload broadcast; the only collective on the path."""
     import torch.distributed as dist
 
-    keys = ["epoch", "height", "width", "steps", "strength", "controlnet_scale", "seed"]
+    keys = PROMPT_HEADER_KEYS
     rank = dist.get_rank()
     hdr = torch.zeros(len(keys), dtype=torch.float64, device=device)
     if rank == src:
@@ -50,84 +100,276 @@ def broadcast_prompt(embeds: Optional[torch.Tensor], header: Optional[Dict[str, 
     return buf, {k: float(v) for k, v in zip(keys, hdr.tolist())}
 
 
+def prompt_key(prompt):
+    """The cache key VideoSDPipeline uses for a prompt (str, or list[str] as in the reference's default)."""
+    return prompt if isinstance(prompt, str) else tuple(prompt)
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+# ----------------------------------------------------------------------------------------- shared-memory frames
+class _ShmRing:
+    """`slots` fixed-size RGB slots in one POSIX shared-memory segment.  The parent owns allocation (a free list);
+    slot i of the request ring pairs with slot i of the reply ring, so a reply needs no allocation of its own."""
+
+    def __init__(self, slots: int, slot_bytes: int, name: Optional[str] = None):
+        from multiprocessing import shared_memory
+
+        self.slots, self.slot_bytes = slots, slot_bytes
+        if name is None:
+            self.shm = shared_memory.SharedMemory(create=True, size=slots * slot_bytes)
+            self.owner = True
+        else:
+            self.shm = shared_memory.SharedMemory(name=name)
+            self.owner = False  # (spawned children share the parent's resource tracker: nothing to unregister here)
+
+    def view(self, slot: int, nbytes: int) -> memoryview:
+        o = slot * self.slot_bytes
+        return self.shm.buf[o:o + nbytes]
+
+    def close(self):
+        try:
+            self.shm.close()
+            if self.owner:
+                self.shm.unlink()
+        except Exception:
+            pass
+
+
+def _image_from_slot(ring: _ShmRing, slot: int, w: int, h: int, copy: bool):
+    from PIL import Image
+
+    mv = ring.view(slot, w * h * 3)
+    if copy:
+        return Image.frombytes("RGB", (w, h), bytes(mv))
+    return Image.frombuffer("RGB", (w, h), mv, "raw", "RGB", 0, 1)  # zero-copy, read-only use
+
+
+def _image_to_slot(ring: _ShmRing, slot: int, img) -> Optional[tuple]:
+    if img.mode != "RGB":
+        img = img.convert("RGB")
+    w, h = img.size
+    n = w * h * 3
+    if n > ring.slot_bytes:
+        return None
+    ring.view(slot, n)[:] = img.tobytes()
+    return (slot, w, h)
+
+
 # ----------------------------------------------------------------------------------------- worker process
 def _resolve(path: str) -> Callable:
     mod, _, name = path.partition(":")
     return getattr(importlib.import_module(mod), name)
 
 
-def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1):
+class _Stats:
+    """Per-worker serving statistics (JSON-lines metrics: fps, p50 / p95 latency, launches, frames per launch)."""
+
+    def __init__(self, keep: int = 512):
+        self.t0 = time.time()
+        self.frames = 0
+        self.launches = 0
+        self.errors = 0
+        self.lat: List[float] = []   # ms, request taken from the pipe -> result sent
+        self.keep = keep
+
+    def add(self, n_frames: int, ms: float):
+        self.frames += n_frames
+        self.launches += 1
+        self.lat.append(ms)
+        if len(self.lat) > self.keep:
+            del self.lat[: len(self.lat) - self.keep]
+
+    def snapshot(self) -> Dict[str, Any]:
+        up = max(time.time() - self.t0, 1e-9)
+        lat = sorted(self.lat)
+        pick = lambda q: round(lat[min(len(lat) - 1, int(q * (len(lat) - 1) + 0.5))], 3) if lat else None  # noqa: E731
+        return {"frames": self.frames, "launches": self.launches, "errors": self.errors, "uptime_s": round(up, 3),
+                "fps": round(self.frames / up, 3), "p50_ms": pick(0.5), "p95_ms": pick(0.95),
+                "frames_per_launch": round(self.frames / self.launches, 3) if self.launches else None}
+
+
+def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1, group: Optional[Dict[str, Any]] = None,
+                 shm: Optional[Dict[str, Any]] = None):
     """Serve calls in order, like a Ray actor.  With max_batch > 1, `infer` calls that are ALREADY queued behind the one
     being taken (frames of other sessions, or of the same stream submitted ahead) and carry the same options are
     coalesced into one `infer_batch` launch: no waiting for a batch to fill, so a lone frame is never delayed.  When
     the pipeline has `submit_batch` / `collect_batch`, up to two launches are kept in flight (two engine lanes): while
     the GPU works on one, this process crops / resizes / uploads the next and converts / sends the previous one.
-    Results always go back in request order."""
+    A request whose options differ from the launches in flight waits until those are collected (a new plan re-prepares
+    the engine the other lane is still running on).  Results always go back in request order."""
+    dist = None
+    rank, world = 0, 1
+    dev = torch.device("cpu")
     try:
+        if group is not None:  # join the workers' process group (RCCL on the GPU box, gloo in CPU tests)
+            import datetime
+
+            import torch.distributed as dist
+
+            rank, world = int(group["rank"]), int(group["world"])
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = str(group["port"])
+            to = datetime.timedelta(seconds=float(group.get("timeout", 120.0)))
+            if group["backend"] == "nccl":
+                dev = torch.device("cuda", int(config.get("device", 0)))
+                torch.cuda.set_device(dev)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=to)
+            else:
+                dist.init_process_group(group["backend"], rank=rank, world_size=world, timeout=to)
         pipe = _resolve(factory)(**config)
         conn.send(("ready", None))
     except BaseException as e:  # construction errors travel to the parent (the reference re-raises KeyError)
         conn.send(("error", (type(e).__name__, str(e))))
         return
+    rings = None
+    if shm is not None:
+        rings = (_ShmRing(shm["slots"], shm["slot_bytes"], shm["in"]), _ShmRing(shm["slots"], shm["slot_bytes"], shm["out"]))
     pipelined = max_batch > 1 and hasattr(pipe, "submit_batch") and hasattr(pipe, "collect_batch")
     backlog, inflight, lane = [], [], 0
+    stats = _Stats()
+    epoch = 0
 
-    def fail(group, e):
-        for r, _ in group:
+    def reply(rid, img, slot):
+        if rings is not None and slot is not None and hasattr(img, "tobytes"):
+            where = _image_to_slot(rings[1], slot, img)
+            if where is not None:
+                conn.send((rid, True, ("__shm__",) + where))
+                return
+        conn.send((rid, True, img))
+
+    def fail(group_, e):
+        stats.errors += len(group_)
+        for r, _a, _s in group_:
             conn.send((r, False, (type(e).__name__, str(e))))
 
     def finish_oldest():
-        group, handle = inflight.pop(0)
+        group_, handle, t_in, _kw = inflight.pop(0)
         try:
-            for (r, _), o in zip(group, pipe.collect_batch(handle)):
-                conn.send((r, True, o))
+            outs = pipe.collect_batch(handle)
+            for (r, _a, s), o in zip(group_, outs):
+                reply(r, o, s)
+            stats.add(len(group_), (time.time() - t_in) * 1e3)
         except BaseException as e:
-            fail(group, e)
+            fail(group_, e)
+
+    def drain():
+        while inflight:
+            finish_oldest()
+
+    def take(msg):
+        """(rid, method, args, kwargs) -> (rid, frame-args, reply slot); shared-memory frames become PIL images here"""
+        rid, method, args, kwargs = msg
+        slot = None
+        if method == "infer" and len(args) == 1 and isinstance(args[0], tuple) and args[0] and args[0][0] == "__shm__":
+            _, slot, w, h = args[0]
+            args = (_image_from_slot(rings[0], slot, w, h, copy=False),)
+        return rid, method, args, kwargs, slot
+
+    def sync_prompt(prompt, header):
+        """A new prompt for every worker of the group: rank 0 encodes (CLIP on its GPU), everyone receives."""
+        nonlocal epoch
+        drain()
+        epoch += 1
+        key = prompt_key(prompt)
+        if dist is None or world == 1:
+            emb = pipe.encode_prompt(prompt)
+            pipe.set_prompt_embeds(emb, key=key)
+            return {"epoch": epoch, "rank": rank, "via": "local"}
+        emb = pipe.encode_prompt(prompt) if rank == 0 else None
+        shape = tuple(getattr(pipe, "prompt_shape", (77, 768)))
+        hdr = dict(header or {})
+        hdr["epoch"] = epoch
+        buf, got = broadcast_prompt(emb, hdr, src=0, device=dev, shape=shape)
+        if dev.type == "cuda":
+            torch.cuda.current_stream().synchronize()
+        pipe.set_prompt_embeds(buf, key=key)
+        return {"epoch": int(got["epoch"]), "rank": rank, "via": dist.get_backend(), "checksum": float(buf.float().sum())}
 
     while True:
         if inflight and not backlog and not conn.poll(0):  # nothing new to start: hand back the oldest launch
             finish_oldest()
             continue
-        msg = backlog.pop(0) if backlog else conn.recv()
+        try:
+            msg = backlog.pop(0) if backlog else conn.recv()
+        except (EOFError, OSError):
+            break
         if msg is None:
             break
-        rid, method, args, kwargs = msg
-        group = [(rid, args)]
+        t_in = time.time()
+        rid, method, args, kwargs, slot = take(msg)
+        if method == "__sync_prompt__":
+            try:
+                conn.send((rid, True, sync_prompt(*args)))
+            except BaseException as e:
+                conn.send((rid, False, (type(e).__name__, str(e))))
+            continue
+        if method == "__metrics__":
+            snap = stats.snapshot()
+            snap.update({"rank": rank, "world": world, "device": config.get("device", 0), "pid": os.getpid()})
+            if hasattr(pipe, "metrics"):
+                try:
+                    snap["pipeline"] = pipe.metrics()
+                except Exception as e:  # metrics must never take a worker down
+                    snap["pipeline"] = {"error": str(e)}
+            conn.send((rid, True, snap))
+            continue
+        group_ = [(rid, args, slot)]
         batchable = max_batch > 1 and method == "infer" and len(args) == 1 and hasattr(pipe, "infer_batch")
         if batchable:
-            while len(group) < max_batch and (backlog or conn.poll(0)):
-                nxt = backlog.pop(0) if backlog else conn.recv()
+            while len(group_) < max_batch and (backlog or conn.poll(0)):
+                try:
+                    nxt = backlog.pop(0) if backlog else conn.recv()
+                except (EOFError, OSError):
+                    nxt = None
                 if nxt is not None and nxt[1] == "infer" and len(nxt[2]) == 1 and nxt[3] == kwargs:
-                    group.append((nxt[0], nxt[2]))
+                    r2, _m, a2, _k, s2 = take(nxt)
+                    group_.append((r2, a2, s2))
                 else:  # different options / another method / shutdown: serve it next, stop growing this batch
                     backlog.insert(0, nxt)
                     break
         if batchable and pipelined:
+            # launches in flight run on engines of THEIR plan: anything that re-prepares (other options, another prompt)
+            # waits for them (ADVICE r1: `_engine_for` / `set_text_embeds` under a running graph)
+            if inflight and inflight[-1][3] != kwargs:
+                drain()
             try:
-                handle = pipe.submit_batch([a[0] for _, a in group], lane=lane, **kwargs)
+                handle = pipe.submit_batch([a[0] for _, a, _s in group_], lane=lane, **kwargs)
             except BaseException as e:
-                while inflight:
-                    finish_oldest()
-                fail(group, e)
+                drain()
+                fail(group_, e)
                 continue
             lane ^= 1
-            inflight.append((group, handle))
+            inflight.append((group_, handle, t_in, kwargs))
             if len(inflight) > 1:
                 finish_oldest()
             continue
-        while inflight:  # anything else runs alone, after what is in flight
-            finish_oldest()
+        drain()  # anything else runs alone, after what is in flight
         try:
-            if len(group) > 1:
-                outs = pipe.infer_batch([a[0] for _, a in group], **kwargs)
-                for (r, _), o in zip(group, outs):
-                    conn.send((r, True, o))
+            if len(group_) > 1:
+                outs = pipe.infer_batch([a[0] for _, a, _s in group_], **kwargs)
+                for (r, _a, s), o in zip(group_, outs):
+                    reply(r, o, s)
+                stats.add(len(group_), (time.time() - t_in) * 1e3)
             else:
-                conn.send((rid, True, getattr(pipe, method)(*args, **kwargs)))
+                out = getattr(pipe, method)(*args, **kwargs)
+                reply(rid, out, slot)
+                if method == "infer":
+                    stats.add(1, (time.time() - t_in) * 1e3)
         except BaseException as e:
-            fail(group, e)
-    while inflight:
-        finish_oldest()
+            fail(group_, e)
+    drain()
+    if dist is not None:
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 class _RemoteMethod:
@@ -144,41 +386,80 @@ class _RemoteMethod:
 
 class RemotePipeline:
     """A VideoSDPipeline living in its own process (one per GPU), like the reference's Ray actor: calls are
-    serialised per worker, inputs/outputs are pickled copies."""
+    serialised per worker; frames travel through shared-memory slots (or pickled, for anything that is not an RGB
+    image or does not fit a slot).
+
+    Health: `dead` becomes True when the process has gone or was killed after a `call_timeout`; every pending call then
+    fails with WorkerDied / CallTimeout, later calls raise at once, and `respawn()` gives a FRESH worker with the same
+    configuration (the old process is never re-executed)."""
 
     def __init__(self, factory: str = "videosd_amd.pipeline:VideoSDPipeline", start_timeout: float = 600.0, batch: int = 1,
-                 **config):
-        """batch > 1: the worker coalesces up to `batch` queued `infer` calls with equal options into one launch."""
+                 call_timeout: Optional[float] = None, group: Optional[Dict[str, Any]] = None, shm_slots: int = 16,
+                 shm_slot_bytes: int = 1024 * 1024 * 3, wait: bool = True, **config):
+        """batch > 1: the worker coalesces up to `batch` queued `infer` calls with equal options into one launch.
+        call_timeout: seconds one call may take before the worker is declared hung and killed (None: no limit).
+        group: {"rank", "world", "port", "backend"} -- the worker joins that torch.distributed group (`spawn_workers`).
+        shm_slots: frames in flight through shared memory (0: always pickle)."""
+        self._ctor = dict(factory=factory, start_timeout=start_timeout, batch=batch, call_timeout=call_timeout,
+                          shm_slots=shm_slots, shm_slot_bytes=shm_slot_bytes, **config)
+        self.group = group
+        self.call_timeout = call_timeout
+        self.dead = False
+        self.death: Optional[BaseException] = None
+        self._start_timeout = start_timeout
+        self._rings = None
+        shm = None
+        if shm_slots > 0:
+            self._rings = (_ShmRing(shm_slots, shm_slot_bytes), _ShmRing(shm_slots, shm_slot_bytes))
+            shm = {"slots": shm_slots, "slot_bytes": shm_slot_bytes, "in": self._rings[0].shm.name, "out": self._rings[1].shm.name}
+        self._free_slots = list(range(shm_slots))
         ctx = mp.get_context("spawn")
         self._conn, child = ctx.Pipe()
-        self._proc = ctx.Process(target=_worker_main, args=(child, factory, config, int(batch)), daemon=True)
+        self._proc = ctx.Process(target=_worker_main, args=(child, factory, config, int(batch), group, shm), daemon=True)
         self._proc.start()
         child.close()
-        if not self._conn.poll(start_timeout):
-            self.close()
-            raise RuntimeError("pipeline worker did not start")
-        tag, payload = self._conn.recv()
-        if tag != "ready":
-            self.close()
-            exc = KeyError if payload[0] == "KeyError" else RuntimeError
-            raise exc(f"pipeline worker failed to start: {payload[0]}: {payload[1]}")
         self._lock = threading.Lock()
         self._next = 0
         self._pending: Dict[int, Any] = {}
-        # Requests leave through a writer thread: a frame is ~0.8 MB, far more than the pipe buffers, so a `send` in the
-        # caller's thread would block the event loop while the worker is busy -- and while holding the lock the reader
-        # needs to hand back the worker's (equally large) result, which is a deadlock.
-        import queue
+        self._ready = False
+        self.infer = _RemoteMethod(self, "infer")
+        self.compile_model = _RemoteMethod(self, "compile_model")
+        self.set_prompt_embeds = _RemoteMethod(self, "set_prompt_embeds")
+        self.sync_prompt = _RemoteMethod(self, "__sync_prompt__")
+        self.metrics = _RemoteMethod(self, "__metrics__")
+        if wait:
+            self.wait_ready()
 
+    def wait_ready(self):
+        if self._ready:
+            return self
+        if not self._conn.poll(self._start_timeout):
+            self._kill()
+            raise RuntimeError("pipeline worker did not start")
+        try:
+            tag, payload = self._conn.recv()
+        except (EOFError, OSError):
+            self._kill()
+            raise WorkerDied("pipeline worker died while starting")
+        if tag != "ready":
+            self._kill()
+            exc = KeyError if payload[0] == "KeyError" else RuntimeError
+            raise exc(f"pipeline worker failed to start: {payload[0]}: {payload[1]}")
+        # Requests leave through a writer thread: a pickled frame is ~0.8 MB, far more than the pipe buffers, so a `send`
+        # in the caller's thread would block the event loop while the worker is busy -- and while holding the lock the
+        # reader needs to hand back the worker's (equally large) result, which is a deadlock.
         self._outbox: "queue.Queue" = queue.Queue()
         self._writer = threading.Thread(target=self._write_loop, daemon=True)
         self._writer.start()
         self._reader = threading.Thread(target=self._read_loop, daemon=True)
         self._reader.start()
-        self.infer = _RemoteMethod(self, "infer")
-        self.compile_model = _RemoteMethod(self, "compile_model")
-        self.set_prompt_embeds = _RemoteMethod(self, "set_prompt_embeds")
+        if self.call_timeout:
+            self._watch = threading.Thread(target=self._watch_loop, daemon=True)
+            self._watch.start()
+        self._ready = True
+        return self
 
+    # ------------------------------------------------------------------ threads
     def _write_loop(self):
         while True:
             msg = self._outbox.get()
@@ -189,31 +470,90 @@ class RemotePipeline:
             if msg is None:
                 return
 
+    def _complete(self, entry, ok, payload):
+        target, loop, slot, _deadline = entry
+        if ok and isinstance(payload, tuple) and payload and payload[0] == "__shm__":
+            _, s, w, h = payload
+            payload = _image_from_slot(self._rings[1], s, w, h, copy=True)
+        if slot is not None:
+            with self._lock:
+                self._free_slots.append(slot)
+        if ok:
+            setter = lambda t=target, p=payload: (not t.done()) and t.set_result(p)  # noqa: E731
+        else:
+            exc = payload if isinstance(payload, BaseException) else _remote_exception(payload[0], payload[1])
+            setter = lambda t=target, e=exc: (not t.done()) and t.set_exception(e)  # noqa: E731
+        if loop is not None:
+            try:
+                loop.call_soon_threadsafe(setter)
+            except RuntimeError:  # the caller's loop is gone
+                pass
+        else:
+            setter()
+
+    def _fail_all(self, exc: BaseException):
+        """The worker is gone: nobody will ever answer the pending calls (callers hung forever)."""
+        with self._lock:
+            self.dead = True
+            self.death = self.death or exc
+            pending, self._pending = self._pending, {}
+        for entry in pending.values():
+            self._complete(entry, False, self.death)
+
     def _read_loop(self):
         while True:
             try:
                 rid, ok, payload = self._conn.recv()
-            except (EOFError, OSError):
+            except (EOFError, OSError, ValueError):
+                try:
+                    self._proc.join(timeout=5)  # (so that `exitcode` / `is_alive` are settled when the callers wake up)
+                except Exception:
+                    pass
+                code = self._proc.exitcode
+                self._fail_all(WorkerDied(f"pipeline worker (pid {self._proc.pid}) died (exit code {code})"))
                 return
             with self._lock:
-                fut = self._pending.pop(rid, None)
-            if fut is None:
-                continue
-            target, loop = fut
-            if ok:
-                setter = lambda t=target, p=payload: (not t.done()) and t.set_result(p)  # noqa: E731
-            else:
-                setter = lambda t=target, p=payload: (not t.done()) and t.set_exception(RuntimeError(f"{p[0]}: {p[1]}"))  # noqa: E731
-            if loop is not None:
-                loop.call_soon_threadsafe(setter)
-            else:
-                setter()
+                entry = self._pending.pop(rid, None)
+            if entry is not None:
+                self._complete(entry, ok, payload)
 
+    def _watch_loop(self):
+        """Per-call timeout: a call past its deadline means a hung GPU / worker.  Kill the process (its pending calls
+        fail through the reader's EOF path); the dispatcher replaces it with a fresh one."""
+        while not self.dead:
+            time.sleep(min(0.25, self.call_timeout / 4))
+            now = time.time()
+            with self._lock:
+                late = [rid for rid, e in self._pending.items() if e[3] is not None and now > e[3]]
+            if late:
+                self.death = CallTimeout(f"pipeline worker (pid {self._proc.pid}) did not answer within {self.call_timeout} s; killed")
+                self._kill()
+                self._fail_all(self.death)
+                return
+
+    # ------------------------------------------------------------------ calls
     def _send(self, name, args, kwargs, target, loop):
+        if self.dead:
+            raise self.death or WorkerDied("pipeline worker is dead")
+        if not self._ready:
+            self.wait_ready()
+        slot = None
+        if name == "infer" and self._rings is not None and len(args) == 1 and hasattr(args[0], "tobytes") and hasattr(args[0], "size"):
+            with self._lock:
+                slot = self._free_slots.pop() if self._free_slots else None
+            if slot is not None:
+                where = _image_to_slot(self._rings[0], slot, args[0])
+                if where is None:
+                    with self._lock:
+                        self._free_slots.append(slot)
+                    slot = None
+                else:
+                    args = (("__shm__",) + where,)
+        deadline = time.time() + self.call_timeout if (self.call_timeout and name in ("infer", "__sync_prompt__")) else None
         with self._lock:
             rid = self._next
             self._next += 1
-            self._pending[rid] = (target, loop)
+            self._pending[rid] = (target, loop, slot, deadline)
         self._outbox.put((rid, name, args, kwargs))
 
     def _submit(self, name, args, kwargs):
@@ -234,19 +574,50 @@ class RemotePipeline:
         self._send(name, args, kwargs, fut, None)
         return fut.result()
 
+    def method(self, name: str) -> _RemoteMethod:
+        """Any other method of the pipeline object: `handle.method("stage_profile").remote()`."""
+        return _RemoteMethod(self, name)
+
+    # ------------------------------------------------------------------ lifecycle
+    def respawn(self, **overrides) -> "RemotePipeline":
+        """A fresh worker process with this one's configuration (this one is closed).  It does NOT rejoin a process
+        group (a communicator cannot be re-entered): it encodes prompts itself, like a stand-alone worker."""
+        self.close()
+        kw = dict(self._ctor)
+        kw.update(overrides)
+        return RemotePipeline(**kw)
+
+    def _kill(self):
+        try:
+            if self._proc.is_alive():
+                self._proc.kill()  # exactly this PID
+                self._proc.join(timeout=5)
+        except Exception:
+            pass
+
     def close(self):
         try:
-            if hasattr(self, "_outbox"):
+            if hasattr(self, "_outbox") and not self.dead:
                 self._outbox.put(None)
                 self._writer.join(timeout=2)
-            else:
+            elif not self.dead:
                 self._conn.send(None)
         except Exception:
             pass
-        if self._proc.is_alive():
-            self._proc.join(timeout=5)
-        if self._proc.is_alive():
-            self._proc.terminate()
+        try:
+            if self._proc.is_alive():
+                self._proc.join(timeout=5)
+            if self._proc.is_alive():
+                self._proc.terminate()
+                self._proc.join(timeout=5)
+        except Exception:
+            pass
+        self.dead = True
+        self.death = self.death or WorkerDied("pipeline worker was closed")
+        if self._rings is not None:
+            for r in self._rings:
+                r.close()
+            self._rings = None
 
     def __del__(self):
         try:
@@ -255,32 +626,101 @@ class RemotePipeline:
             pass
 
 
+def spawn_workers(n: int, factory: str = "videosd_amd.pipeline:VideoSDPipeline", backend: Optional[str] = "auto",
+                  devices: Optional[List[int]] = None, **kwargs) -> List[RemotePipeline]:
+    """The reference's `for i in range(gpu_num): pipelines[i] = VideoSDPipeline.remote(**config)` (server.py:317-321):
+    N worker processes, worker i on GPU `devices[i]` (default i), all in ONE process group so that a new prompt is one
+    RCCL broadcast from rank 0 (`backend` "nccl" = RCCL over xGMI on the GPU box; "gloo" for CPU tests; None: no group,
+    every worker encodes for itself).  The workers start concurrently (the rendezvous needs all of them)."""
+    if backend == "auto":
+        backend = "nccl" if torch.cuda.device_count() >= n and n > 1 else None
+    if n == 1:
+        backend = None
+    port = free_port() if backend else None
+    devices = devices if devices is not None else list(range(n))
+    ws = []
+    try:
+        for i in range(n):
+            grp = {"rank": i, "world": n, "port": port, "backend": backend} if backend else None
+            ws.append(RemotePipeline(factory=factory, group=grp, wait=False, device=devices[i], **kwargs))
+        for w in ws:
+            w.wait_ready()
+    except BaseException:
+        for w in ws:
+            w.close()
+        raise
+    return ws
+
+
 # ----------------------------------------------------------------------------------------- dispatcher
 class FrameDispatcher:
     """Round-robin frame scheduler over N pipeline handles (RemotePipeline or anything with `.infer.remote`).
 
     submit(frame, **options) returns the frame's sequence number, or None when the owning worker is still busy
     (the frame is dropped, as the reference does while every GPU is generating).  Results come out of
-    `await next_result()`: in submission order ("in_order") or whichever finished last ("latest")."""
+    `await next_result()`: in submission order ("in_order") or whichever finished last ("latest").
 
-    def __init__(self, pipelines: List[Any], mode: str = "in_order", depth: int = 1):
+    Prompts: when the handles share a process group (`spawn_workers`), a frame whose `prompt` differs from the last one
+    first sends every worker a prompt sync -- rank 0 encodes, RCCL broadcasts, the others install the embeddings -- so
+    the frame itself finds the prompt cached wherever it lands.
+    Health: an exception that is the caller's (ValueError / TypeError / KeyError from bad options) is returned and the
+    worker stays in rotation; anything else (worker died, timeout, HIP error) takes the worker out and, with
+    `respawn=True`, a fresh process replaces it in the background and rejoins the rotation when it is ready."""
+
+    def __init__(self, pipelines: List[Any], mode: str = "in_order", depth: int = 1, respawn: bool = False,
+                 warm_options: Optional[Dict[str, Any]] = None):
         """depth: frames one worker may hold at once (1 = the reference's `generating[gpu]` flag; set it to the
-        workers' `batch` x launches in flight so that queued frames can be coalesced)."""
+        workers' `batch` x launches in flight so that queued frames can be coalesced).
+        warm_options: `infer` options a respawned worker is warmed up with (plan + graph) before it rejoins."""
         assert mode in ("in_order", "latest")
         self.pipelines, self.mode = pipelines, mode
         self.n = len(pipelines)
         self.depth = max(1, int(depth))
         self.busy = [0] * self.n              # server.py:277 `generating`, as a count
         self.healthy = [True] * self.n
+        self.respawn = respawn
+        self.respawns = 0
+        self.warm_options = warm_options
+        self._respawning = [False] * self.n
         self.seq = 0
         self.submitted = 0
         self.dropped = 0
+        self.caller_errors = 0
+        self.worker_faults = 0
         self._done: Dict[int, Any] = {}
         self._next_release = 0
         self._inflight = set()
         self._event = asyncio.Event()
         self.avg_gen_time = 0.4               # server.py:96 prior, updated as an EMA (server.py:113)
+        self.group_ok = self.n > 1 and all(getattr(p, "group", None) for p in pipelines)
+        self._prompt = object()               # nothing broadcast yet
+        self.prompt_syncs = 0
 
+    # ---- prompt broadcast
+    def _sync_prompt(self, options):
+        prompt = options.get("prompt", ["pixar, cg"])  # the reference's default (videopipeline.py:78)
+        key = prompt_key(prompt)
+        if not self.group_ok or key == self._prompt:
+            return
+        self._prompt = key
+        self.prompt_syncs += 1
+        header = {k: float(options[k]) for k in PROMPT_HEADER_KEYS if k in options and isinstance(options[k], (int, float))}
+        for g, p in enumerate(self.pipelines):
+            try:
+                fut = p.sync_prompt.remote(prompt, header)
+                fut.add_done_callback(lambda f, g=g: self._prompt_done(g, f))
+            except Exception:
+                self._group_broken(g)
+
+    def _prompt_done(self, gpu, fut):
+        if fut.cancelled() or fut.exception() is not None:
+            self._group_broken(gpu)
+
+    def _group_broken(self, gpu):
+        # a member is gone: the communicator cannot be repaired; every worker encodes for itself from now on
+        self.group_ok = False
+
+    # ---- frames
     def submit(self, frame, **options) -> Optional[int]:
         k = self.seq
         self.seq += 1
@@ -290,6 +730,7 @@ class FrameDispatcher:
         if self.busy[gpu] >= self.depth or not self.healthy[gpu]:
             self.dropped += 1
             return None
+        self._sync_prompt(options)
         self.busy[gpu] += 1
         ticket = self.submitted
         self.submitted += 1
@@ -302,14 +743,46 @@ class FrameDispatcher:
         try:
             img = await self.pipelines[gpu].infer.remote(frame, **options)
             self._done[ticket] = img
-        except Exception as e:  # a failed worker frees its slot (server.py:110-111) and is skipped afterwards
-            self.healthy[gpu] = False
+        except Exception as e:  # the slot is freed either way (server.py:110-111)
             self._done[ticket] = e
+            if is_caller_error(e):
+                self.caller_errors += 1      # a bad option is the session's problem, not the GPU's
+            else:
+                self.worker_faults += 1
+                self._mark_unhealthy(gpu)
         finally:
             self.busy[gpu] -= 1
             self._inflight.discard(ticket)
         self.avg_gen_time = 0.95 * self.avg_gen_time + 0.05 * (time.time() - t0)
         self._event.set()
+
+    def _mark_unhealthy(self, gpu):
+        if not self.healthy[gpu]:
+            return
+        self.healthy[gpu] = False
+        if getattr(self.pipelines[gpu], "group", None):
+            self._group_broken(gpu)
+        if self.respawn and hasattr(self.pipelines[gpu], "respawn") and not self._respawning[gpu]:
+            self._respawning[gpu] = True
+            asyncio.ensure_future(self._respawn(gpu))
+
+    async def _respawn(self, gpu):
+        loop = asyncio.get_running_loop()
+        old = self.pipelines[gpu]
+        try:
+            new = await loop.run_in_executor(None, old.respawn)  # model load + first prepare take seconds: off the loop
+            if self.warm_options is not None:
+                from PIL import Image
+
+                w, h = self.warm_options.get("width", 640), self.warm_options.get("height", 360)
+                await new.infer.remote(Image.new("RGB", (w, h)), **self.warm_options)
+            self.pipelines[gpu] = new
+            self.healthy[gpu] = True
+            self.respawns += 1
+        except Exception:
+            pass  # stays out of the rotation
+        finally:
+            self._respawning[gpu] = False
 
     async def next_result(self):
         """(ticket, image-or-exception)."""
@@ -331,3 +804,24 @@ class FrameDispatcher:
     @property
     def pending(self) -> int:
         return len(self._inflight) + len(self._done)
+
+    # ---- metrics (JSON lines; the reference prints an EMA and a watchdog dump: server.py:113-114, 344-349)
+    async def metrics(self) -> Dict[str, Any]:
+        per = []
+        for g, p in enumerate(self.pipelines):
+            m = {"gpu": g, "healthy": self.healthy[g], "busy": self.busy[g]}
+            if self.healthy[g] and hasattr(p, "metrics"):
+                try:
+                    m.update(await asyncio.wait_for(p.metrics.remote(), timeout=30))
+                except Exception as e:
+                    m["error"] = str(e)
+            per.append(m)
+        return {"submitted": self.submitted, "dropped": self.dropped, "caller_errors": self.caller_errors,
+                "worker_faults": self.worker_faults, "respawns": self.respawns, "prompt_syncs": self.prompt_syncs,
+                "group": bool(self.group_ok), "avg_gen_time_s": round(self.avg_gen_time, 4), "workers": per}
+
+    async def metrics_lines(self) -> List[str]:
+        """One JSON line per worker plus one for the dispatcher."""
+        m = await self.metrics()
+        workers = m.pop("workers")
+        return [json.dumps({"kind": "worker", **w}) for w in workers] + [json.dumps({"kind": "dispatcher", **m})]

@@ -179,6 +179,12 @@ class HipOps:
             out = src.to("cpu", non_blocking=False)
         return out
 
+    def download_into(self, dst_cpu: torch.Tensor, src: torch.Tensor):
+        """D2H into a (pinned) host tensor on the kernel stream, then wait for that stream."""
+        with torch.cuda.stream(self.stream):
+            dst_cpu.view(src.shape).copy_(src, non_blocking=True)
+        self.stream.synchronize()
+
     # ------------------------------------------------------------------ ops
     def conv(self, src0, src1, g: Geom, w: PackedConv, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None,
              residual2=None, ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0,

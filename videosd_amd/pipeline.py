@@ -10,6 +10,7 @@ What differs underneath: no diffusers / TensorRT / torch.compile; the frame goes
 videosd_amd.engine.Engine (libvsd.so HIP kernels replayed as one hipGraph).
 """
 import os
+import time
 import zlib
 from typing import Dict, List, Optional, Union
 
@@ -62,8 +63,10 @@ class VideoSDPipeline:
             raise
         self._prompt_key = None
         self._plan_key = None
-        self._engines = {}  # (plan_key, batch) -> prepared engine (the first one is self.model, the others are its slots)
+        self._engines = {}  # (plan_key, batch, lane) -> prepared engine (the first one is self.model, the others are its slots)
         self.max_plans = int(kwargs.get("max_plans", 8))
+        self._outstanding = []  # engines with a submitted, not yet collected launch
+        self._host_ms = {"crop_resize": [], "upload_enqueue": [], "wait_download": [], "to_pil": [], "gpu": [], "prepare": []}
 
     # ------------------------------------------------------------------ model loading
     def load_model(self, model_name, controlnet_model="lllyasviel/control_v11p_sd15_canny"):
@@ -124,10 +127,56 @@ class VideoSDPipeline:
         g = torch.Generator().manual_seed(zlib.crc32(("pooled:" + text).encode()))
         return (torch.randn(self.unet_cfg.add_pooled_dim, generator=g) * 0.5).half()
 
+    @property
+    def prompt_shape(self):
+        """Shape of the embeddings `set_prompt_embeds` takes (what the RCCL broadcast of dispatch.py carries)."""
+        return (77, self.unet_cfg.cross_dim)
+
     def set_prompt_embeds(self, embeds: torch.Tensor, key=None):
         """Install embeddings produced elsewhere (rank 0 broadcasts them over RCCL, dispatch.py)."""
+        self._require_idle("install new prompt embeddings")
         self.model.set_text_embeds(embeds)
         self._prompt_key = key
+        if self.is_xl:  # the added conditioning (pooled embedding) is baked into the time embeddings at `prepare`
+            self._pooled = self.encode_pooled(key if isinstance(key, str) else list(key or ()))
+            self._engines.clear()
+            self._plan_key = None
+
+    def _require_idle(self, what: str):
+        """Prompt constants (cross-attention K / V^T) and plans are shared by every lane: rewriting them under a launch
+        that is still running would hand that launch's caller another plan's frame."""
+        if self._outstanding:
+            raise RuntimeError(f"cannot {what} while {len(self._outstanding)} launch(es) are in flight: collect them first")
+
+    def _note(self, what: str, t0: float):
+        v = self._host_ms[what]
+        v.append((time.perf_counter() - t0) * 1e3)
+        if len(v) > 256:
+            del v[:128]
+
+    def metrics(self):
+        """Per-stage host / device milliseconds of this worker (medians over the last frames): where a frame's time goes
+        between `infer` entry and the PIL image (per-stage ms per GPU)."""
+        import statistics
+
+        out = {k: (round(statistics.median(v), 3) if v else None) for k, v in self._host_ms.items()}
+        out["plans_cached"] = len(self._engines)
+        return {"stage_ms_p50": out}
+
+    def stage_profile(self, batch: int = 1):
+        """Per-kernel-family device ms of ONE eager pass of the current plan (vsd_stage_times; the captured graph cannot be
+        bracketed per launch).  On demand only: it re-runs the program un-captured."""
+        self._require_idle("profile")
+        eng = self.model
+        if eng.plan is None:
+            raise RuntimeError("no plan prepared yet: call infer first")
+        ops = eng.ops
+        eng.program.run()
+        ops.synchronize()
+        ops.profile_begin()
+        eng.program.run()
+        ops.synchronize()
+        return {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in ops.profile_end().items()}
 
     # ------------------------------------------------------------------ per frame
     def infer(
@@ -168,9 +217,12 @@ class VideoSDPipeline:
         """First half of `infer_batch`: crop / resize, upload, enqueue -- returns a handle for `collect_batch` without
         waiting for the GPU.  `lane` picks one of the prepared engines of that (options, batch size): two lanes keep two
         launches in flight while the host works on the frames around them (the worker loop of dispatch.py does that)."""
+        t0 = time.perf_counter()
         imgs = [center_crop_resize(im, width, height) for im in imgs]
+        self._note("crop_resize", t0)
         pkey = prompt if isinstance(prompt, str) else tuple(prompt)
         if pkey != self._prompt_key:
+            self._require_idle("change the prompt")
             self.model.set_text_embeds(self.encode_prompt(prompt))
             self._prompt_key = pkey  # (the cross-attention K / V^T caches are rewritten in place: captured graphs stay valid)
             if self.is_xl:
@@ -183,15 +235,29 @@ class VideoSDPipeline:
         plan_key = (height, width, int(steps), float(strength), float(controlnet_scale), use_cn)
         eng = self._engine_for(plan_key, len(imgs), lane)
         np.random.seed(seed)  # kept for parity with videopipeline.py:112 (nothing downstream consumes it)
-        frames = np.stack([np.asarray(im.convert("RGB"), dtype=np.uint8) for im in imgs])
+        t0 = time.perf_counter()
+        frames = np.stack([np.asarray(im if im.mode == "RGB" else im.convert("RGB"), dtype=np.uint8) for im in imgs])
         eng.submit_u8(frames[0] if len(imgs) == 1 else frames)
+        self._outstanding.append(eng)
+        self._note("upload_enqueue", t0)
         return (eng, len(imgs))
 
     def collect_batch(self, handle):
         eng, n = handle
-        out = eng.collect_u8()
+        t0 = time.perf_counter()
+        try:
+            out = eng.collect_u8()
+        finally:
+            if eng in self._outstanding:
+                self._outstanding.remove(eng)
+        self._note("wait_download", t0)
+        if getattr(eng, "last_gpu_ms", None) is not None:
+            self._host_ms["gpu"].append(eng.last_gpu_ms)
         out = out[None] if n == 1 else out
-        return [Image.fromarray(o, mode="RGB") for o in out]
+        t0 = time.perf_counter()
+        res = [Image.fromarray(o, mode="RGB") for o in out]
+        self._note("to_pil", t0)
+        return res
 
     def _engine_for(self, plan_key, batch: int, lane: int = 0):
         """A prepared engine per (options, batch size, lane): the parent engine serves the first plan, slots (shared
@@ -199,9 +265,16 @@ class VideoSDPipeline:
         key = (plan_key, batch, lane)
         eng = self._engines.get(key)
         if eng is not None:
+            if eng in self._outstanding:
+                raise RuntimeError("this lane's previous launch has not been collected")
             return eng
         height, width, steps, strength, cn_scale, use_cn = plan_key
-        if plan_key != self._plan_key or len(self._engines) >= self.max_plans:
+        t0 = time.perf_counter()
+        # a new plan re-prepares the parent engine (and drops its slots); so does a full cache -- but never under a
+        # launch that is still running: the cache just grows until the lanes are idle
+        evict = len(self._engines) >= self.max_plans and not self._outstanding
+        if plan_key != self._plan_key or evict:
+            self._require_idle("prepare another plan")
             self._engines.clear()
             self.model.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch)
             self._plan_key = plan_key
@@ -210,6 +283,7 @@ class VideoSDPipeline:
             eng = self.model.make_slot()
             eng.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch)
         self._engines[key] = eng
+        self._note("prepare", t0)
         return eng
 
     # `VideoSDPipeline.remote(**config)` -> awaitable handle (replaces the Ray actor API, server.py:320-321)
@@ -218,6 +292,13 @@ class VideoSDPipeline:
         from .dispatch import RemotePipeline
 
         return RemotePipeline(**config)
+
+    @classmethod
+    def remote_group(cls, gpus: int, **config):
+        """`gpus` workers, one per GPU, in one RCCL process group (config.yaml `gpus: N`, server.py:273-274, 317-321)."""
+        from .dispatch import spawn_workers
+
+        return spawn_workers(int(gpus), **config)
 
 
 VideoPipeline = VideoSDPipeline  # BASELINE.json's north_star calls the class by this name
