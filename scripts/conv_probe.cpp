@@ -1,6 +1,6 @@
 // Standalone timing probe of csrc/conv_gemm.hip (not part of libvsd): builds the kernel with -DVSD_CONV_PROBE, runs one
 // conv / linear problem and prints the launch time and where wave 0 of workgroup 0 spent its shader clocks.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DVSD_CONV_PROBE scripts/conv_probe.cpp videosd_amd/csrc/conv_gemm.hip \
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DVSD_CONV_PROBE scripts/conv_probe.cpp videosd_amd/csrc/conv_gemm.hip videosd_amd/csrc/conv_t*.hip videosd_amd/csrc/conv_halo.hip \
 //         videosd_amd/csrc/api.hip -o scripts/conv_probe.bin
 // usage: conv_probe.bin H W Cin Cout ksize tile pipeline split batch [residual]
 #include <hip/hip_runtime.h>

@@ -264,6 +264,44 @@ def test_fused_layernorm_producer_rowstats_and_consumer(ops, m, c):
     check(f, hid * F.gelu(gate), "ln->geglu", rel=3e-3)
 
 
+@pytest.mark.parametrize("c", [320, 1280])
+def test_fused_layernorm_on_rows_with_a_large_mean_and_outlier_channels(ops, c):
+    """the folded LayerNorm computes rstd * (x.W' - mean * s) from one-pass (sum, sumsq) partials -- two large
+    terms cancel.  Real SD residual streams have rows with |mean| >> std and a few outlier channels; check that regime
+    (mean 50, std 0.5, four channels 100x larger) against an explicit fp32 LayerNorm + linear of the same fp16 rows."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_geglu_ln, pack_linear, pack_linear_ln
+
+    m = 256
+    g = torch.Generator().manual_seed(5)
+    h0 = 50.0 + 0.5 * torch.randn(m, c, generator=g)
+    h0[:, [3, 77, 130, c - 5]] *= 100.0
+    # the rows reach the consumer through a producer GEMM (identity weights) that also leaves the row partials
+    eye = torch.eye(c).half()
+    p0 = ops.to_device_pack(pack_linear(eye, None))
+    h = torch.zeros(m, c, dtype=torch.float16, device="cuda")
+    rs = torch.zeros(m, c // 64, 2, dtype=torch.float32, device="cuda")
+    ops.conv(h0.half().cuda(), None, Geom.linear(m), p0, h, rowstat_out=rs, tile=2)
+    ops.synchronize()
+    hq = h.float().cpu()
+    assert torch.equal(hq, h0.half().float())
+    gamma, beta = (1 + 0.1 * rnd(c, seed=5).float()).half(), rnd(c, seed=6, scale=0.1)
+    ln = F.layer_norm(hq, (c,), gamma.float(), beta.float(), 1e-5)
+    wq = rnd(c, c, seed=7, scale=c ** -0.5)
+    pq = ops.to_device_pack(pack_linear_ln([wq], None, gamma, beta))
+    q = torch.zeros(m, c, dtype=torch.float16, device="cuda")
+    ops.conv(h, None, Geom.linear(m), pq, q, ln_part=rs, tile=2)
+    ops.synchronize()
+    check(q, F.linear(ln, wq.float()), "ln(large mean)->q", rel=5e-3)
+    wf, bf = rnd(8 * c, c, seed=10, scale=c ** -0.5), rnd(8 * c, seed=11, scale=0.1)
+    pf = ops.to_device_pack(pack_geglu_ln(wf, bf, gamma, beta))
+    f = torch.zeros(m, 4 * c, dtype=torch.float16, device="cuda")
+    ops.conv(h, None, Geom.linear(m), pf, f, ln_part=rs)
+    ops.synchronize()
+    hid, gate = F.linear(ln, wf.float(), bf.float()).chunk(2, dim=-1)
+    check(f, hid * F.gelu(gate), "ln(large mean)->geglu", rel=5e-3)
+
+
 def test_qkv_transposed_output_and_dual_output(ops):
     from videosd_amd.ops import Geom
     from videosd_amd.packing import pack_linear_cat
@@ -400,6 +438,28 @@ def test_attention(ops, sq, sk, heads, d, causal):
     ops.attention(q.cuda(), c, k.cuda(), c, vt.cuda(), ldvt, out, c, sq, sk, heads, d, scale, causal)
     ops.synchronize()
     check(out, attention_ref(q, k, v, heads, scale, causal), f"attention {sq}x{sk} h{heads} d{d}", rel=3e-3)
+
+
+@pytest.mark.parametrize("sq,sk,heads,d", [(4096, 4096, 8, 40), (1024, 1024, 8, 80), (1024, 77, 8, 80)])
+def test_attention_with_peaked_softmax_rows(ops, sq, sk, heads, d):
+    """N(0, 1/sqrt(fan_in)) weights give near-uniform softmax rows.  Trained attention has logits with
+    a dynamic range of 10-30: a few keys take almost all the mass, the running maximum is raised many times along the
+    key loop and most probabilities underflow to 0 in fp16.  Logit spread here: std ~6, |s| up to ~30."""
+    c = heads * d
+    g = torch.Generator().manual_seed(11)
+    q = (torch.randn(sq, c, generator=g) * 2.5).half()
+    k = (torch.randn(sk, c, generator=g) * 2.5).half()
+    v = torch.randn(sk, c, generator=g).half()
+    ldvt = (sk + 63) // 64 * 64
+    vt = torch.zeros(c, ldvt, dtype=torch.float16)
+    vt[:, :sk] = v.t()
+    out = torch.zeros(sq, c, dtype=torch.float16, device="cuda")
+    scale = d ** -0.5
+    s0 = (q[:, :d].float() @ k[:, :d].float().t()) * scale
+    assert 4.0 < float(s0.std()) < 9.0 and float(s0.abs().max()) > 20.0
+    ops.attention(q.cuda(), c, k.cuda(), c, vt.cuda(), ldvt, out, c, sq, sk, heads, d, scale, False)
+    ops.synchronize()
+    check(out, attention_ref(q, k, v, heads, scale), f"peaked attention {sq}x{sk} d{d}", rel=4e-3)
 
 
 def test_preprocess_and_postprocess(ops):

@@ -6,44 +6,90 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvsd.so")
-SOURCES = ["api.hip", "conv_gemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+# the implicit-GEMM conv kernel is a template with ~60 instantiations: one translation unit per tile family, so that
+# the families compile in parallel (as one file the library took 4.5 minutes to build)
+SOURCES = ["api.hip", "conv_gemm.hip", "conv_t128x128.hip", "conv_t128x64.hip", "conv_t64x64.hip", "conv_t64x128.hip",
+           "conv_t256x128.hip", "conv_halo.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+HEADERS = ["common.h", "conv_kernels.h", os.path.join("..", "..", "include", "vsd.h")]
 # attention keeps its O / S accumulators live across the key loop and touches them with VALU every tile (online-softmax
 # rescale, exp): with the default AGPR placement the compiler moves them through v_accvgpr_read/write every tile
 # (~190 of 1300 instructions in the d=40 kernel); VGPR-form MFMA operands remove those moves.
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def _obj(f: str) -> str:
+    return os.path.join(HERE, "build", f.replace(".hip", ".o"))
+
+
+def _stale(f: str) -> bool:
+    o = _obj(f)
+    if not os.path.exists(o):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "vsd.h")]
+    t = os.path.getmtime(o)
+    deps = [os.path.join(CSRC, f)] + [os.path.join(CSRC, h) for h in HEADERS]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def needs_build() -> bool:
+    return not os.path.exists(LIB) or any(_stale(f) or os.path.getmtime(_obj(f)) > os.path.getmtime(LIB) for f in SOURCES)
+
+
+def build(force: bool = False, verbose: bool = True, jobs: int = 0) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    for f in SOURCES:
-        o = os.path.join(HERE, "build", f.replace(".hip", ".o"))
-        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"] + EXTRA_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", o]
+    todo = [f for f in SOURCES if force or _stale(f)]
+    jobs = jobs or min(len(todo), os.cpu_count() or 4) or 1
+    running = []
+
+    def reap(block_until: int):
+        while len(running) > block_until:
+            p, f = running.pop(0)
+            if p.wait() != 0:
+                for q, _ in running:
+                    q.kill()
+                raise RuntimeError(f"hipcc failed on {f}")
+
+    for f in todo:
+        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"] + EXTRA_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", _obj(f)]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((subprocess.Popen(cmd), f))
-        objs.append(o)
-    for p, f in procs:
-        if p.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {f}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        running.append((subprocess.Popen(cmd), f))
+        reap(jobs - 1)
+    reap(0)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
 
 
+def build_probe(verbose: bool = False) -> str:
+    """scripts/conv_probe.bin: the conv kernels built with -DVSD_CONV_PROBE (in-kernel cycle stamps) + the probe driver."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    root = os.path.dirname(HERE)
+    out = os.path.join(root, "scripts", "conv_probe.bin")
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    srcs = [f for f in SOURCES if f.startswith("conv_") or f == "api.hip"]
+    procs, objs = [], []
+    for f in srcs:
+        o = os.path.join(HERE, "build", "probe_" + f.replace(".hip", ".o"))
+        objs.append(o)
+        procs.append((subprocess.Popen([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-DVSD_CONV_PROBE", "-w", "-c",
+                                        os.path.join(CSRC, f), "-o", o]), f))
+    for p, f in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {f}")
+    drv = os.path.join(HERE, "build", "probe_main.o")
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-DVSD_CONV_PROBE", "-w", "-c",
+                           os.path.join(root, "scripts", "conv_probe.cpp"), "-o", drv])
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-o", out, drv] + objs)
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--probe" in sys.argv:
+        print(build_probe())
+    else:
+        build(force="--force" in sys.argv)

@@ -1,0 +1,1158 @@
+// (shared by the conv_*.hip translation units: the kernel templates are compiled where they are instantiated, one tile
+// family per file, so that the files build in parallel)
+//
+// Implicit-GEMM convolution / linear layer on MFMA (gfx950, wave64, v_mfma_f32_16x16x32_f16).
+//
+//   out[m][n] = epilogue( sum_k A[m][k] * W[n][k] )
+//
+// A is never materialised: each 64-wide K tile is gathered straight from the NHWC source(s)
+// (3x3 taps, stride, zero padding, nearest resize and channel concat are all address arithmetic in
+// the tile loader).  Tiles are staged global -> registers -> LDS (XOR-swizzled 128-B rows, conflict
+// free for ds_read_b128 fragment reads), double buffered with one barrier per K tile; the next
+// tile's global loads are issued before the current tile's MFMAs (issue-early / write-late).
+// The accumulator tile is transposed through LDS so that bias / residual reads and the output
+// stores are 16-byte row-contiguous.  K can be split across workgroups (fp32 slabs + a reduce
+// kernel that applies the same epilogue) for the small-M, huge-K layers of the 16x16 / 8x8 levels.
+//
+// Algorithmic work per launch: 2*M*N*K FLOP, fp16 bytes: N*Kp (weights) + M*Cin (input) + M*N (output).
+#pragma once
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+constexpr int BK = 64;  // halfs per K tile (128-byte LDS rows)
+
+struct ConvParams {
+  const half_t* src0;
+  const half_t* src1;
+  int c0, c1, cin;
+  int hs, ws, hi, wi, ho, wo;
+  int ksize, stride, pad;
+  int resize;   // hi != hs || wi != ws
+  unsigned rmul_y, rmul_x;  // resize: ceil(hs * 2^22 / hi), source row = (iy * rmul_y) >> 22; else 1 and shift 0
+  int rshift;
+  int generic;  // cin % 64 != 0: per-chunk tap computation
+  int fast;     // buffer-load address path usable: !generic, no resize, every operand < 2 GB
+  int halo_ok;  // the same without the "no resize" condition (the halo kernel folds the nearest resize into its patch fetch)
+  const half_t* w;
+  int M, N, K, Kp;
+  const half_t* bias;
+  const half_t* rowvec;
+  const half_t* residual;
+  const half_t* residual2;
+  int ldr;
+  float out_scale;
+  int act;
+  half_t* out;
+  int ldo;
+  half_t* out2;
+  const half_t* add2;
+  half_t* out_t;
+  int ldt, t_col0;
+  int split_k, kt_per_split;
+  float* ws_partial;
+  float* rowstat_out;    // [M][N/64][2]: per-row (sum, sumsq) of the fp16 outputs over each 64-column group
+  float* chanstat_part;  // [tiles_m][N][2] scratch: per-tile column (sum, sumsq) of the fp16 outputs
+  float* chanstat_out;   // [N][2]: per-channel (sum, sumsq) over all M rows -- the next GroupNorm's statistics
+  int* chan_counters;    // [tiles_n] arrival tickets (all zero between launches)
+  const float* ln_part;  // fused input LayerNorm: row partials of the A operand, [M][ln_groups][2]
+  int ln_groups;
+  float ln_eps;
+  const float* ln_s;     // [N] sum_k W'[n][k]  (W' = W * gamma)
+  const float* ln_t;     // [N] sum_k beta[k] W[n][k] + bias[n]
+  const half_t* zeros;  // >= 16 zero bytes: source of out-of-bounds chunks for the direct-to-LDS loader
+  int* counters;  // per-tile arrival tickets for the in-kernel split-K reduction (all zero between launches)
+  int tiles_m, tiles_n;
+  int order;    // block_to_tile: 0 = workgroups sharing a weight tile share an XCD, 1 = workgroups sharing input rows do
+#ifdef VSD_CONV_PROBE
+  long long* probe;  // scripts/conv_probe.cpp: per-section shader-clock totals of wave 0 of workgroup 0
+#endif
+  int batch;    // images stacked along M: M = batch * ho * wo, image b's source pixels start at b * hs * ws
+  int hw_out;   // ho * wo
+  int img_in;   // hs * ws
+  int t_img;    // transposed output: columns per image (image b's rows m land at b * t_img + (m - b * hw_out))
+};
+
+#ifdef VSD_CONV_PROBE
+inline long long* g_conv_probe = nullptr;
+#define CPROBE(I_)                                         \
+  {                                                        \
+    long long t_ = __builtin_readcyclecounter();           \
+    pacc[I_] += t_ - plast;                                \
+    plast = t_;                                            \
+  }
+#define CPROBE_OUT()                                                                       \
+  if (p.probe && blockIdx.x == 0 && threadIdx.x == 0)                                      \
+    for (int i_ = 0; i_ < 8; ++i_) p.probe[i_] = pacc[i_];
+#else
+#define CPROBE(I_)
+#define CPROBE_OUT()
+#endif
+
+
+// launchers of the tile families (one translation unit each; conv_gemm.hip dispatches)
+void vsd_launch_conv_128x128(const ConvParams& p, int grid, int stages, hipStream_t s);
+void vsd_launch_conv_128x64(const ConvParams& p, int grid, int stages, hipStream_t s);
+void vsd_launch_conv_64x64(const ConvParams& p, int grid, int stages, hipStream_t s);   // stages 8: the 8-stage ring
+void vsd_launch_conv_64x128(const ConvParams& p, int grid, int stages, hipStream_t s);
+void vsd_launch_conv_256x128(const ConvParams& p, int grid, int stages, hipStream_t s);
+void vsd_launch_conv_halo(const ConvParams& p, int bm, int bn, int grid, hipStream_t s);
+void vsd_launch_splitk_reduce(const ConvParams& p, int grid, hipStream_t s);
+
+namespace {
+
+// ---------------------------------------------------------------- epilogue (shared with the reducer)
+__device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int n, float (&v)[8], float& rsum, float& rsq,
+                                                const half8* res_pre = nullptr, const float* brv_pre = nullptr) {
+  // n is a multiple of 8; handles n + 8 > N by scalar fallback
+  // res_pre / brv_pre: the residual chunk / bias + rowvec of these 8 columns, loaded by the caller BEFORE its first
+  // store (vmcnt counts stores too: a load issued after a store is only waited for once that store has retired)
+  const bool full = (n + 8 <= p.N);
+  if (brv_pre) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += brv_pre[i];
+  } else {
+  if (p.bias) {
+    if (full) {
+      half8 b = *reinterpret_cast<const half8*>(p.bias + n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += (float)b[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (n + i < p.N) v[i] += (float)p.bias[n + i];
+    }
+  }
+  if (p.rowvec) {
+    if (full) {
+      half8 b = *reinterpret_cast<const half8*>(p.rowvec + n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += (float)b[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (n + i < p.N) v[i] += (float)p.rowvec[n + i];
+    }
+  }
+  }
+  const int act = p.act & 0xff;
+  const bool post = (p.act & VSD_ACT_POST) != 0;
+  auto apply_act = [&](float x) -> float {
+    if (act == VSD_ACT_RELU) return fmaxf(x, 0.0f);
+    if (act == VSD_ACT_SILU) return silu_f(x);
+    if (act == VSD_ACT_QUICKGELU) return quick_gelu_f(x);
+    return x;
+  };
+  if (act != VSD_ACT_NONE && !post) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i]);
+  }
+  if (p.out_scale != 1.0f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= p.out_scale;
+  }
+  if (p.out_t && n >= p.t_col0) {
+    int col = m;
+    if (p.batch > 1) {
+      const int b = m / p.hw_out;
+      col = b * p.t_img + (m - b * p.hw_out);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (n + i < p.N) p.out_t[(size_t)(n + i - p.t_col0) * p.ldt + col] = (half_t)v[i];
+    return;
+  }
+  if (full) {
+    if (p.residual) {
+      half8 r = res_pre ? *res_pre : *reinterpret_cast<const half8*>(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += (float)r[i];
+    }
+    if (p.residual2) {
+      half8 r = *reinterpret_cast<const half8*>(p.residual2 + (size_t)m * p.ldr + n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += (float)r[i];
+    }
+    if (post) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i]);
+    }
+    half8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      o[i] = (half_t)v[i];
+      float f = (float)o[i];
+      v[i] = f;  // hand the rounded value back: the fused statistics are those of the stored tensor
+      rsum += f;
+      rsq += f * f;
+    }
+    *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
+    if (p.out2) {
+      half8 a = *reinterpret_cast<const half8*>(p.add2 + (size_t)m * p.ldo + n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (half_t)(v[i] + (float)a[i]);
+      *reinterpret_cast<half8*>(p.out2 + (size_t)m * p.ldo + n) = o;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (n + i >= p.N) continue;
+      float x = v[i];
+      if (p.residual) x += (float)p.residual[(size_t)m * p.ldr + n + i];
+      if (p.residual2) x += (float)p.residual2[(size_t)m * p.ldr + n + i];
+      if (post) x = apply_act(x);
+      p.out[(size_t)m * p.ldo + n + i] = (half_t)x;
+      if (p.out2) p.out2[(size_t)m * p.ldo + n + i] = (half_t)(x + (float)p.add2[(size_t)m * p.ldo + n + i]);
+    }
+  }
+}
+
+// Fused input LayerNorm: the GEMM ran on the raw rows x with W' = W*gamma, so
+//   LN(x) W^T + b = rstd * (x W'^T - mean * s) + t,   s[n] = sum_k W'[n][k],  t[n] = sum_k beta[k] W[n][k] + b[n].
+// Row mean / rstd come from the (sum, sumsq) partials the producing kernel's epilogue left per 64-column group.
+__device__ __forceinline__ void ln_row_stats(const ConvParams& p, int m, float& mean, float& rstd) {
+  // partials of one row are contiguous: [M][ln_groups][2]; ln_groups is a multiple of... anything >= 1
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2* src = reinterpret_cast<const f32x2*>(p.ln_part) + (size_t)m * p.ln_groups;
+  float S = 0.f, Q = 0.f;
+  int g = 0;
+  for (; g + 4 <= p.ln_groups; g += 4) {  // four independent loads in flight
+    f32x2 a = src[g], b = src[g + 1], c = src[g + 2], d = src[g + 3];
+    S += a[0]; Q += a[1];
+    S += b[0]; Q += b[1];
+    S += c[0]; Q += c[1];
+    S += d[0]; Q += d[1];
+  }
+  for (; g < p.ln_groups; ++g) {
+    f32x2 a = src[g];
+    S += a[0]; Q += a[1];
+  }
+  const float inv = 1.0f / (float)p.K;
+  mean = S * inv;
+  rstd = rsqrtf(fmaxf(Q * inv - mean * mean, 0.f) + p.ln_eps);
+}
+__device__ __forceinline__ void ln_transform8(const ConvParams& p, int n, float mean, float rstd, float (&v)[8]) {
+  if (n + 8 <= p.N) {
+    f32x4 s0 = *reinterpret_cast<const f32x4*>(p.ln_s + n), s1 = *reinterpret_cast<const f32x4*>(p.ln_s + n + 4);
+    f32x4 t0 = *reinterpret_cast<const f32x4*>(p.ln_t + n), t1 = *reinterpret_cast<const f32x4*>(p.ln_t + n + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = rstd * (v[i] - mean * s0[i]) + t0[i];
+      v[4 + i] = rstd * (v[4 + i] - mean * s1[i]) + t1[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (n + i < p.N) v[i] = rstd * (v[i] - mean * p.ln_s[n + i]) + p.ln_t[n + i];
+  }
+}
+
+// 8 consecutive fp32 outputs of row r / column c8 of this tile: from the LDS-staged accumulators, or (last
+// arriver of a split-K tile) the sum of all slabs in the fixed order 0..split_k-1 (deterministic).
+__device__ __forceinline__ void load_chunk8(const ConvParams& p, const float* Cs, int pitch, bool from_slabs, int r, int c8,
+                                            int m, int n, float (&v)[8]) {
+  if (!from_slabs) {
+    f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * pitch + c8);
+    f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * pitch + c8 + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = lo[i];
+      v[4 + i] = hi[i];
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  const size_t slab = (size_t)p.M * p.N;
+  const float* s = p.ws_partial + (size_t)m * p.N + n;
+  if (n + 8 <= p.N) {
+    for (int k = 0; k < p.split_k; ++k) {
+      f32x4 lo = *reinterpret_cast<const f32x4*>(s + k * slab);
+      f32x4 hi = *reinterpret_cast<const f32x4*>(s + k * slab + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] += lo[i];
+        v[4 + i] += hi[i];
+      }
+    }
+  } else {
+    for (int k = 0; k < p.split_k; ++k) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (n + i < p.N) v[i] += s[k * slab + i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- block -> tile (XCD-aware)
+// Workgroups b and b+8 share an XCD (round-robin dispatch) and each XCD has its own L2, so the order decides how often an
+// operand crosses the fabric.  order 0: the tiles_m workgroups that stream the SAME weight tile (same tile_n / split) get
+// ids b, b+8, b+16, ...: a weight tile is fetched into ONE L2, the activation rows into every L2 whose workgroups need
+// them (up to 8) -- right when the weights are the big operand (the deep levels).  order 1: the tiles_n * split_k
+// workgroups that read the SAME activation rows (same tile_m) share the XCD instead: the rows cross the fabric once, the
+// (small) weights up to 8 times -- right for the wide, shallow layers of the 64x64 / 32x32 levels and TAESD, where round 1's
+// counters showed every N tile's XCD re-fetching the input rows (51 MB of fabric traffic per launch against 21 MB of
+// operands).  The host picks the cheaper one per launch.  Pure speed: any placement gives the same result.
+__device__ __forceinline__ void block_to_tile(const ConvParams& p, int bid, int& tile_m, int& grp) {
+  const int G = p.tiles_n * p.split_k;
+  const int P = p.order ? p.tiles_m : G;   // spread over the XCDs
+  const int S = p.order ? G : p.tiles_m;   // share one XCD
+  const int full = (P >> 3) << 3;
+  int prim, sec;
+  if (bid < full * S) {
+    const int span = 8 * S;
+    const int chunk = bid / span, r = bid - chunk * span;
+    prim = chunk * 8 + (r & 7);
+    sec = r >> 3;
+  } else {
+    const int rem = bid - full * S;
+    prim = full + rem / S;
+    sec = rem - (rem / S) * S;
+  }
+  tile_m = p.order ? prim : sec;
+  grp = p.order ? sec : prim;
+}
+
+// ---------------------------------------------------------------- main kernel
+// STAGES == 0: register-staged double buffer (global -> VGPR -> LDS), one tile of prefetch.
+// STAGES >= 3: direct-to-LDS ring (global_load_lds, 16 B per lane) with STAGES-1 tiles in flight behind counted
+//              vmcnt waits and raw barriers; the XOR swizzle is applied on the per-lane SOURCE address because a
+//              wave's LDS-DMA destination is lane-linear; out-of-bounds chunks read a zero page.
+// FAST (direct-to-LDS ring, cin % 64 == 0, no resize): the per-tile operand addresses come almost for free.  The
+//   generic issue path recomputes tap / channel / bounds / 64-bit addresses for every 16-byte chunk of every K tile
+//   (~160 instructions, a dozen quarter-rate integer multiplies and a scalar division per tile -- 3x the issue time
+//   of the 16 MFMAs they feed).  Here every chunk is a raw BUFFER load to LDS: the per-row byte offset of the tile
+//   row's CENTRE pixel and a 9-bit "which taps are inside the image" mask are computed once; per K tile the tap /
+//   channel displacement is ONE scalar (the instruction's soffset, kept by an incremental scalar cursor instead of a
+//   division), an out-of-image tap turns the lane's offset into an out-of-range one (the buffer unit then writes
+//   zeros into LDS: the conv's zero padding), and the weight rows need no vector instruction at all.
+template <int BM, int BN, bool GENERIC, int STAGES, bool ILV, bool FAST>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+  constexpr int WM = 2, WN = 2;             // 2x2 waves
+  constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
+  constexpr int FM = TM / 16, FN = TN / 16;  // 16x16 fragments per wave
+  constexpr int AR = BM / 32, BR = BN / 32;  // 16-byte chunks per thread per K tile
+  constexpr int BNP = BN + 4;                // fp32 epilogue row pitch
+  constexpr int NBUF = STAGES == 0 ? 2 : STAGES;
+  constexpr int STAGE_HALFS = (BM + BN) * BK;
+  constexpr int STAGE_BYTES = NBUF * STAGE_HALFS * 2;
+  constexpr int EPI_BYTES = BM * BNP * 4;
+  constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + BM * 8];  // + per-row (mean, rstd) of a fused LN
+  half_t* As = reinterpret_cast<half_t*>(smem);                                        // register path: [2][BM][64]
+  half_t* Bs = reinterpret_cast<half_t*>(smem) + 2 * BM * BK;                          //                [2][BN][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // block -> (tile_m, tile_n, split).  Workgroups b and b+8 share an XCD (round-robin dispatch), so the tiles_m
+  // workgroups that stream the SAME weight tile (same tile_n / split) are given ids b, b+8, b+16, ...: the tile is
+  // then fetched into one XCD's L2 once instead of once per XCD.  Pure speed: any placement gives the same result.
+  int tile_m, grp;
+  block_to_tile(p, blockIdx.x, tile_m, grp);
+  const int tile_n = grp % p.tiles_n;
+  const int split = grp / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int KT = p.Kp / BK;
+  const int kt_begin = split * p.kt_per_split;
+  const int kt_end = min(KT, kt_begin + p.kt_per_split);
+
+  // ---- loader coordinates
+  const int cc = tid & 7;    // 16-byte chunk within the 128-byte tile row
+  const int lr = tid >> 3;   // 0..31
+  int iy0[AR], ix0[AR], ib[AR];  // ib: first source pixel of the row's image
+  bool mvalid[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    int m = m0 + lr + 32 * i;
+    mvalid[i] = m < p.M;
+    int mm = mvalid[i] ? m : 0;
+    int b = 0;
+    if (p.batch > 1) {
+      b = mm / p.hw_out;
+      mm -= b * p.hw_out;
+    }
+    ib[i] = b * p.img_in;
+    int oy = mm / p.wo, ox = mm - oy * p.wo;
+    iy0[i] = oy * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.pad;
+  }
+  const half_t* wrow[BR];
+  bool nvalid[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    int n = n0 + lr + 32 * i;
+    nvalid[i] = n < p.N;
+    wrow[i] = p.w + (size_t)(nvalid[i] ? n : 0) * p.Kp + cc * 8;
+  }
+
+  u32x4 areg[AR], breg[BR];
+  const u32x4 zero4 = (u32x4){0u, 0u, 0u, 0u};
+
+// Tile loader (macro, not a lambda: keeps areg/breg in registers).  Loads are unconditional from a
+// clamped, always-valid address and zeroed by a select, so there is no divergent control flow.
+#define VSD_LOAD_TILE(KT_)                                                                          \
+  {                                                                                                 \
+    const int kt_ = (KT_);                                                                          \
+    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                \
+      u32x4 v = *reinterpret_cast<const u32x4*>(wrow[i] + (size_t)kt_ * BK);                        \
+      breg[i] = nvalid[i] ? v : zero4;                                                              \
+    }                                                                                               \
+    int k_, cs_;                                                                                    \
+    const half_t* src_;                                                                             \
+    bool kok_ = true;                                                                               \
+    if (!GENERIC) {                                                                                 \
+      k_ = kt_ * BK; /* uniform: the whole tile lies inside one tap and one source */              \
+    } else {                                                                                        \
+      k_ = kt_ * BK + cc * 8;                                                                       \
+      kok_ = k_ < p.K;                                                                              \
+    }                                                                                               \
+    const int tap_ = k_ / p.cin;                                                                    \
+    int c_ = k_ - tap_ * p.cin;                                                                     \
+    const int ky_ = tap_ / p.ksize, kx_ = tap_ - ky_ * p.ksize;                                     \
+    if (!GENERIC && c_ >= p.c0) {                                                                   \
+      src_ = p.src1; cs_ = p.c1; c_ -= p.c0;                                                        \
+    } else {                                                                                        \
+      src_ = p.src0; cs_ = p.c0;                                                                    \
+    }                                                                                               \
+    if (!GENERIC) c_ += cc * 8;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                \
+      int iy = iy0[i] + ky_, ix = ix0[i] + kx_;                                                     \
+      bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi; \
+      /* nearest resize as a fixed-point multiply: floor(i*hs/hi) exactly for i*hi < 2^22 (identity: 2^22) */ \
+      const int sy = (int)(((unsigned)iy * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)ix * p.rmul_x) >> p.rshift); \
+      size_t off = ok ? ((size_t)(ib[i] + sy * p.ws + sx)) * cs_ + c_ : 0;                                  \
+      u32x4 v = *reinterpret_cast<const u32x4*>(src_ + off);                                        \
+      areg[i] = ok ? v : zero4;                                                                     \
+    }                                                                                               \
+  }
+#define VSD_STORE_TILE(BUF_)                                                                        \
+  {                                                                                                 \
+    half_t* a_ = As + (BUF_) * BM * BK;                                                             \
+    half_t* b_ = Bs + (BUF_) * BN * BK;                                                             \
+    _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                \
+      int r = lr + 32 * i;                                                                          \
+      *reinterpret_cast<u32x4*>(a_ + r * BK + ((cc ^ (r & 7)) << 3)) = areg[i];                     \
+    }                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                \
+      int r = lr + 32 * i;                                                                          \
+      *reinterpret_cast<u32x4*>(b_ + r * BK + ((cc ^ (r & 7)) << 3)) = breg[i];                     \
+    }                                                                                               \
+  }
+
+#ifdef VSD_CONV_PROBE
+  long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long plast = __builtin_readcyclecounter();
+#endif
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float* rowms = reinterpret_cast<float*>(smem + LDS_BYTES);  // per-row (mean, rstd) of a fused input LayerNorm
+// issued right after the prologue tile loads so that its memory latency overlaps theirs
+#define VSD_LN_ROWSTATS()                                              \
+  if (p.ln_part && tid < BM) {                                         \
+    float mean = 0.f, rstd = 0.f;                                      \
+    if (m0 + tid < p.M) ln_row_stats(p, m0 + tid, mean, rstd);         \
+    rowms[2 * tid] = mean;                                             \
+    rowms[2 * tid + 1] = rstd;                                         \
+  }
+  const int fr = lane & 15;  // fragment row (A) / column (B)
+  const int fq = lane >> 4;  // k-chunk quarter
+
+  if constexpr (STAGES == 0) {
+    if (kt_begin < kt_end) {
+      VSD_LOAD_TILE(kt_begin)
+      VSD_LN_ROWSTATS()
+      VSD_STORE_TILE(0)
+    } else {
+      VSD_LN_ROWSTATS()
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int buf = (kt - kt_begin) & 1;
+      const bool more = kt + 1 < kt_end;
+      if (more) VSD_LOAD_TILE(kt + 1)
+      const half_t* a = As + buf * BM * BK;
+      const half_t* b = Bs + buf * BN * BK;
+  #pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        half8 af[FM], bf[FN];
+  #pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          int r = wm * TM + i * 16 + fr;
+          af[i] = *reinterpret_cast<const half8*>(a + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+        }
+  #pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          int r = wn * TN + j * 16 + fr;
+          bf[j] = *reinterpret_cast<const half8*>(b + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+        }
+  #pragma unroll
+        for (int i = 0; i < FM; ++i)
+  #pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) VSD_STORE_TILE(buf ^ 1)
+      __syncthreads();
+    }
+  } else {
+    // ------------------------------------------------------------ direct-to-LDS ring
+    constexpr int LPT = AR + BR;            // LDS-DMA instructions per thread per tile
+    const int lc = cc ^ (lr & 7);           // logical 16-byte chunk this lane fetches; it lands in slot cc of its row
+    const int nt = kt_end - kt_begin;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    // ---- FAST path state (see the kernel's header comment)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // scalar: the DMA's LDS base goes to M0 without a v_readfirstlane
+    [[maybe_unused]] int apix[AR];          // centre pixel (oy*stride, ox*stride) of the row, in pixels from the tensor start
+    [[maybe_unused]] unsigned tapmask[AR];  // bit (ky*ksize + kx): that tap of this row lies inside the image
+    [[maybe_unused]] int bvoff[BR];         // weight row byte offset (+ this lane's chunk), or out of range
+    [[maybe_unused]] int cur_c = 0, cur_tap = 0, cur_ky = 0, cur_kx = 0, cur_kt = kt_begin;  // scalar cursor: next tile to fetch
+    // the A descriptors start (pad*ws + pad) pixels BEFORE the tensor: soffset = (ky*ws + kx)*cs*2 + c*2 is then
+    // never negative; a lane only ever adds it to a centre pixel whose tap is inside the image.  (Descriptors are
+    // rebuilt from these scalars per tile: a handful of SALU moves.)
+    const int neg_pix = p.pad * p.ws + p.pad;
+    [[maybe_unused]] const half_t* abase0 = p.src0 - (size_t)neg_pix * p.c0;
+    [[maybe_unused]] const half_t* abase1 = (p.src1 ? p.src1 : p.src0) - (size_t)neg_pix * p.c1;
+    [[maybe_unused]] const int anr0 = (int)(((size_t)p.batch * p.img_in + neg_pix) * p.c0 * 2);
+    [[maybe_unused]] const int anr1 = (int)(((size_t)p.batch * p.img_in + neg_pix) * p.c1 * 2);
+    [[maybe_unused]] const int bnr = (int)((size_t)p.N * p.Kp * 2);
+    constexpr int OOB = (int)0x80000000;
+    if constexpr (FAST) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        apix[i] = ib[i] + (iy0[i] + p.pad) * p.ws + (ix0[i] + p.pad);
+        unsigned mk = 0;
+        for (int ky = 0; ky < p.ksize; ++ky)
+          for (int kx = 0; kx < p.ksize; ++kx) {
+            const bool in = mvalid[i] && (unsigned)(iy0[i] + ky) < (unsigned)p.hi && (unsigned)(ix0[i] + kx) < (unsigned)p.wi;
+            mk |= (in ? 1u : 0u) << (ky * p.ksize + kx);
+          }
+        tapmask[i] = mk;
+      }
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const int n = n0 + lr + 32 * i;
+        bvoff[i] = n < p.N ? n * p.Kp * 2 + lc * 16 : OOB;
+      }
+      const int k0 = kt_begin * BK;
+      cur_tap = k0 / p.cin;
+      cur_c = k0 - cur_tap * p.cin;
+      cur_ky = cur_tap / p.ksize;
+      cur_kx = cur_tap - cur_ky * p.ksize;
+    }
+// fetch the cursor's tile into ring slot SLOT_, then (ADV_) move the cursor one K tile on
+#define VSD_ISSUE_FAST(SLOT_, ADV_)                                                                    \
+  {                                                                                                    \
+    half_t* a_ = reinterpret_cast<half_t*>(smem) + (SLOT_) * STAGE_HALFS;                              \
+    half_t* b_ = a_ + BM * BK;                                                                         \
+    const int soff_b_ = cur_kt * (BK * 2);                                                             \
+    /* (descriptors are made next to their use: hipcc drops the host stub of a kernel that reads one declared in an \
+       outer scope) */                                                                                 \
+    const __amdgpu_buffer_rsrc_t rsb_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, bnr, 0x00020000); \
+    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                   \
+      const int bv_ = bvoff[i] + 0;                                                                    \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb_, (lds_ptr_t)(b_ + (8 * wave_s + 32 * i) * BK), 16, bv_, soff_b_, 0, 0); \
+    }                                                                                                  \
+    const bool second_ = cur_c >= p.c0;                                                                \
+    const int cs2_ = (second_ ? p.c1 : p.c0) * 2;                                                      \
+    const int soff_a_ = (cur_ky * p.ws + cur_kx) * cs2_ + (second_ ? cur_c - p.c0 : cur_c) * 2;        \
+    const __amdgpu_buffer_rsrc_t rs_ =                                                                 \
+        __builtin_amdgcn_make_buffer_rsrc((void*)(second_ ? abase1 : abase0), 0, second_ ? anr1 : anr0, 0x00020000); \
+    const unsigned bit_ = 1u << cur_tap;                                                               \
+    _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                   \
+      const int vo_ = (tapmask[i] & bit_) ? __mul24(apix[i], cs2_) + lc * 16 : OOB; /* < 2^24 pixels: host check */                            \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)(a_ + (8 * wave_s + 32 * i) * BK), 16, vo_, soff_a_, 0, 0); \
+    }                                                                                                  \
+    if (ADV_) {                                                                                        \
+      ++cur_kt;                                                                                        \
+      cur_c += BK;                                                                                     \
+      if (cur_c >= p.cin) {                                                                            \
+        cur_c = 0;                                                                                     \
+        ++cur_tap;                                                                                     \
+        if (++cur_kx == p.ksize) {                                                                     \
+          cur_kx = 0;                                                                                  \
+          ++cur_ky;                                                                                    \
+        }                                                                                              \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+#define VSD_ISSUE_TILE(KT_, SLOT_)                                                                    \
+  {                                                                                                   \
+    const int kt_ = (KT_);                                                                            \
+    half_t* a_ = reinterpret_cast<half_t*>(smem) + (SLOT_) * STAGE_HALFS;                             \
+    half_t* b_ = a_ + BM * BK;                                                                        \
+    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                  \
+      const half_t* g_ = nvalid[i] ? (wrow[i] - cc * 8 + lc * 8 + (size_t)kt_ * BK) : p.zeros;        \
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(b_ + (8 * wave + 32 * i) * BK), 16, 0, 0); \
+    }                                                                                                 \
+    int k_, cs_;                                                                                      \
+    const half_t* src_;                                                                               \
+    bool kok_ = true;                                                                                 \
+    if (!GENERIC) {                                                                                   \
+      k_ = kt_ * BK;                                                                                  \
+    } else {                                                                                          \
+      k_ = kt_ * BK + lc * 8;                                                                         \
+      kok_ = k_ < p.K;                                                                                \
+    }                                                                                                 \
+    const int tap_ = k_ / p.cin;                                                                      \
+    int c_ = k_ - tap_ * p.cin;                                                                       \
+    const int ky_ = tap_ / p.ksize, kx_ = tap_ - ky_ * p.ksize;                                       \
+    if (!GENERIC && c_ >= p.c0) {                                                                     \
+      src_ = p.src1; cs_ = p.c1; c_ -= p.c0;                                                          \
+    } else {                                                                                          \
+      src_ = p.src0; cs_ = p.c0;                                                                      \
+    }                                                                                                 \
+    if (!GENERIC) c_ += lc * 8;                                                                       \
+    _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                  \
+      int iy = iy0[i] + ky_, ix = ix0[i] + kx_;                                                       \
+      bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi;  \
+      const int sy = (int)(((unsigned)iy * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)ix * p.rmul_x) >> p.rshift); \
+      const half_t* g_ = ok ? src_ + ((size_t)(ib[i] + sy * p.ws + sx)) * cs_ + c_ : p.zeros;                 \
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(a_ + (8 * wave + 32 * i) * BK), 16, 0, 0); \
+    }                                                                                                 \
+  }
+    if constexpr (!ILV) {
+  #pragma unroll
+      for (int st = 0; st < STAGES - 1; ++st)
+        if (st < nt) {
+          if constexpr (FAST) VSD_ISSUE_FAST(st, true)
+          else VSD_ISSUE_TILE(kt_begin + st, st)
+        }
+      VSD_LN_ROWSTATS()
+      CPROBE(0)
+      int slot = 0;
+      for (int t = 0; t < nt; ++t) {
+        // tile t has landed once all but the younger tiles' loads are done; then everyone's has (barrier)
+        const int rem = min(STAGES - 2, nt - 1 - t);
+        if (STAGES > 4 && rem >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+        else if (STAGES > 4 && rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");  // (tail: over-waits a little)
+        else if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CPROBE(1)
+        __builtin_amdgcn_s_barrier();
+        CPROBE(2)
+        if (t + STAGES - 1 < nt) {
+          int ns = slot + STAGES - 1;
+          if (ns >= STAGES) ns -= STAGES;
+          if constexpr (FAST) VSD_ISSUE_FAST(ns, true)
+          else VSD_ISSUE_TILE(kt_begin + t + STAGES - 1, ns)
+        }
+        CPROBE(3)
+        const half_t* a = reinterpret_cast<const half_t*>(smem) + slot * STAGE_HALFS;
+        const half_t* b = a + BM * BK;
+  #pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          half8 af[FM], bf[FN];
+  #pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            int r = wm * TM + i * 16 + fr;
+            af[i] = *reinterpret_cast<const half8*>(a + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+          }
+  #pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            int r = wn * TN + j * 16 + fr;
+            bf[j] = *reinterpret_cast<const half8*>(b + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
+          }
+  #pragma unroll
+          for (int i = 0; i < FM; ++i)
+  #pragma unroll
+            for (int j = 0; j < FN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        CPROBE(4)
+        if (++slot == STAGES) slot = 0;
+      }
+
+    } else {
+      // Interleaved form: every iteration is ONE basic block -- the next tile's LDS-DMA issue is unconditional (tile
+      // index clamped: the last iterations re-fetch the final tile into a slot nobody reads) so the wait count is a
+      // constant and the scheduler may spread the DMA issues and LDS fragment reads between the MFMAs
+      // (sched_group_barrier), instead of running "all loads, then all reads, then all MFMAs" back to back.
+      const int kt_last = kt_end - 1;
+#pragma unroll
+      for (int st = 0; st < STAGES - 1; ++st) {
+        if constexpr (FAST) VSD_ISSUE_FAST(st, cur_kt < kt_last)
+        else VSD_ISSUE_TILE(min(kt_begin + st, kt_last), st)
+      }
+      VSD_LN_ROWSTATS()
+      int slot = 0;
+      constexpr int NM = FM * FN * 2;       // MFMAs per tile per wave
+      for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int ns = slot + STAGES - 1;
+        if (ns >= STAGES) ns -= STAGES;
+        // ---- per-tile scalars of the tile to fetch (same arithmetic as VSD_ISSUE_TILE / VSD_ISSUE_FAST)
+        half_t* na = reinterpret_cast<half_t*>(smem) + ns * STAGE_HALFS;
+        half_t* nb = na + BM * BK;
+        [[maybe_unused]] int ktn = 0, k_ = 0, cs_ = 0, c_ = 0, ky_ = 0, kx_ = 0;
+        [[maybe_unused]] const half_t* src_ = nullptr;
+        [[maybe_unused]] bool kok_ = true;
+        [[maybe_unused]] int f_soff_b = 0, f_soff_a = 0, f_cs2 = 0;
+        [[maybe_unused]] unsigned f_bit = 0;
+        const bool f_second = FAST && cur_c >= p.c0;
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t f_rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(f_second ? abase1 : abase0), 0, f_second ? anr1 : anr0, 0x00020000);
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t f_rsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, bnr, 0x00020000);
+        if constexpr (FAST) {
+          f_soff_b = cur_kt * (BK * 2);
+          f_cs2 = (f_second ? p.c1 : p.c0) * 2;
+          f_soff_a = (cur_ky * p.ws + cur_kx) * f_cs2 + (f_second ? cur_c - p.c0 : cur_c) * 2;
+          f_bit = 1u << cur_tap;
+        } else {
+          ktn = min(kt_begin + t + STAGES - 1, kt_last);
+          if (!GENERIC) {
+            k_ = ktn * BK;
+          } else {
+            k_ = ktn * BK + lc * 8;
+            kok_ = k_ < p.K;
+          }
+          const int tap_ = k_ / p.cin;
+          c_ = k_ - tap_ * p.cin;
+          ky_ = tap_ / p.ksize;
+          kx_ = tap_ - ky_ * p.ksize;
+          if (!GENERIC && c_ >= p.c0) {
+            src_ = p.src1; cs_ = p.c1; c_ -= p.c0;
+          } else {
+            src_ = p.src0; cs_ = p.c0;
+          }
+          if (!GENERIC) c_ += lc * 8;
+        }
+        const half_t* a = reinterpret_cast<const half_t*>(smem) + slot * STAGE_HALFS;
+        const half_t* b = a + BM * BK;
+        half8 af[2][FM], bf[2][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          int r = wm * TM + i * 16 + fr;
+          af[0][i] = *reinterpret_cast<const half8*>(a + r * BK + (((fq) ^ (r & 7)) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          int r = wn * TN + j * 16 + fr;
+          bf[0][j] = *reinterpret_cast<const half8*>(b + r * BK + (((fq) ^ (r & 7)) << 3));
+        }
+        // ---- LPT pieces: one LDS-DMA issue, then MPP MFMAs; the k-step-1 fragments are read half way
+#pragma unroll
+        for (int pc = 0; pc < LPT; ++pc) {
+          if constexpr (FAST) {
+            if (pc < BR) {
+              const int bv_ = bvoff[pc < BR ? pc : 0] + 0;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rsb, (lds_ptr_t)(nb + (8 * wave_s + 32 * pc) * BK), 16, bv_, f_soff_b, 0, 0);
+            } else {
+              const int i = pc - BR;
+              const int vo_ = (tapmask[i] & f_bit) ? __mul24(apix[i], f_cs2) + lc * 16 : OOB;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rs, (lds_ptr_t)(na + (8 * wave_s + 32 * i) * BK), 16, vo_, f_soff_a, 0, 0);
+            }
+          } else if (pc < BR) {
+            const int i = pc;
+            const half_t* g_ = nvalid[i] ? (wrow[i] - cc * 8 + lc * 8 + (size_t)ktn * BK) : p.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(nb + (8 * wave + 32 * i) * BK), 16, 0, 0);
+          } else {
+            const int i = pc - BR;
+            int iy = iy0[i] + ky_, ix = ix0[i] + kx_;
+            bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi;
+            const int sy = (int)(((unsigned)iy * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)ix * p.rmul_x) >> p.rshift);
+            const half_t* g_ = ok ? src_ + ((size_t)(ib[i] + sy * p.ws + sx)) * cs_ + c_ : p.zeros;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(na + (8 * wave + 32 * i) * BK), 16, 0, 0);
+          }
+          if (pc == 0) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+              int r = wm * TM + i * 16 + fr;
+              af[1][i] = *reinterpret_cast<const half8*>(a + r * BK + (((4 + fq) ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              int r = wn * TN + j * 16 + fr;
+              bf[1][j] = *reinterpret_cast<const half8*>(b + r * BK + (((4 + fq) ^ (r & 7)) << 3));
+            }
+          }
+#pragma unroll
+          for (int idx = pc * NM / LPT; idx < (pc + 1) * NM / LPT; ++idx) {  // this piece's share of the NM MFMAs
+            const int ks = idx / (FM * FN), ij = idx % (FM * FN);        // k-step 0 first, then k-step 1
+            const int i = ij / FN, j = ij % FN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the DMA / MFMA alternation as written
+        }
+        if constexpr (FAST) {
+          if (cur_kt < kt_last) {  // clamped like ktn: past the end the last tile is fetched again into a slot nobody reads
+            ++cur_kt;
+            cur_c += BK;
+            if (cur_c >= p.cin) {
+              cur_c = 0;
+              ++cur_tap;
+              if (++cur_kx == p.ksize) {
+                cur_kx = 0;
+                ++cur_ky;
+              }
+            }
+          }
+        }
+        if (++slot == STAGES) slot = 0;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail fetches must land before the LDS is reused
+    }
+    __syncthreads();  // every wave is done reading the ring before the epilogue reuses the LDS
+#undef VSD_ISSUE_TILE
+#undef VSD_ISSUE_FAST
+  }
+
+  // ---- residual prefetch.  The epilogue below walks this thread's 8-wide output chunks one after the other; loading
+  // each chunk's residual inside that walk exposes one full memory round trip PER CHUNK (measured: 7.4k of the 17k
+  // cycles a 128x64 workgroup of a K=320 layer lives).  The addresses do not depend on the GEMM, so the loads are
+  // issued here, before the accumulator transpose, and land while it and its barrier run.
+  constexpr int CHP = BN / 8;
+  constexpr int NITP = BM * CHP / 256;
+  constexpr int NPRE = NITP <= 8 ? NITP : 8;
+  half8 rpre[NPRE];
+  const bool use_pre = p.residual != nullptr && p.split_k == 1 && (p.act & 0xff) != VSD_ACT_GEGLU && !(p.out_t && n0 >= p.t_col0);
+  // bias + rowvec of this thread's 8 columns (the same columns in every chunk it handles: 256 % CHP == 0)
+  float brv[8];
+  const int pre_n = n0 + (tid % CHP) * 8;
+  const bool use_brv = pre_n + 8 <= p.N && (p.act & 0xff) != VSD_ACT_GEGLU && !(p.out_t && n0 >= p.t_col0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) brv[i] = 0.f;
+  if (use_brv) {
+    if (p.bias) {
+      half8 b = *reinterpret_cast<const half8*>(p.bias + pre_n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) brv[i] += (float)b[i];
+    }
+    if (p.rowvec) {
+      half8 b = *reinterpret_cast<const half8*>(p.rowvec + pre_n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) brv[i] += (float)b[i];
+    }
+  }
+  if (use_pre) {
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int q = tid + j * 256;
+      const int r = q / CHP, c8 = (q - r * CHP) * 8;
+      const int m = m0 + r, n = n0 + c8;
+      const bool ok = m < p.M && n + 8 <= p.N;  // (otherwise an in-range dummy address; the value is not used)
+      rpre[j] = *reinterpret_cast<const half8*>(p.residual + (ok ? (size_t)m * p.ldr + n : 0));
+    }
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32) -> row-contiguous 8-wide chunks
+  float* Cs = reinterpret_cast<float*>(smem);
+
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      int col = wn * TN + j * 16 + fr;
+      int row = wm * TM + i * 16 + fq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[(row + r) * BNP + col] = acc[i][j][r];
+    }
+  __syncthreads();
+
+  CPROBE(5)
+  bool from_slabs = false;
+  if (p.split_k > 1) {
+    constexpr int CH = BN / 8;
+    float* slab = p.ws_partial + (size_t)split * p.M * p.N;
+    // With the in-kernel reduction the slabs are stored WRITE-THROUGH (sc1): they are then visible to the
+    // reducing workgroup on any XCD without an L2 write-back fence on every producer (cdna guide, G16 R1).
+    const bool wt = p.counters != nullptr;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        slab, 0, (int)min((size_t)p.M * p.N * sizeof(float), (size_t)0x7fffffff), 0x00020000);
+    for (int q = tid; q < BM * CH; q += 256) {
+      int r = q / CH, c8 = (q - r * CH) * 8;
+      int m = m0 + r, n = n0 + c8;
+      if (m >= p.M || n >= p.N) continue;
+      const float* s = Cs + r * BNP + c8;
+      float* d = slab + (size_t)m * p.N + n;
+      if (n + 8 <= p.N) {
+        if (wt) {
+          int off = (int)(((size_t)m * p.N + n) * sizeof(float));
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(s), rsrc, off, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(s + 4), rsrc, off + 16, 0, 16);
+        } else {
+          *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(s);
+          *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(s + 4);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (n + i < p.N) {
+            if (wt) __hip_atomic_store(d + i, s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else d[i] = s[i];
+          }
+      }
+    }
+    if (!p.counters) return;  // two-kernel form: splitk_reduce_kernel finishes the job
+    // In-launch reduction: the LAST workgroup to arrive at this tile sums the slabs and runs the epilogue.
+    // Write-through slab stores, every wave drains them (vmcnt(0)), barrier, one relaxed agent-scope ticket;
+    // agent-scope acquire on the reducer
+    // (cdna guide, "In-launch split-K reduction").  Placement independent; the counter is left at zero.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* lastflag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      int* cnt = p.counters + tile_n * p.tiles_m + tile_m;
+      int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int last = ticket == p.split_k - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *lastflag = last;
+    }
+    __syncthreads();
+    if (!*lastflag) return;
+    from_slabs = true;
+  }
+
+  if ((p.act & 0xff) == VSD_ACT_GEGLU) {
+    constexpr int CH = BN / 16;  // chunks over the hidden half
+    const int no = p.N >> 1;
+    for (int q = tid; q < BM * CH; q += 256) {
+      int r = q / CH, c8 = (q - r * CH) * 8;
+      int m = m0 + r;
+      if (m >= p.M) continue;
+      const float* s = Cs + r * BNP + c8;
+      half8 o;
+      if (p.ln_part) {
+        const float mean = rowms[2 * r], rstd = rowms[2 * r + 1];
+        const int nh = n0 + c8, ng = n0 + BN / 2 + c8;
+        float hv[8], gv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          hv[i] = s[i];
+          gv[i] = s[BN / 2 + i];
+        }
+        ln_transform8(p, nh, mean, rstd, hv);
+        ln_transform8(p, ng, mean, rstd, gv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (half_t)(hv[i] * gelu_erf_f(gv[i]));
+      } else {
+        half8 bh = *reinterpret_cast<const half8*>(p.bias + n0 + c8);
+        half8 bg = *reinterpret_cast<const half8*>(p.bias + n0 + BN / 2 + c8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float h = s[i] + (float)bh[i];
+          float g = s[BN / 2 + i] + (float)bg[i];
+          o[i] = (half_t)(h * gelu_erf_f(g));
+        }
+      }
+      int n = (n0 >> 1) + c8;
+      if (n < no) *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
+    }
+    return;
+  }
+
+  const bool transposed_tile = p.out_t && n0 >= p.t_col0;
+  if (transposed_tile) {
+    // lanes run along m so that the 2-byte transposed stores coalesce
+    constexpr int CH = BN / 8;
+    for (int q = tid; q < BM * CH; q += 256) {
+      int r = q % BM, c8 = (q / BM) * 8;
+      int m = m0 + r, n = n0 + c8;
+      if (m >= p.M || n >= p.N) continue;
+      float v[8];
+      if (from_slabs) {
+        load_chunk8(p, Cs, BNP, true, r, c8, m, n, v);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = Cs[r * BNP + c8 + i];
+      }
+      if (p.ln_part) ln_transform8(p, n, rowms[2 * r], rowms[2 * r + 1], v);
+      float rs = 0.f, rq = 0.f;
+      epilogue_store8(p, m, n, v, rs, rq);
+    }
+  } else if (!p.ln_part && !p.rowstat_out && !p.chanstat_out && !p.out2 && !p.residual2 && !from_slabs &&
+             p.out_scale == 1.0f && (p.N & 7) == 0 && NITP <= NPRE && (!p.residual || use_pre)) {
+    // ---- the common epilogue (bias / time vector, one activation, one residual), specialised per activation: the
+    // general loop below tests ~25 uniform flags per 8-wide chunk and inlines every activation twice (15k instructions
+    // per kernel); for the short-K layers that walk was 40 % of the workgroup's life
+    constexpr int CH = BN / 8;
+    auto simple = [&](auto act_tag) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(act_tag)::value;  // 0 none, 1 relu, 2 silu, 3 relu AFTER the residual, 4 quick-gelu
+#pragma unroll
+      for (int j = 0; j < NITP; ++j) {
+        const int q = tid + j * 256;
+        const int r = q / CH, c8 = (q - r * CH) * 8;
+        const int m = m0 + r, n = n0 + c8;
+        if (m < p.M && n < p.N) {
+          f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8);
+          f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8 + 4);
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          half8 o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float x = v[i] + brv[i];
+            if (ACT == 1) x = fmaxf(x, 0.f);
+            if (ACT == 2) x = silu_f(x);
+            if (ACT == 4) x = quick_gelu_f(x);
+            if (p.residual) x += (float)rpre[j < NPRE ? j : 0][i];
+            if (ACT == 3) x = fmaxf(x, 0.f);
+            o[i] = (half_t)x;
+          }
+          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
+        }
+      }
+    };
+    const int act = p.act & 0xff;
+    const bool post = (p.act & VSD_ACT_POST) != 0;
+    if (act == VSD_ACT_NONE) simple(std::integral_constant<int, 0>{});
+    else if (act == VSD_ACT_RELU && !post) simple(std::integral_constant<int, 1>{});
+    else if (act == VSD_ACT_SILU && !post) simple(std::integral_constant<int, 2>{});
+    else if (act == VSD_ACT_RELU && post) simple(std::integral_constant<int, 3>{});
+    else if (act == VSD_ACT_QUICKGELU && !post) simple(std::integral_constant<int, 4>{});
+    else {  // (activation after the residual other than ReLU: not used by the networks; keep it correct)
+#pragma unroll
+      for (int j = 0; j < NITP; ++j) {
+        const int q = tid + j * 256;
+        const int r = q / CH, c8 = (q - r * CH) * 8;
+        const int m = m0 + r, n = n0 + c8;
+        if (m < p.M && n < p.N) {
+          float v[8], rs = 0.f, rq = 0.f;
+          load_chunk8(p, Cs, BNP, false, r, c8, m, n, v);
+          epilogue_store8(p, m, n, v, rs, rq);
+        }
+      }
+    }
+  } else {
+    constexpr int CH = BN / 8;
+    float cs[8], cq[8];  // this thread's 8 columns (fixed: c8 = (tid % CH) * 8), summed over its rows
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cs[i] = cq[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NITP; ++j) {  // BM*CH is a multiple of 256: every lane runs every iteration
+      const int q = tid + j * 256;
+      int r = q / CH, c8 = (q - r * CH) * 8;
+      int m = m0 + r, n = n0 + c8;
+      const bool valid = m < p.M && n < p.N;
+      float rs = 0.f, rq = 0.f;
+      if (valid) {
+        float v[8];
+        load_chunk8(p, Cs, BNP, from_slabs, r, c8, m, n, v);
+        if (p.ln_part) ln_transform8(p, n, rowms[2 * r], rowms[2 * r + 1], v);
+        epilogue_store8(p, m, n, v, rs, rq, (use_pre && j < NPRE) ? &rpre[j < NPRE ? j : 0] : nullptr, use_brv ? brv : nullptr);
+        if (p.chanstat_out) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            cs[i] += v[i];
+            cq[i] += v[i] * v[i];
+          }
+        }
+      }
+      if (p.rowstat_out) {
+        // the 8 lanes of one (row, 64-column group) are consecutive: fold their sums and let the first write
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+          rs += __shfl_xor(rs, o);
+          rq += __shfl_xor(rq, o);
+        }
+        if ((tid & 7) == 0 && valid) {
+          float* dst = p.rowstat_out + ((size_t)m * (p.N >> 6) + (n >> 6)) * 2;
+          dst[0] = rs;
+          dst[1] = rq;
+        }
+      }
+    }
+    if (p.chanstat_out) {
+      // ---- fused GroupNorm statistics of the tensor just written.  (1) fold this tile's rows per column in a
+      // fixed order through LDS; (2) store the tile's column partials write-through; (3) ticket: the last of the
+      // tiles_m workgroups of this column block adds the partials in tile order and publishes chan[N][2].
+      // Deterministic; placement independent (agent-scope acquire on the reducer, cdna guide G16).
+      constexpr int RG = 256 / CH;
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);  // [RG][BN][2]
+      {
+        const int rg = tid / CH, c8 = (tid - rg * CH) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          red[(rg * BN + c8 + i) * 2] = cs[i];
+          red[(rg * BN + c8 + i) * 2 + 1] = cq[i];
+        }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.N) {
+        float S = 0.f, Q = 0.f;
+        for (int g = 0; g < RG; ++g) {
+          S += red[(g * BN + tid) * 2];
+          Q += red[(g * BN + tid) * 2 + 1];
+        }
+        float* dst = p.chanstat_part + ((size_t)tile_m * p.N + n0 + tid) * 2;
+        __hip_atomic_store(dst, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, Q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* lastflag = reinterpret_cast<int*>(smem);
+      if (tid == 0) {
+        int* cnt = p.chan_counters + tile_n;
+        int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = ticket == p.tiles_m - 1;
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *lastflag = last;
+      }
+      __syncthreads();
+      if (*lastflag && tid < BN && n0 + tid < p.N) {
+        float S = 0.f, Q = 0.f;
+        const float* src = p.chanstat_part + ((size_t)(n0 + tid)) * 2;
+        for (int tm = 0; tm < p.tiles_m; ++tm) {
+          S += src[(size_t)tm * p.N * 2];
+          Q += src[(size_t)tm * p.N * 2 + 1];
+        }
+        p.chanstat_out[(n0 + tid) * 2] = S;
+        p.chanstat_out[(n0 + tid) * 2 + 1] = Q;
+      }
+    }
+  }
+  CPROBE(6)
+  CPROBE_OUT()
+}
+
+// the FAST form exists for the direct-to-LDS rings only (STAGES >= 3)
+template <int BM, int BN, int STAGES, bool ILV>
+struct FastLaunch {
+  static void go(const ConvParams& p, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, STAGES, ILV, true>), dim3(grid), dim3(256), 0, s, p);
+  }
+};
+template <int BM, int BN, bool ILV>
+struct FastLaunch<BM, BN, 0, ILV> {
+  static void go(const ConvParams& p, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, 0, ILV, false>), dim3(grid), dim3(256), 0, s, p);
+  }
+};
+
+template <int BM, int BN, int STAGES, bool ILV>
+void launch2(const ConvParams& p, int grid, hipStream_t s) {
+  if (p.generic) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, true, STAGES, ILV, false>), dim3(grid), dim3(256), 0, s, p);
+  else if (STAGES >= 3 && p.fast) FastLaunch<BM, BN, STAGES, ILV>::go(p, grid, s);
+  else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, STAGES, ILV, false>), dim3(grid), dim3(256), 0, s, p);
+}
+template <int BM, int BN>
+void launch(const ConvParams& p, int grid, int stages, hipStream_t s) {
+  if (stages == 0) launch2<BM, BN, 0, false>(p, grid, s);
+  else if (stages == 3) launch2<BM, BN, 3, false>(p, grid, s);
+  else if (stages == 4) launch2<BM, BN, 4, false>(p, grid, s);
+  else if (stages == 5) launch2<BM, BN, 3, true>(p, grid, s);
+  else launch2<BM, BN, 4, true>(p, grid, s);
+}
+
+
+}  // namespace

@@ -233,6 +233,7 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
         rings = (_ShmRing(shm["slots"], shm["slot_bytes"], shm["in"]), _ShmRing(shm["slots"], shm["slot_bytes"], shm["out"]))
     pipelined = max_batch > 1 and hasattr(pipe, "submit_batch") and hasattr(pipe, "collect_batch")
     backlog, inflight, lane = [], [], 0
+    ema_launch_s = [0.0]  # running average: request taken -> launch collected
     stats = _Stats()
     epoch = 0
 
@@ -253,6 +254,8 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
         group_, handle, t_in, _kw = inflight.pop(0)
         try:
             outs = pipe.collect_batch(handle)
+            dt = time.time() - t_in
+            ema_launch_s[0] = dt if ema_launch_s[0] == 0.0 else 0.8 * ema_launch_s[0] + 0.2 * dt
             for (r, _a, s), o in zip(group_, outs):
                 reply(r, o, s)
             stats.add(len(group_), (time.time() - t_in) * 1e3)
@@ -323,7 +326,15 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
         group_ = [(rid, args, slot)]
         batchable = max_batch > 1 and method == "infer" and len(args) == 1 and hasattr(pipe, "infer_batch")
         if batchable:
-            while len(group_) < max_batch and (backlog or conn.poll(0)):
+            # While a launch is on the GPU a new one could not start anyway: a partial batch then waits for more frames
+            # until that launch is (by the running average) about to finish -- the batch fills at no cost in latency.
+            # With nothing in flight a frame is never held back.
+            fill_until = (inflight[0][2] + 0.8 * ema_launch_s[0]) if (pipelined and inflight) else 0.0
+            while len(group_) < max_batch:
+                if not (backlog or conn.poll(0)):
+                    wait = fill_until - time.time()
+                    if wait <= 0 or not conn.poll(min(wait, 0.25)):
+                        break
                 try:
                     nxt = backlog.pop(0) if backlog else conn.recv()
                 except (EOFError, OSError):
