@@ -270,6 +270,11 @@ def run_rank(args):
     t_prep = time.perf_counter()
     plan = eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=B)
     prepare_ms = (time.perf_counter() - t_prep) * 1e3
+    # a slider step (strength / controlnet_scale): device constants only, same captured graph
+    t_upd = time.perf_counter()
+    eng.update_options(0.62, 1.05)
+    eng.update_options(STRENGTH, 1.0)
+    update_options_ms = (time.perf_counter() - t_upd) * 1e3 / 2
     # frames are independent (the reference resets its RNG per frame): keep `slots` of them in flight per GPU,
     # each with its own buffers, streams and hipGraph, sharing the weight replica
     engines = [eng]
@@ -455,7 +460,7 @@ def run_rank(args):
         "fps_one_frame_per_launch": round(fps_b1, 3) if fps_b1 else None,
         "fps_end_to_end": round(fps_e2e, 3) if fps_e2e else None,
         "fps_without_controlnet": round(fps_nocn, 3),
-        "prepare_ms": round(prepare_ms, 1),
+        "prepare_ms": round(prepare_ms, 1), "update_options_ms": round(update_options_ms, 2),
         "frame_roofline": {"algorithmic_tflop_per_frame": 4.623, "mfma_frac": round(4.623 * fps / world / MFMA_PEAK_TFLOPS, 4)},
         "roofline": roofline,
     }

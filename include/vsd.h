@@ -127,6 +127,9 @@ typedef struct vsd_conv_desc {
                              streams) share one launch and one pass over the weights. */
   int32_t t_img;          /* transposed output with batch > 1: image b's row m goes to column b*t_img + (m - b*ho*wo)
                              of out_t (t_img >= ho*wo, a multiple of 8; 0 = ho*wo) */
+  const void* out_scale_dev; /* optional: ONE fp32 in device memory that replaces out_scale (read by the kernel at run
+                             time): the ControlNet zero-convs' conditioning scale (lcm_controlnet.py:558-566) can then
+                             change under a captured graph.  General epilogue only (not the halo-patch form). */
 } vsd_conv_desc;
 #define VSD_SPLITK_MAX_TILES 16384
 
@@ -195,6 +198,16 @@ int vsd_add_noise(vsd_ctx* ctx, const void* x0, const void* noise_f32, float sqr
  * dec_in (optional): 3*tanh(denoised/3), the TAESD decoder input clamp (DecoderTiny.forward).        */
 int vsd_lcm_step(vsd_ctx* ctx, const void* eps, const void* sample, const void* noise_f32, const float* coef_host,
                  int hw, void* prev, void* denoised, void* dec_in, void* stream);
+
+/* The two scheduler kernels with their coefficients in DEVICE memory (fp32: {sqrt_a, sqrt_b} / the six of
+ * vsd_lcm_step) and `batch` images per launch (image b = rows [b*hw, (b+1)*hw); all images use the same noise draw,
+ * as the reference's per-frame RNG reset implies).  A captured graph built on these follows a new `strength` (another
+ * set of timesteps of the same count, lcm_controlnet.py:929-936) by rewriting the floats -- no re-capture
+ * (server.py:163-197 patches options live, one slider step at a time). */
+int vsd_add_noise_dev(vsd_ctx* ctx, const void* x0, const void* noise_f32, const void* coef_dev, int hw, int batch, void* out,
+                      void* stream);
+int vsd_lcm_step_dev(vsd_ctx* ctx, const void* eps, const void* sample, const void* noise_f32, const void* coef_dev, int hw,
+                     int batch, void* prev, void* denoised, void* dec_in, void* stream);
 
 /* decoder output fp16 [hw][ld] (3 channels used; value c of the last conv) -> u8 RGB HWC:
  * y = fp16(2c - 1) (DecoderTiny), (y/2 + 0.5).clamp(0,1)*255 rounded half-to-even

@@ -64,7 +64,9 @@ class FakeOps:
     def conv(self, src0, src1, g, w, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None, residual2=None,
              ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0, t_col0=0, tile=None,
              split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None, ln_eps=1e-5,
-             chanstat_out=None, t_img=0):
+             chanstat_out=None, t_img=0, out_scale_dev=None):
+        if out_scale_dev is not None:
+            out_scale = float(out_scale_dev.reshape(-1)[0])
         c0 = c0 if c0 is not None else (w.cin - c1)
         B = g.batch
         x = self._nhwc(src0, g.hs, g.ws, c0, B)
@@ -225,6 +227,17 @@ class FakeOps:
     def add_noise(self, x0, noise_f32, sqrt_a, sqrt_b, hw, out):
         out.zero_()
         out[:, :4] = (sqrt_a * x0[:, :4].float() + sqrt_b * noise_f32.reshape(4, hw).t()).half()
+
+    def add_noise_dev(self, x0, noise_f32, coef_dev, hw, batch, out):
+        sa, sb = [float(v) for v in coef_dev.reshape(-1)[:2]]
+        for b in range(batch):
+            self.add_noise(x0[b * hw:(b + 1) * hw], noise_f32, sa, sb, hw, out[b * hw:(b + 1) * hw])
+
+    def lcm_step_dev(self, eps, sample, noise_f32, coef_dev, hw, batch, prev, denoised, dec_in=None):
+        coef = [float(v) for v in coef_dev.reshape(-1)[:6]]
+        sl = lambda t, b: None if t is None else t[b * hw:(b + 1) * hw]  # noqa: E731
+        for b in range(batch):
+            self.lcm_step(sl(eps, b), sl(sample, b), noise_f32, coef, hw, sl(prev, b), sl(denoised, b), sl(dec_in, b))
 
     def lcm_step(self, eps, sample, noise_f32, coef, hw, prev, denoised, dec_in=None):
         sa, sb, cskip, cout, sap, sbp = [float(torch.tensor(c, dtype=torch.float32)) for c in coef]

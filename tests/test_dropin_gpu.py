@@ -61,7 +61,38 @@ def test_infer_batch_gives_every_frame_its_single_frame_result(pipe):
         assert a.shape == b.shape and np.abs(a.astype(int) - b.astype(int)).mean() < 0.5
     # both plans stay prepared: going back to single frames replays the first graph bit-exactly
     assert np.array_equal(np.asarray(pipe.infer(imgs[0], **OPTS)), single[0])
-    assert len(pipe._engines) == 2  # (options, 1, lane 0) and (options, 3, lane 0)
+    assert len(pipe._engines) == 2  # (program, 1, lane 0) and (program, 3, lane 0)
+
+
+def test_slider_options_do_not_rebuild_the_plan(pipe):
+    """The client patches `strength` (step 0.02) and `controlnet_scale` (0.05 - 3) live (server.py:163-197): through the
+    drop-in class a new value must keep the prepared engines (no `prepare`, no re-capture) and still give the frame a
+    pipeline freshly built with those options gives; changing the prompt or the options under launches in flight is
+    refused instead of corrupting them."""
+    from videosd_amd.pipeline import VideoSDPipeline
+
+    img = _photo(300, 200, 11)
+    base = np.asarray(pipe.infer(img, **OPTS))
+    n_prep = len(pipe._host_ms["prepare"])
+    graph = pipe.model.graph
+    a = np.asarray(pipe.infer(img, **{**OPTS, "controlnet_scale": 2.25}))
+    b = np.asarray(pipe.infer(img, **{**OPTS, "strength": 0.7}))
+    assert len(pipe._host_ms["prepare"]) == n_prep and pipe.model.graph is graph  # nothing was prepared or captured
+    assert len(pipe._host_ms["update_options"]) >= 2
+    assert not np.array_equal(a, base) and not np.array_equal(b, base)
+    fresh = VideoSDPipeline(**CFG)
+    assert np.array_equal(np.asarray(fresh.infer(img, **{**OPTS, "controlnet_scale": 2.25})), a)
+    assert np.array_equal(np.asarray(fresh.infer(img, **{**OPTS, "strength": 0.7})), b)
+    assert np.array_equal(np.asarray(pipe.infer(img, **OPTS)), base)  # and back
+    # two lanes: a launch in flight pins its plan / prompt
+    h = pipe.submit_batch([img], lane=0, **OPTS)
+    with pytest.raises(RuntimeError, match="in flight"):
+        pipe.submit_batch([img], lane=1, **{**OPTS, "strength": 0.8})
+    with pytest.raises(RuntimeError, match="in flight"):
+        pipe.submit_batch([img], lane=1, **{**OPTS, "prompt": "another prompt"})
+    assert np.array_equal(np.asarray(pipe.collect_batch(h)[0]), base)
+    with pytest.raises(ValueError):
+        pipe.infer(img, **{**OPTS, "strength": 0.01})  # empty schedule: the caller's error, typed as such
 
 
 def test_remote_handle_across_a_process_boundary(pipe):

@@ -133,3 +133,35 @@ def test_prepare_rejects_bad_sizes_and_missing_text(mini):
         eng.prepare(60, 64, 2, 0.6, use_graph=False)
     with pytest.raises(ValueError):
         eng.prepare(64, 64, 4, 0.01, use_graph=False)  # empty schedule (reference would crash at :588)
+
+
+def test_update_options_equals_a_fresh_prepare(mini):
+    """strength / controlnet_scale live in device constants the program READS (scheduler coefficients, ControlNet residual
+    scales, per-step time embeddings): `update_options` on a prepared plan gives exactly what preparing with those options
+    gives, slots follow their parent, and a strength that changes the NUMBER of timesteps is refused (the program itself
+    would change)."""
+    wu, wc, wv, text = mini
+    frame = _frame(64, 64)
+
+    def fresh(strength, scale):
+        e = Engine(FakeOps(), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
+        e.set_text_embeds(text)
+        e.prepare(64, 64, 2, strength, controlnet_scale=scale, use_controlnet=True, use_graph=False)
+        return e.infer_u8(frame), e.plan["timesteps"]
+
+    eng = Engine(FakeOps(), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
+    eng.set_text_embeds(text)
+    eng.prepare(64, 64, 2, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
+    n_ops = len(eng.program.calls)
+    slot = eng.make_slot()
+    slot.prepare(64, 64, 2, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
+    base = eng.infer_u8(frame)
+    for strength, scale in [(0.6, 2.5), (0.8, 0.3), (0.5, 1.0)]:
+        assert eng.update_options(strength, scale) is True
+        assert len(eng.program.calls) == n_ops  # same recorded program: nothing was rebuilt
+        ref, ts = fresh(strength, scale)
+        assert eng.plan["timesteps"] == ts
+        got = eng.infer_u8(frame)
+        assert np.array_equal(got, ref) and not np.array_equal(got, base)
+        assert np.array_equal(slot.infer_u8(frame), ref)  # the slot reads the same constant block
+    assert eng.update_options(0.03, 1.0) is False  # int(50 * 0.03) = 1 candidate timestep: a 1-step schedule, another program

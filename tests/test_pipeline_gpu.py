@@ -93,6 +93,31 @@ def test_graph_replay_is_deterministic_and_equals_eager(mini_setup):
     assert np.array_equal(a, eng.infer_u8(f))
 
 
+def test_option_sweep_with_one_capture_matches_fresh_prepares(mini_setup):
+    """`controlnet_scale` and `strength` must not cost a re-capture.  One hipGraph; ten scales and three
+    strengths through `update_options` (device constants the graph reads); every result bit-identical to a fresh
+    `prepare` with those options, on the parent engine and on a slot that shares its constants."""
+    eng, orc, text = mini_setup
+    f = _frame(128, 128, seed=6)
+    eng.prepare(128, 128, 4, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=True)
+    graph = eng.graph
+    slot = eng.make_slot()
+    slot.prepare(128, 128, 4, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=True)
+    sweep = [(0.6, s) for s in (0.05, 0.3, 0.55, 0.8, 1.05, 1.3, 1.75, 2.0, 2.5, 3.0)] + [(0.5, 1.0), (0.72, 2.0), (0.9, 0.4)]
+    got, got_slot = [], []
+    for strength, scale in sweep:
+        assert eng.update_options(strength, scale)
+        assert eng.graph is graph  # same captured graph
+        got.append(eng.infer_u8(f).copy())
+        got_slot.append(slot.infer_u8(f).copy())
+    assert not eng.update_options(0.03, 1.0)  # a 1-step schedule is another program
+    for (strength, scale), a, b in zip(sweep, got, got_slot):
+        eng.prepare(128, 128, 4, strength, controlnet_scale=scale, use_controlnet=True, use_graph=True)
+        ref = eng.infer_u8(f)
+        assert np.array_equal(a, ref) and np.array_equal(b, ref), (strength, scale)
+    assert len({g.tobytes() for g in got}) == len(sweep)  # and the options do change the image
+
+
 def test_two_frames_in_flight_equal_sequential_results(mini_setup):
     """Slots share weights/constants but nothing mutable: concurrent frames are bit-identical to sequential ones."""
     eng, orc, text = mini_setup

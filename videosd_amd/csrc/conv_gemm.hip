@@ -49,6 +49,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.residual2 = (const half_t*)d->residual2;
   p.ldr = d->ldr;
   p.out_scale = d->out_scale;
+  p.out_scale_dev = (const float*)d->out_scale_dev;
   p.act = d->act;
   p.out = (half_t*)d->out; p.ldo = d->ldo;
   p.out2 = (half_t*)d->out2; p.add2 = (const half_t*)d->add2;
@@ -106,7 +107,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   }
   if (halo) {
     const bool simple_epi = !p.out2 && !p.residual2 && !p.out_t && !p.rowstat_out && !p.chanstat_out && !p.ln_part &&
-                            p.out_scale == 1.0f && (p.act & 0xff) != VSD_ACT_GEGLU && (p.act & 0xff) != VSD_ACT_QUICKGELU &&
+                            p.out_scale == 1.0f && !p.out_scale_dev && (p.act & 0xff) != VSD_ACT_GEGLU && (p.act & 0xff) != VSD_ACT_QUICKGELU &&
                             !((p.act & VSD_ACT_POST) && (p.act & 0xff) != VSD_ACT_RELU);
     if (!p.halo_ok || p.ksize != 3 || p.stride != 1 || p.pad != 1 || BM < 128 || p.N % 8 || p.c0 % 64 || p.c1 % 64 || !simple_epi)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the halo-patch form (pipeline 7) needs a 3x3 stride-1 conv, Cin %% 64 == 0 per "

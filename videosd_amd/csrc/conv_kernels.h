@@ -45,6 +45,7 @@ struct ConvParams {
   const half_t* residual2;
   int ldr;
   float out_scale;
+  const float* out_scale_dev;  // optional: the scale lives in device memory (read at run time; replaces out_scale)
   int act;
   half_t* out;
   int ldo;
@@ -150,7 +151,11 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i]);
   }
-  if (p.out_scale != 1.0f) {
+  if (p.out_scale_dev) {
+    const float sc = *p.out_scale_dev;  // uniform address: a scalar load
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= sc;
+  } else if (p.out_scale != 1.0f) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= p.out_scale;
   }
@@ -977,7 +982,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       epilogue_store8(p, m, n, v, rs, rq);
     }
   } else if (!p.ln_part && !p.rowstat_out && !p.chanstat_out && !p.out2 && !p.residual2 && !from_slabs &&
-             p.out_scale == 1.0f && (p.N & 7) == 0 && NITP <= NPRE && (!p.residual || use_pre)) {
+             p.out_scale == 1.0f && !p.out_scale_dev && (p.N & 7) == 0 && NITP <= NPRE && (!p.residual || use_pre)) {
     // ---- the common epilogue (bias / time vector, one activation, one residual), specialised per activation: the
     // general loop below tests ~25 uniform flags per 8-wide chunk and inlines every activation twice (15k instructions
     // per kernel); for the short-K layers that walk was 40 % of the workgroup's life

@@ -141,6 +141,22 @@ struct StepCoef {
   float sa, sb, cskip, cout, sap, sbp;
 };
 
+// Same arithmetic with the coefficients read from device memory: a captured graph then follows a new strength /
+// schedule without being captured again (the host rewrites the few floats between replays).  blockIdx.y = image of a
+// batch (every image uses the same noise draw: the reference resets its RNG per frame).
+__global__ void add_noise_dev_kernel(const half_t* __restrict__ x0, const float* __restrict__ noise, const float* __restrict__ coef,
+                                     int hw, half_t* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hw) return;
+  const float sa = coef[0], sb = coef[1];
+  const size_t row = (size_t)blockIdx.y * hw + i;
+  half8 x = *reinterpret_cast<const half8*>(x0 + row * 8);
+  half8 o = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o[c] = (half_t)(sa * (float)x[c] + sb * noise[(size_t)c * hw + i]);
+  *reinterpret_cast<half8*>(out + row * 8) = o;
+}
+
 __global__ void lcm_step_kernel(const half_t* __restrict__ eps, const half_t* __restrict__ sample,
                                 const float* __restrict__ noise, StepCoef k, int hw, half_t* __restrict__ prev,
                                 half_t* __restrict__ den, half_t* __restrict__ dec_in) {
@@ -162,6 +178,31 @@ __global__ void lcm_step_kernel(const half_t* __restrict__ eps, const half_t* __
   if (prev) *reinterpret_cast<half8*>(prev + (size_t)i * 8) = op;
   if (den) *reinterpret_cast<half8*>(den + (size_t)i * 8) = od;
   if (dec_in) *reinterpret_cast<half8*>(dec_in + (size_t)i * 8) = oi;
+}
+
+__global__ void lcm_step_dev_kernel(const half_t* __restrict__ eps, const half_t* __restrict__ sample,
+                                    const float* __restrict__ noise, const float* __restrict__ coef, int hw,
+                                    half_t* __restrict__ prev, half_t* __restrict__ den, half_t* __restrict__ dec_in) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hw) return;
+  const StepCoef k = {coef[0], coef[1], coef[2], coef[3], coef[4], coef[5]};
+  const size_t row = (size_t)blockIdx.y * hw + i;
+  half8 e = *reinterpret_cast<const half8*>(eps + row * 8);
+  half8 x = *reinterpret_cast<const half8*>(sample + row * 8);
+  half8 op = (half8){0, 0, 0, 0, 0, 0, 0, 0}, od = op, oi = op;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float xs = (float)x[c];
+    float px0 = (xs - k.sb * (float)e[c]) / k.sa;
+    float d = k.cout * px0 + k.cskip * xs;
+    od[c] = (half_t)d;
+    float pv = noise ? k.sap * d + k.sbp * noise[(size_t)c * hw + i] : d;
+    op[c] = (half_t)pv;
+    oi[c] = (half_t)(tanhf((float)od[c] / 3.0f) * 3.0f);
+  }
+  if (prev) *reinterpret_cast<half8*>(prev + row * 8) = op;
+  if (den) *reinterpret_cast<half8*>(den + row * 8) = od;
+  if (dec_in) *reinterpret_cast<half8*>(dec_in + row * 8) = oi;
 }
 
 __global__ void postprocess_kernel(const half_t* __restrict__ img, int ld, int hw, unsigned char* __restrict__ rgb) {
@@ -242,6 +283,31 @@ extern "C" int vsd_lcm_step(vsd_ctx* ctx, const void* eps, const void* sample, c
   LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
   hipLaunchKernelGGL(lcm_step_kernel, dim3(cdiv(hw, 256)), dim3(256), 0, s, (const half_t*)eps, (const half_t*)sample,
                      (const float*)noise_f32, k, hw, (half_t*)prev, (half_t*)denoised, (half_t*)dec_in);
+  return ls.finish();
+}
+
+extern "C" int vsd_add_noise_dev(vsd_ctx* ctx, const void* x0, const void* noise_f32, const void* coef_dev, int hw, int batch,
+                                 void* out, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (!x0 || !noise_f32 || !coef_dev || !out || hw <= 0 || batch < 1 || batch > 65535)
+    return vsd_fail(ctx, VSD_ERR_ARG, "add_noise_dev: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
+  hipLaunchKernelGGL(add_noise_dev_kernel, dim3(cdiv(hw, 256), batch), dim3(256), 0, s, (const half_t*)x0,
+                     (const float*)noise_f32, (const float*)coef_dev, hw, (half_t*)out);
+  return ls.finish();
+}
+
+extern "C" int vsd_lcm_step_dev(vsd_ctx* ctx, const void* eps, const void* sample, const void* noise_f32, const void* coef_dev,
+                                int hw, int batch, void* prev, void* denoised, void* dec_in, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (!eps || !sample || !coef_dev || hw <= 0 || batch < 1 || batch > 65535)
+    return vsd_fail(ctx, VSD_ERR_ARG, "lcm_step_dev: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
+  hipLaunchKernelGGL(lcm_step_dev_kernel, dim3(cdiv(hw, 256), batch), dim3(256), 0, s, (const half_t*)eps,
+                     (const half_t*)sample, (const float*)noise_f32, (const float*)coef_dev, hw, (half_t*)prev,
+                     (half_t*)denoised, (half_t*)dec_in);
   return ls.finish();
 }
 

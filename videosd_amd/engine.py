@@ -316,6 +316,9 @@ class Engine:
         self.fuse_gn_stats = False
         self._stats = {}
         self.overlap_controlnet = True  # run the ControlNet encoder on a second stream, parallel to the UNet encoder
+        # what a slot shares with its parent besides the weights: the per-plan constant block (schedule coefficients,
+        # ControlNet scales) that the captured graphs READ, so that `update_options` reaches every graph at once
+        self.shared = {}
 
     def make_slot(self) -> "Engine":
         """A further frame in flight on the same GPU: shares the weights and the prompt / schedule constants of
@@ -583,21 +586,22 @@ class Engine:
         `down_block_additional_residuals` / `mid_block_additional_residual` adds of UNet2DConditionModel)."""
         a, net = self.arena, self.cn
         nres = len(cn_skips) + 1
-        scales = torch.logspace(-1, 0, nres) * scale
+        sc = self._cn_scale_consts  # fp32 [nres] in device memory: logspace(-1, 0, nres) * controlnet_scale
+        assert sc.numel() >= nres
         merged = []
         for i, ((s, c, lvl), (us, uc, ulvl)) in enumerate(zip(cn_skips, u_skips)):
             assert (c, lvl) == (uc, ulvl)
             hh, ww = sizes[lvl]
             rows = self.batch * hh * ww
             o = a.alloc(rows, c)
-            r.conv(s, None, Geom.linear(rows), net.zero_convs[i], o, out_scale=float(scales[i]), residual=us,
+            r.conv(s, None, Geom.linear(rows), net.zero_convs[i], o, out_scale_dev=sc[i:i + 1], residual=us,
                    chanstat_out=self._stat_buf(o, c))
             merged.append((o, c, lvl))
         hh, ww = sizes[-1]
         rows = self.batch * hh * ww
         c = net.cfg.block_out_channels[-1]
         mid = a.alloc(rows, c)
-        r.conv(cn_mid, None, Geom.linear(rows), net.zero_mid, mid, out_scale=float(scales[-1]), residual=u_mid,
+        r.conv(cn_mid, None, Geom.linear(rows), net.zero_mid, mid, out_scale_dev=sc[nres - 1:nres], residual=u_mid,
                chanstat_out=self._stat_buf(mid, c))
         return mid, merged
 
@@ -723,12 +727,23 @@ class Engine:
         self.frame_u8 = frame_b[0] if B == 1 else frame_b
         self.out_u8 = out_b[0] if B == 1 else out_b
         self.edge_u8 = ops.zeros(B * H * W, dtype=torch.uint8)
-        for net in [self.unet] + ([self.cn] if use_controlnet else []):
-            if self.is_slot:  # schedule constants were computed by the parent engine's prepare
-                assert net.temb_all.shape[0] == n, "prepare the parent engine with the same schedule first"
-                continue
-            net.temb_all = ops.zeros(n, net.temb_proj.n)
-            self._time_embeddings(net, sched, net.temb_all)
+        # Per-plan constants the captured graph reads from device memory: [0:2] add_noise coefficients, [2 + 6i : 8 + 6i]
+        # the scheduler coefficients of step i, then the 13 ControlNet residual scales; plus the time-embedding projections
+        # of every step.  `update_options` rewrites them in place -- a new strength / controlnet_scale needs no re-capture.
+        ncn = 16
+        if self.is_slot:  # computed by the parent engine's prepare / update_options
+            c = self.shared.get("consts")
+            assert c is not None and self.shared.get("n") == n, "prepare the parent engine with the same schedule first"
+        else:
+            c = self.shared.get("consts")
+            if c is None or self.shared.get("n") != n:
+                self.shared["consts"] = c = ops.zeros(2 + 6 * n + ncn, dtype=torch.float32)
+                self.shared["n"] = n
+            for net in [self.unet] + ([self.cn] if use_controlnet else []):
+                if getattr(net, "temb_all", None) is None or net.temb_all.shape[0] != n:
+                    net.temb_all = ops.zeros(n, net.temb_proj.n)
+            self._write_constants(sched, controlnet_scale, use_controlnet)
+        self._cn_scale_consts = c[2 + 6 * n:]
         # noise draws: the reference resets the global CPU generator to a fresh-Generator state on every
         # frame (videopipeline.py:126), so for a fixed shape the draws are the same every frame.
         self.noise = ops.to_device(self.host_noise(n, h0, w0))
@@ -754,9 +769,8 @@ class Engine:
             cond_emb = self._cond_embedding(r, ctrl, H, W)
             self.buffers["control"], self.buffers["cond_emb"] = ctrl, cond_emb
         self._encode(r, enc_in, H, W, x0)
-        sa, sb = sched.add_noise_coef()
-        for b in range(B):  # every frame gets the same draws: the reference resets its RNG per frame
-            r.add_noise(img(x0, b, hw0), self.noise[0], sa, sb, hw0, img(lat[0], b, hw0))
+        # every frame gets the same draws: the reference resets its RNG per frame
+        r.add_noise_dev(x0, self.noise[0], c[0:2], hw0, B, lat[0])
         mark = a.mark()
         for i in range(n):
             a.rewind(mark)
@@ -780,9 +794,7 @@ class Engine:
             self._unet_decoder(r, i, u_mid, u_skips, sizes, eps)
             nz = self.noise[i + 1] if sched.multistep else None
             last = i == n - 1
-            for b in range(B):
-                r.lcm_step(img(eps, b, hw0), img(cur, b, hw0), nz, sched.step_coef(i), hw0, img(nxt, b, hw0), img(den, b, hw0),
-                           img(dec_in, b, hw0) if last else None)
+            r.lcm_step_dev(eps, cur, nz, c[2 + 6 * i:8 + 6 * i], hw0, B, nxt, den, dec_in if last else None)
         self._decode(r, dec_in, h0, w0, dec_out)
         r.postprocess_rgb(dec_out, 8, B * H * W, out_b)
         self.program = r
@@ -799,6 +811,39 @@ class Engine:
             r.run()
             self.graph = ops.graph_end()
         return self.plan
+
+    def _write_constants(self, sched: LCMSchedule, controlnet_scale: float, use_controlnet: bool):
+        """Schedule- and option-dependent constants -> the device block / time-embedding tables the graphs read."""
+        n = len(sched)
+        vals = list(sched.add_noise_coef())
+        for i in range(n):
+            vals += [float(x) for x in sched.step_coef(i)]
+        nres = 13 if self.cn is None else len(self.cn.zero_convs) + 1
+        # ControlNetModel guess mode: logspace(-1, 0, 13) * conditioning_scale (always on: lcm_controlnet.py:399,447)
+        vals += (torch.logspace(-1, 0, nres) * float(controlnet_scale)).tolist()
+        c = self.shared["consts"]
+        host = torch.zeros(c.numel(), dtype=torch.float32)
+        host[:len(vals)] = torch.tensor(vals, dtype=torch.float32)
+        self.ops.upload(c, host)
+        for net in [self.unet] + ([self.cn] if (use_controlnet and self.cn is not None) else []):
+            self._time_embeddings(net, sched, net.temb_all)
+        self.ops.synchronize()
+
+    def update_options(self, strength: float, controlnet_scale: float) -> bool:
+        """New `strength` / `controlnet_scale` for the prepared plan WITHOUT re-capturing: the captured graph reads the
+        scheduler coefficients, the ControlNet scales and the per-step time-embedding projections from device memory, so
+        a slider drag (server.py:163-197: strength in steps of 0.02, controlnet_scale 0.05-3) costs a few small uploads and
+        the ~10 tiny GEMMs of the time path.  Returns False when the new strength gives another NUMBER of timesteps (then
+        the program itself changes: call `prepare`).  Call it on the parent engine, with no launch in flight; its slots
+        follow (they share the constant block)."""
+        if self.plan is None or self.is_slot:
+            raise RuntimeError("update_options: prepare the parent engine first")
+        sched = LCMSchedule(strength, self.plan["steps"])
+        if len(sched) != self.plan["n"]:
+            return False
+        self._write_constants(sched, controlnet_scale, self.plan["cn"])
+        self.plan.update(strength=strength, cn_scale=controlnet_scale, timesteps=sched.timesteps)
+        return True
 
     @staticmethod
     def host_noise(n_steps: int, h: int, w: int) -> torch.Tensor:

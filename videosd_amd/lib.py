@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("ln_s", C.c_void_p), ("ln_t", C.c_void_p),
         ("counters", C.c_void_p),
         ("batch", C.c_int32), ("t_img", C.c_int32),
+        ("out_scale_dev", C.c_void_p),
     ]
 
 
@@ -72,6 +73,9 @@ SIGNATURES = {
                                 C.c_void_p]),
     "vsd_lcm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsd_add_noise_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vsd_lcm_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsd_postprocess_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vsd_axpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]),
     "vsd_graph_begin": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -63,10 +63,11 @@ class VideoSDPipeline:
             raise
         self._prompt_key = None
         self._plan_key = None
+        self._opt_key = None
         self._engines = {}  # (plan_key, batch, lane) -> prepared engine (the first one is self.model, the others are its slots)
         self.max_plans = int(kwargs.get("max_plans", 8))
         self._outstanding = []  # engines with a submitted, not yet collected launch
-        self._host_ms = {"crop_resize": [], "upload_enqueue": [], "wait_download": [], "to_pil": [], "gpu": [], "prepare": []}
+        self._host_ms = {"crop_resize": [], "upload_enqueue": [], "wait_download": [], "to_pil": [], "gpu": [], "prepare": [], "update_options": []}
 
     # ------------------------------------------------------------------ model loading
     def load_model(self, model_name, controlnet_model="lllyasviel/control_v11p_sd15_canny"):
@@ -232,8 +233,15 @@ class VideoSDPipeline:
         if self.is_xl:  # micro-conditioning: original size = target size = the frame size, no crop
             self.model.set_added_cond(self._pooled, (height, width, 0, 0, height, width))
         use_cn = False if self.is_xl else (bool(controlnet) if self.honor_controlnet_flag else True)
-        plan_key = (height, width, int(steps), float(strength), float(controlnet_scale), use_cn)
-        eng = self._engine_for(plan_key, len(imgs), lane)
+        # The captured program depends on the frame size, the NUMBER of timesteps and the ControlNet switch; `strength`
+        # and `controlnet_scale` only change constants the graph reads from device memory (Engine.update_options): a
+        # slider drag in the client (server.py:163-197) does not rebuild or re-capture anything.
+        from .lcm import lcm_timesteps
+
+        n_eff = len(lcm_timesteps(float(strength), int(steps)))  # ValueError for an empty schedule: the caller's problem
+        plan_key = (height, width, int(steps), n_eff, use_cn)
+        opts = (float(strength), float(controlnet_scale))
+        eng = self._engine_for(plan_key, opts, len(imgs), lane)
         np.random.seed(seed)  # kept for parity with videopipeline.py:112 (nothing downstream consumes it)
         t0 = time.perf_counter()
         frames = np.stack([np.asarray(im if im.mode == "RGB" else im.convert("RGB"), dtype=np.uint8) for im in imgs])
@@ -259,27 +267,36 @@ class VideoSDPipeline:
         self._note("to_pil", t0)
         return res
 
-    def _engine_for(self, plan_key, batch: int, lane: int = 0):
-        """A prepared engine per (options, batch size, lane): the parent engine serves the first plan, slots (shared
-        weights, own arena / graph) serve the others, so switching between batch sizes costs nothing per frame."""
+    def _engine_for(self, plan_key, opts, batch: int, lane: int = 0):
+        """A prepared engine per (program, batch size, lane): the parent engine serves the first one, slots (shared
+        weights and constants, own arena / graph) serve the others, so switching between batch sizes costs nothing per
+        frame.  `opts` = (strength, controlnet_scale): a change rewrites the shared device constants, nothing else."""
+        height, width, steps, _n, use_cn = plan_key
+        strength, cn_scale = opts
+        if plan_key == self._plan_key and opts != self._opt_key:
+            self._require_idle("change strength / controlnet_scale")
+            t0 = time.perf_counter()
+            if not self.model.update_options(strength, cn_scale):  # (cannot happen: the timestep count is in the key)
+                self._plan_key = None
+            self._opt_key = opts
+            self._note("update_options", t0)
         key = (plan_key, batch, lane)
-        eng = self._engines.get(key)
+        eng = self._engines.get(key) if plan_key == self._plan_key else None
         if eng is not None:
             if eng in self._outstanding:
                 raise RuntimeError("this lane's previous launch has not been collected")
             return eng
-        height, width, steps, strength, cn_scale, use_cn = plan_key
         t0 = time.perf_counter()
-        # a new plan re-prepares the parent engine (and drops its slots); so does a full cache -- but never under a
+        # a new program re-prepares the parent engine (and drops its slots); so does a full cache -- but never under a
         # launch that is still running: the cache just grows until the lanes are idle
         evict = len(self._engines) >= self.max_plans and not self._outstanding
         if plan_key != self._plan_key or evict:
             self._require_idle("prepare another plan")
             self._engines.clear()
             self.model.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch)
-            self._plan_key = plan_key
+            self._plan_key, self._opt_key = plan_key, opts
             eng = self.model
-        else:  # same schedule constants as the parent's current plan: a slot suffices
+        else:  # same program and constants as the parent's current plan: a slot suffices
             eng = self.model.make_slot()
             eng.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch)
         self._engines[key] = eng
