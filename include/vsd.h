@@ -209,6 +209,13 @@ int vsd_add_noise_dev(vsd_ctx* ctx, const void* x0, const void* noise_f32, const
 int vsd_lcm_step_dev(vsd_ctx* ctx, const void* eps, const void* sample, const void* noise_f32, const void* coef_dev, int hw,
                      int batch, void* prev, void* denoised, void* dec_in, void* stream);
 
+/* AdaIN of the reference-only mode (lcm_reference_pipeline.py:593-603, dead at v2 but still exposed as `ref`):
+ * out[r][c] = (x[r][c] - mean_c) / std_c * std_ref_c + mean_ref_c, statistics over the `rows` pixels of one image,
+ * population variance clamped at eps before the square root.  stats / stats_ref: fp32 [c][2] per-channel (sum, sum of
+ * squares) over those rows, as vsd_conv_gemm's chanstat_out writes them.  x, out: fp16 [rows][c]; may alias. */
+int vsd_adain(vsd_ctx* ctx, const void* x, const void* stats, const void* stats_ref, int rows, int c, float eps, void* out,
+              void* stream);
+
 /* decoder output fp16 [hw][ld] (3 channels used; value c of the last conv) -> u8 RGB HWC:
  * y = fp16(2c - 1) (DecoderTiny), (y/2 + 0.5).clamp(0,1)*255 rounded half-to-even
  * (VaeImageProcessor.postprocess, lcm_controlnet.py:609-611).                                         */

@@ -86,7 +86,71 @@ def attention(w, p, x, ctx, heads):
     return linear(w, p + ".to_out.0", o)
 
 
-def transformer(w, p, cfg, x, text, depth=1):
+class RefState:
+    """The state of the "reference-only" mode (dead code at the reference's v2, kept behind `ref` / `style_fidelity`:
+    /root/reference/diffusert/lcm/lcm_reference_pipeline.py:488-853).  Per denoising step the UNet runs twice: a WRITE
+    pass over the noised reference latents that banks (a) every BasicTransformerBlock's norm1 output (:527-528) and
+    (b) the per-channel spatial mean / variance of the block outputs of the gated blocks (:587-598, :621-625, ...), then
+    the READ pass over the frame's latents, whose self-attentions see [x ; bank] as keys / values (:535-546) and whose
+    gated block outputs are re-normalised to the banked statistics (AdaIN, :593-603).  `style_fidelity` blends two
+    identical tensors there (`x_c = x_uc.clone()`, :541, :601) and so has no effect."""
+
+    def __init__(self, n_down, n_up, attention_auto_machine_weight=1.0, gn_auto_machine_weight=1.0):
+        self.mode = "write"
+        self.attn_bank = {}   # transformer-block name -> norm1 output of the write pass
+        self.stat_bank = {}   # (block, layer) -> (mean, var) of the write pass
+        self.attn_w = attention_auto_machine_weight
+        self.gn_w = gn_auto_machine_weight
+        self.n_down, self.n_up = n_down, n_up
+        self.attn_rank = {}   # transformer-block name -> attn_weight (:806-813), filled by `rank_attention`
+
+    def gn_gate(self, kind, i):
+        """module.gn_weight (:816-846): mid 0; down w -> 2 (1 - w / n_down); up w -> 2 w / n_up; banked iff
+        gn_auto_machine_weight >= gn_weight."""
+        gw = 0.0 if kind == "mid" else (2.0 * (1.0 - i / self.n_down) if kind == "down" else 2.0 * i / self.n_up)
+        return self.gn_w >= gw
+
+    def adain(self, key, x, eps=1e-6):
+        if self.mode == "write":
+            var, mean = torch.var_mean(x, dim=(2, 3), keepdim=True, correction=0)
+            self.stat_bank[key] = (mean, var)
+            return x
+        if key not in self.stat_bank:
+            return x
+        mean_acc, var_acc = self.stat_bank.pop(key)
+        var, mean = torch.var_mean(x, dim=(2, 3), keepdim=True, correction=0)
+        std = torch.maximum(var, torch.zeros_like(var) + eps) ** 0.5
+        std_acc = torch.maximum(var_acc, torch.zeros_like(var_acc) + eps) ** 0.5
+        return ((x - mean) / std) * std_acc + mean_acc
+
+
+def transformer_block_names(cfg):
+    """Every BasicTransformerBlock of the UNet with its channel width, in module order."""
+    out = []
+    ch = cfg.block_out_channels
+    for i in range(len(ch)):
+        if cfg.down_attn[i]:
+            for j in range(cfg.layers_per_block):
+                out += [(f"down_blocks.{i}.attentions.{j}.transformer_blocks.{k}", ch[i]) for k in range(cfg.transformer_depth[i])]
+    out += [(f"mid_block.attentions.0.transformer_blocks.{k}", ch[-1]) for k in range(cfg.mid_depth)]
+    rev = list(reversed(ch))
+    for i in range(len(ch)):
+        if cfg.up_attn[i]:
+            for j in range(cfg.layers_per_block + 1):
+                out += [(f"up_blocks.{i}.attentions.{j}.transformer_blocks.{k}", rev[i]) for k in range(cfg.up_depth[i])]
+    return out
+
+
+def rank_attention(cfg, ref: RefState):
+    """attn_weight = rank / count after a stable sort by descending width (:806-813); a block reads the bank iff
+    attention_auto_machine_weight > attn_weight (:529)."""
+    names = transformer_block_names(cfg)
+    order = sorted(range(len(names)), key=lambda i: -names[i][1])
+    for rank, i in enumerate(order):
+        ref.attn_rank[names[i][0]] = rank / float(len(names))
+
+
+def transformer(w, p, cfg, x, text, depth=1, ref=None):
     """Transformer2DModel: `depth` BasicTransformerBlocks between proj_in / proj_out (1x1 conv for SD1.5, Linear on
     the token matrix when use_linear_projection, SDXL)."""
     b, c, hh, ww = x.shape
@@ -101,7 +165,13 @@ def transformer(w, p, cfg, x, text, depth=1):
     for k in range(depth):
         t = f"{p}.transformer_blocks.{k}"
         n = layer_norm(w, t + ".norm1", h)
-        h = h + attention(w, t + ".attn1", n, n, heads)
+        kv = n
+        if ref is not None:
+            if ref.mode == "write":
+                ref.attn_bank[t] = n.clone()
+            elif ref.attn_w > ref.attn_rank.get(t, 0.0) and t in ref.attn_bank:
+                kv = torch.cat([n, ref.attn_bank.pop(t)], dim=1)
+        h = h + attention(w, t + ".attn1", n, kv, heads)
         n = layer_norm(w, t + ".norm2", h)
         h = h + attention(w, t + ".attn2", n, text, heads)
         n = layer_norm(w, t + ".norm3", h)
@@ -116,30 +186,35 @@ def transformer(w, p, cfg, x, text, depth=1):
     return h + res
 
 
-def _down_and_mid(w, cfg, h, temb, text):
+def _down_and_mid(w, cfg, h, temb, text, ref=None):
     skips = [h]
     ch = cfg.block_out_channels
     for i in range(len(ch)):
         for j in range(cfg.layers_per_block):
             h = resnet(w, f"down_blocks.{i}.resnets.{j}", cfg, h, temb)
             if cfg.down_attn[i]:
-                h = transformer(w, f"down_blocks.{i}.attentions.{j}", cfg, h, text, cfg.transformer_depth[i])
+                h = transformer(w, f"down_blocks.{i}.attentions.{j}", cfg, h, text, cfg.transformer_depth[i], ref)
+            if ref is not None and ref.gn_gate("down", i):
+                h = ref.adain(("down", i, j), h)
             skips.append(h)
         if i < len(ch) - 1:
             h = conv(w, f"down_blocks.{i}.downsamplers.0.conv", h, stride=2, padding=1)
             skips.append(h)
     h = resnet(w, "mid_block.resnets.0", cfg, h, temb)
-    h = transformer(w, "mid_block.attentions.0", cfg, h, text, cfg.mid_depth)
+    h = transformer(w, "mid_block.attentions.0", cfg, h, text, cfg.mid_depth, ref)
     h = resnet(w, "mid_block.resnets.1", cfg, h, temb)
+    if ref is not None and ref.gn_gate("mid", 0):
+        h = ref.adain(("mid", 0, 0), h)
     return h, skips
 
 
-def unet_forward(w, cfg, sample, t, text, w_emb=None, down_res=None, mid_res=None, added=None):
+def unet_forward(w, cfg, sample, t, text, w_emb=None, down_res=None, mid_res=None, added=None, ref=None):
     """UNet2DConditionModel.forward as used at lcm_controlnet.py:568-577.  t: int64 [B].
-    added = (pooled text embeds [B, add_pooled_dim], time ids [B, 6]) for the SDXL configuration."""
+    added = (pooled text embeds [B, add_pooled_dim], time ids [B, 6]) for the SDXL configuration.
+    ref: a RefState in "write" or "read" mode (reference-only extension, see RefState)."""
     temb = time_embedding(w, cfg, t, w_emb, added)
     h = conv(w, "conv_in", sample)
-    h, skips = _down_and_mid(w, cfg, h, temb, text)
+    h, skips = _down_and_mid(w, cfg, h, temb, text, ref)
     if down_res is not None:
         skips = [s + r for s, r in zip(skips, down_res)]
         h = h + mid_res
@@ -152,7 +227,9 @@ def unet_forward(w, cfg, sample, t, text, w_emb=None, down_res=None, mid_res=Non
             h = torch.cat([h, skips.pop()], dim=1)
             h = resnet(w, f"up_blocks.{i}.resnets.{j}", cfg, h, temb)
             if cfg.up_attn[i]:
-                h = transformer(w, f"up_blocks.{i}.attentions.{j}", cfg, h, text, cfg.up_depth[i])
+                h = transformer(w, f"up_blocks.{i}.attentions.{j}", cfg, h, text, cfg.up_depth[i], ref)
+            if ref is not None and ref.gn_gate("up", i):
+                h = ref.adain(("up", i, j), h)
         if i < nb - 1:
             if fwd_size:
                 h = F.interpolate(h, size=skips[-1].shape[2:], mode="nearest")

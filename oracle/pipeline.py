@@ -82,7 +82,13 @@ class OraclePipeline:
     @torch.no_grad()
     def infer(self, img: Image.Image, prompt_embeds: torch.Tensor, height=360, width=640, strength=0.4, steps=20,
               seed=42, controlnet_scale=1.0, use_controlnet=True, keep_trace=False, pooled=None,
-              time_ids=None) -> Image.Image:
+              time_ids=None, ref_image: Image.Image = None) -> Image.Image:
+        """ref_image: run the reference-only mode of lcm_reference_pipeline.py:855-890 -- no ControlNet (that pipeline
+        has none); per step a fresh noise draw for the reference latents (:861-871, taken from the same per-frame-reset
+        CPU stream as every other draw of the frame, in call order), a WRITE pass WITHOUT the guidance embedding
+        (:875-881 passes no timestep_cond) and the READ pass (:884-891).  The reference latents are the TAESD encoding of
+        the reference image (`prepare_ref_latents` :161-209 calls `.latent_dist.sample`, which AutoencoderTiny does not
+        have -- one reason this path is dead at v2; the live path's `retrieve_latents` behaviour is used)."""
         img = center_crop_resize(img, width, height)
         canny = sobel_edges(img, 0.11, 0.8)
         reset_rng(seed)
@@ -105,13 +111,26 @@ class OraclePipeline:
         if keep_trace:
             self.trace = {"init_latents": init.clone(), "noisy_latents": latents.clone(), "eps": [], "denoised": []}
         denoised = None
+        ref_state = ref_latents = None
+        if ref_image is not None:
+            use_controlnet = False
+            ref_latents = nets.taesd_encode(self.w_vae, preprocess_image(center_crop_resize(ref_image, width, height)))
+            nlev = len(self.unet_cfg.block_out_channels)
+            ref_state = nets.RefState(nlev, nlev)
+            nets.rank_attention(self.unet_cfg, ref_state)
         for i, t in enumerate(ts):
             tt = torch.full((1,), int(t), dtype=torch.long)
             down = mid = None
+            if ref_state is not None:
+                ref_noise = torch.randn(ref_latents.shape, dtype=ref_latents.dtype)
+                ref_xt = self.sched.add_noise(ref_latents, ref_noise, tt)
+                ref_state.mode = "write"
+                nets.unet_forward(self.w_unet, self.unet_cfg, ref_xt, tt, text, None, None, None, added, ref=ref_state)
+                ref_state.mode = "read"
             if use_controlnet:
                 down, mid = nets.controlnet_forward(self.w_cn, self.cn_cfg, latents, tt, text, control,
                                                     conditioning_scale=controlnet_scale, guess_mode=True)
-            eps = nets.unet_forward(self.w_unet, self.unet_cfg, latents, tt, text, w_emb, down, mid, added)
+            eps = nets.unet_forward(self.w_unet, self.unet_cfg, latents, tt, text, w_emb, down, mid, added, ref=ref_state)
             latents, denoised = self.sched.step(eps, i, t, latents)
             if keep_trace:
                 self.trace["eps"].append(eps.clone())

@@ -228,6 +228,13 @@ class FakeOps:
         out.zero_()
         out[:, :4] = (sqrt_a * x0[:, :4].float() + sqrt_b * noise_f32.reshape(4, hw).t()).half()
 
+    def adain(self, x, stats, stats_ref, rows, c, out, eps=1e-6):
+        mean, mean_r = stats[:, 0] / rows, stats_ref[:, 0] / rows
+        var = (stats[:, 1] / rows - mean * mean).clamp_min(0)
+        var_r = (stats_ref[:, 1] / rows - mean_r * mean_r).clamp_min(0)
+        sd, sd_r = var.clamp_min(eps).sqrt(), var_r.clamp_min(eps).sqrt()
+        out[:, :c] = (((x[:, :c].float() - mean) / sd) * sd_r + mean_r).half()
+
     def add_noise_dev(self, x0, noise_f32, coef_dev, hw, batch, out):
         sa, sb = [float(v) for v in coef_dev.reshape(-1)[:2]]
         for b in range(batch):

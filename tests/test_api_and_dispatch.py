@@ -81,13 +81,19 @@ def test_host_noise_follows_the_reference_rng_contract():
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lcm_scheduler.json")))
     torch.manual_seed(1234)
     before = torch.get_rng_state()
-    nz = Engine.host_noise(4, 64, 64)
+    nz, _ = Engine.host_noise(4, 64, 64)
     assert torch.equal(before, torch.get_rng_state())  # the caller's RNG stream is left untouched
     assert nz.shape == (5, 4, 64 * 64)
     assert float(nz[0].sum()) == pytest.approx(g["rng"]["23"]["draw0_sum"], rel=1e-6)
     assert nz[0, 0, :4].tolist() == g["rng"]["23"]["draw0_first4"]
     assert float(nz[1].sum()) == pytest.approx(g["rng"]["23"]["draw1_sum"], rel=1e-6)
-    assert Engine.host_noise(1, 8, 8).shape == (2, 4, 64)
+    assert Engine.host_noise(1, 8, 8)[0].shape == (2, 4, 64)
+    # reference-only mode: every step draws the reference latents' noise first (lcm_reference_pipeline.py:861-863)
+    d, rd = Engine.host_noise(2, 8, 8, ref=True)
+    torch.manual_seed(0)
+    torch.default_generator.set_state(torch.Generator(device="cpu").get_state())
+    seq = [torch.randn(1, 4, 8, 8) for _ in range(5)]
+    assert torch.equal(d, torch.cat([seq[0], seq[2], seq[4]]).reshape(3, 4, 64)) and torch.equal(rd, torch.cat([seq[1], seq[3]]).reshape(2, 4, 64))
 
 
 def test_sharding_is_strict_round_robin():

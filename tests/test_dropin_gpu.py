@@ -80,9 +80,14 @@ def test_slider_options_do_not_rebuild_the_plan(pipe):
     assert len(pipe._host_ms["prepare"]) == n_prep and pipe.model.graph is graph  # nothing was prepared or captured
     assert len(pipe._host_ms["update_options"]) >= 2
     assert not np.array_equal(a, base) and not np.array_equal(b, base)
+    # a pipeline built with those options from scratch gives the same frames (another instance times its own tile /
+    # split-K choices for shapes missing from the tuning table, so the fp32 summation order may differ by a few LSB;
+    # the bit-exact form of this check, on one engine, is test_option_sweep_with_one_capture_matches_fresh_prepares)
     fresh = VideoSDPipeline(**CFG)
-    assert np.array_equal(np.asarray(fresh.infer(img, **{**OPTS, "controlnet_scale": 2.25})), a)
-    assert np.array_equal(np.asarray(fresh.infer(img, **{**OPTS, "strength": 0.7})), b)
+    fa = np.asarray(fresh.infer(img, **{**OPTS, "controlnet_scale": 2.25}))
+    fb = np.asarray(fresh.infer(img, **{**OPTS, "strength": 0.7}))
+    assert np.abs(fa.astype(int) - a.astype(int)).mean() < 0.5 and np.abs(fb.astype(int) - b.astype(int)).mean() < 0.5
+    assert np.abs(fa.astype(int) - base.astype(int)).mean() > 0.5
     assert np.array_equal(np.asarray(pipe.infer(img, **OPTS)), base)  # and back
     # two lanes: a launch in flight pins its plan / prompt
     h = pipe.submit_batch([img], lane=0, **OPTS)
@@ -93,6 +98,31 @@ def test_slider_options_do_not_rebuild_the_plan(pipe):
     assert np.array_equal(np.asarray(pipe.collect_batch(h)[0]), base)
     with pytest.raises(ValueError):
         pipe.infer(img, **{**OPTS, "strength": 0.01})  # empty schedule: the caller's error, typed as such
+
+
+def test_reference_only_mode_through_the_drop_in_class():
+    """`infer(..., ref=True)` with `honor_ref_flag=True` runs the reference-only program (banked
+    self-attention + AdaIN, lcm_reference_pipeline.py:498-794) on the HIP kernels, against the oracle restatement; with
+    the flag off (default) `ref` is accepted and ignored like the reference's v2 (videopipeline.py:84-85)."""
+    from oracle.pipeline import OraclePipeline
+    from videosd_amd import config as C
+    from videosd_amd import weights as W
+    from videosd_amd.pipeline import VideoSDPipeline
+
+    p = VideoSDPipeline(honor_ref_flag=True, **CFG)
+    img, refimg = _photo(300, 200, 21), _photo(320, 240, 22)
+    p.set_reference(refimg)
+    opts = dict(prompt="a watercolor painting", height=128, width=192, strength=0.6, steps=2, seed=7)
+    got = np.asarray(p.infer(img, ref=True, **opts))
+    wu = W.synthesize(W.unet_spec(C.SD15_UNET), "unet.", device="cuda")
+    wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda")
+    orc = OraclePipeline(C.SD15_UNET, C.SD15_CONTROLNET, _cpu(wu), None, _cpu(wv))
+    text = p.encode_prompt(opts["prompt"])
+    want = np.asarray(orc.infer(img, text[None].float(), height=128, width=192, strength=0.6, steps=2, seed=7, ref_image=refimg))
+    assert np.abs(got.astype(int) - want.astype(int)).mean() <= 1.5 and _psnr(got, want) >= 38.0
+    plain = np.asarray(p.infer(img, ref=False, **opts))
+    assert np.abs(plain.astype(int) - got.astype(int)).mean() > 1.0  # the mode changes the frame
+    assert np.array_equal(np.asarray(p.infer(img, ref=True, **opts)), got)  # deterministic replay of the captured graph
 
 
 def test_remote_handle_across_a_process_boundary(pipe):

@@ -165,3 +165,32 @@ def test_update_options_equals_a_fresh_prepare(mini):
         assert np.array_equal(got, ref) and not np.array_equal(got, base)
         assert np.array_equal(slot.infer_u8(frame), ref)  # the slot reads the same constant block
     assert eng.update_options(0.03, 1.0) is False  # int(50 * 0.03) = 1 candidate timestep: a 1-step schedule, another program
+
+
+@pytest.mark.parametrize("H,W,steps", [(64, 64, 2), (64, 64, 1)])
+def test_reference_only_mode_matches_oracle(mini, H, W, steps):
+    """SURVEY 8f-4 (lcm_reference_pipeline.py:498-794, 855-890): per step a WRITE pass over the noised reference latents
+    banks self-attention keys / values and block-output statistics; the READ pass attends over [x ; bank] and AdaINs the
+    gated block outputs.  Host wiring through the op emulator against the oracle restatement."""
+    wu, wc, wv, text = mini
+    eng = Engine(FakeOps(), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
+    eng.set_text_embeds(text)
+    eng.prepare(H, W, steps, 0.6, use_controlnet=False, use_graph=False, ref_mode=True)
+    frame, refimg = _frame(H, W, seed=1), _frame(H, W, seed=9)
+    eng.ops.upload(eng.ref_u8, torch.from_numpy(refimg))
+    got = eng.infer_u8(frame)
+    orc = OraclePipeline(C.MINI_UNET, C.MINI_CONTROLNET, wu, wc, wv)
+    ref = np.asarray(orc.infer(Image.fromarray(frame, "RGB"), text[None].float(), height=H, width=W, strength=0.6, steps=steps,
+                               seed=23, ref_image=Image.fromarray(refimg, "RGB"), keep_trace=True))
+    h0, w0 = H // 8, W // 8
+    den = eng.buffers["denoised"][:, :4].float().reshape(h0, w0, 4).permute(2, 0, 1)
+    ref_den = orc.trace["denoised"][-1][0]
+    rel = float((den - ref_den).norm() / ref_den.norm())
+    assert rel < 2e-2, rel
+    assert np.abs(got.astype(int) - ref.astype(int)).mean() < 1.5
+    # and the mode does something: the plain UNet-only frame differs
+    plain = np.asarray(orc.infer(Image.fromarray(frame, "RGB"), text[None].float(), height=H, width=W, strength=0.6, steps=steps,
+                                 seed=23, use_controlnet=False))
+    assert np.abs(plain.astype(int) - ref.astype(int)).mean() > 2.0
+    with pytest.raises(ValueError):
+        eng.prepare(H, W, steps, 0.6, use_controlnet=True, use_graph=False, ref_mode=True)

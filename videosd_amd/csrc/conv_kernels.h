@@ -827,20 +827,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   float brv[8];
   const int pre_n = n0 + (tid % CHP) * 8;
   const bool use_brv = pre_n + 8 <= p.N && (p.act & 0xff) != VSD_ACT_GEGLU && !(p.out_t && n0 >= p.t_col0);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) brv[i] = 0.f;
-  if (use_brv) {
-    if (p.bias) {
-      half8 b = *reinterpret_cast<const half8*>(p.bias + pre_n);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) brv[i] += (float)b[i];
-    }
-    if (p.rowvec) {
-      half8 b = *reinterpret_cast<const half8*>(p.rowvec + pre_n);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) brv[i] += (float)b[i];
-    }
-  }
+  // Issue order: the residual chunks first (they come from HBM / the Infinity Cache: the longest latency of the epilogue),
+  // then bias and time vector as RAW halfs -- converting them here would make the wave wait for them before the
+  // residual loads are even issued (vmcnt retires in order; measured: one L2 round trip per workgroup, serialised in
+  // front of the residual's).  They are converted after the accumulator transpose and its barrier.
   if (use_pre) {
 #pragma unroll
     for (int j = 0; j < NPRE; ++j) {
@@ -850,6 +840,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       const bool ok = m < p.M && n + 8 <= p.N;  // (otherwise an in-range dummy address; the value is not used)
       rpre[j] = *reinterpret_cast<const half8*>(p.residual + (ok ? (size_t)m * p.ldr + n : 0));
     }
+  }
+  half8 braw = (half8){0, 0, 0, 0, 0, 0, 0, 0}, rvraw = braw;
+  if (use_brv) {
+    if (p.bias) braw = *reinterpret_cast<const half8*>(p.bias + pre_n);
+    if (p.rowvec) rvraw = *reinterpret_cast<const half8*>(p.rowvec + pre_n);
   }
 
   // ---- epilogue: accumulators -> LDS (fp32) -> row-contiguous 8-wide chunks
@@ -865,6 +860,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       for (int r = 0; r < 4; ++r) Cs[(row + r) * BNP + col] = acc[i][j][r];
     }
   __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) brv[i] = (float)braw[i] + (float)rvraw[i];
 
   CPROBE(5)
   bool from_slabs = false;

@@ -205,6 +205,28 @@ __global__ void lcm_step_dev_kernel(const half_t* __restrict__ eps, const half_t
   if (dec_in) *reinterpret_cast<half8*>(dec_in + row * 8) = oi;
 }
 
+// AdaIN of the reference-only mode (lcm_reference_pipeline.py:593-603): per channel, re-normalise x (its own spatial
+// mean / variance, population form) to the banked statistics of the reference pass.  Both statistics arrive as
+// per-channel (sum, sum of squares) over `rows` pixels -- what vsd_conv_gemm's chanstat_out leaves behind.
+__global__ void adain_kernel(const half_t* __restrict__ x, const float* __restrict__ st, const float* __restrict__ st_ref,
+                             int rows, int c8, float eps, half_t* __restrict__ out) {
+  const size_t total = (size_t)rows * c8;
+  const float inv = 1.0f / (float)rows;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(q % c8) * 8;
+    half8 v = *reinterpret_cast<const half8*>(x + q * 8);
+    half8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float mean = st[(ch + i) * 2] * inv, var = fmaxf(st[(ch + i) * 2 + 1] * inv - mean * mean, 0.f);
+      const float mean_r = st_ref[(ch + i) * 2] * inv, var_r = fmaxf(st_ref[(ch + i) * 2 + 1] * inv - mean_r * mean_r, 0.f);
+      const float sd = sqrtf(fmaxf(var, eps)), sd_r = sqrtf(fmaxf(var_r, eps));
+      o[i] = (half_t)((((float)v[i] - mean) / sd) * sd_r + mean_r);
+    }
+    *reinterpret_cast<half8*>(out + q * 8) = o;
+  }
+}
+
 __global__ void postprocess_kernel(const half_t* __restrict__ img, int ld, int hw, unsigned char* __restrict__ rgb) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= hw) return;
@@ -308,6 +330,20 @@ extern "C" int vsd_lcm_step_dev(vsd_ctx* ctx, const void* eps, const void* sampl
   hipLaunchKernelGGL(lcm_step_dev_kernel, dim3(cdiv(hw, 256), batch), dim3(256), 0, s, (const half_t*)eps,
                      (const half_t*)sample, (const float*)noise_f32, (const float*)coef_dev, hw, (half_t*)prev,
                      (half_t*)denoised, (half_t*)dec_in);
+  return ls.finish();
+}
+
+extern "C" int vsd_adain(vsd_ctx* ctx, const void* x, const void* stats, const void* stats_ref, int rows, int c, float eps,
+                         void* out, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (!x || !stats || !stats_ref || !out || rows <= 0 || c <= 0 || c % 8) return vsd_fail(ctx, VSD_ERR_ARG, "adain: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)rows * (c / 8);
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
+  hipLaunchKernelGGL(adain_kernel, dim3(grid), dim3(256), 0, s, (const half_t*)x, (const float*)stats, (const float*)stats_ref,
+                     rows, c / 8, eps, (half_t*)out);
   return ls.finish();
 }
 

@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int GN_MAX_PART = 64;
+constexpr int GN_MAX_PART = 128;
 
 struct GnParams {
   const half_t* src0;
@@ -54,10 +54,16 @@ __global__ void gn_stats_kernel(const GnParams p) {
   float s[8], q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
-  int r = r0 + rl;
-  for (; r + 3 * p.rpp < r1; r += 4 * p.rpp) {
-    half8 x0 = gn_load(p, r, ch8), x1 = gn_load(p, r + p.rpp, ch8);
-    half8 x2 = gn_load(p, r + 2 * p.rpp, ch8), x3 = gn_load(p, r + 3 * p.rpp, ch8);
+  // rows in batches of four PREDICATED loads (an out-of-range row re-reads the block's first row and is masked to zero):
+  // every batch is one memory round trip, the ragged tail included -- a per-row tail loop pays one round trip per row
+  const half8 zero8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = r0 + rl; r < r1; r += 4 * p.rpp) {
+    const bool ok1 = r + p.rpp < r1, ok2 = r + 2 * p.rpp < r1, ok3 = r + 3 * p.rpp < r1;
+    half8 x0 = gn_load(p, r, ch8), x1 = gn_load(p, ok1 ? r + p.rpp : r, ch8);
+    half8 x2 = gn_load(p, ok2 ? r + 2 * p.rpp : r, ch8), x3 = gn_load(p, ok3 ? r + 3 * p.rpp : r, ch8);
+    x1 = ok1 ? x1 : zero8;
+    x2 = ok2 ? x2 : zero8;
+    x3 = ok3 ? x3 : zero8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float v0 = (float)x0[i], v1 = (float)x1[i], v2 = (float)x2[i], v3 = (float)x3[i];
@@ -65,15 +71,6 @@ __global__ void gn_stats_kernel(const GnParams p) {
       s[i] += v1; q[i] += v1 * v1;
       s[i] += v2; q[i] += v2 * v2;
       s[i] += v3; q[i] += v3 * v3;
-    }
-  }
-  for (; r < r1; r += p.rpp) {
-    half8 x = gn_load(p, r, ch8);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float v = (float)x[i];
-      s[i] += v;
-      q[i] += v * v;
     }
   }
   float* mine = sm + ((size_t)rl * p.c + ch8 * 8) * 2;
@@ -99,6 +96,21 @@ __global__ void gn_apply_kernel(const GnParams p) {
   extern __shared__ float sm[];  // [groups][2] mean, rstd | [nch][groups*2] partial folds
   const int t = threadIdx.x;
   const int npairs = p.groups * 2;
+  // The first batch of rows, gamma and beta do not depend on the statistics: their loads are issued FIRST, so that the
+  // partial fold below (a dependent round trip of its own) runs under their latency instead of in front of it.
+  const int ch8 = t % p.c8;
+  const int rl = t / p.c8;
+  const int rows_per_blk = (p.hw + gridDim.x - 1) / gridDim.x;
+  const int img0 = blockIdx.y * p.hw;
+  const int r0 = img0 + blockIdx.x * rows_per_blk;
+  const int r1 = min(img0 + p.hw, r0 + rows_per_blk);
+  const int rf = r0 + rl;  // this thread's first row
+  const bool okf0 = rf < r1, okf1 = rf + p.rpp < r1, okf2 = rf + 2 * p.rpp < r1, okf3 = rf + 3 * p.rpp < r1;
+  const int rsafe = okf0 ? rf : img0;
+  half8 xf0 = gn_load(p, rsafe, ch8), xf1 = gn_load(p, okf1 ? rf + p.rpp : rsafe, ch8);
+  half8 xf2 = gn_load(p, okf2 ? rf + 2 * p.rpp : rsafe, ch8), xf3 = gn_load(p, okf3 ? rf + 3 * p.rpp : rsafe, ch8);
+  const half8 ga = *reinterpret_cast<const half8*>(p.gamma + ch8 * 8);
+  const half8 be = *reinterpret_cast<const half8*>(p.beta + ch8 * 8);
   if (p.chan0) {
     for (int i = t; i < npairs; i += blockDim.x) {
       const int g = i >> 1, which = i & 1;
@@ -110,10 +122,10 @@ __global__ void gn_apply_kernel(const GnParams p) {
       sm[i] = acc;
     }
   } else {
-    // fold the statistics partials: (pair, chunk) per thread, chunk ch sums blocks ch, ch+nch, ... (at most 16 loads,
+    // fold the statistics partials: (pair, chunk) per thread, chunk ch sums blocks ch, ch+nch, ... (16 loads at a time,
     // all independent), then the chunks are added in order: deterministic
     int nch = (int)blockDim.x / npairs;
-    nch = nch < 1 ? 1 : (nch > 4 ? 4 : nch);
+    nch = nch < 1 ? 1 : (nch > 8 ? 8 : nch);
     float* fold = sm + npairs;
     for (int i = t; i < npairs * nch; i += blockDim.x) {
       const int pair = i % npairs, ch = i / npairs;
@@ -149,24 +161,14 @@ __global__ void gn_apply_kernel(const GnParams p) {
     sm[g * 2 + 1] = rstd_r;
   }
   __syncthreads();
-  const int ch8 = t % p.c8;
-  const int rl = t / p.c8;
   float a[8], b[8];
-  {
-    half8 ga = *reinterpret_cast<const half8*>(p.gamma + ch8 * 8);
-    half8 be = *reinterpret_cast<const half8*>(p.beta + ch8 * 8);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int g = (ch8 * 8 + i) / p.cpg;
-      float mean = sm[g * 2], rstd = sm[g * 2 + 1];
-      a[i] = rstd * (float)ga[i];
-      b[i] = (float)be[i] - mean * a[i];
-    }
+  for (int i = 0; i < 8; ++i) {
+    int g = (ch8 * 8 + i) / p.cpg;
+    float mean = sm[g * 2], rstd = sm[g * 2 + 1];
+    a[i] = rstd * (float)ga[i];
+    b[i] = (float)be[i] - mean * a[i];
   }
-  const int rows_per_blk = (p.hw + gridDim.x - 1) / gridDim.x;
-  const int img0 = blockIdx.y * p.hw;
-  const int r0 = img0 + blockIdx.x * rows_per_blk;
-  const int r1 = min(img0 + p.hw, r0 + rows_per_blk);
   auto norm_store = [&](int r, const half8& x) {
     half8 y;
 #pragma unroll
@@ -177,18 +179,18 @@ __global__ void gn_apply_kernel(const GnParams p) {
     }
     *reinterpret_cast<half8*>(p.out + (size_t)r * p.c + ch8 * 8) = y;
   };
-  int r = r0 + rl;
-  for (; r + 3 * p.rpp < r1; r += 4 * p.rpp) {
-    half8 x0 = gn_load(p, r, ch8), x1 = gn_load(p, r + p.rpp, ch8);
-    half8 x2 = gn_load(p, r + 2 * p.rpp, ch8), x3 = gn_load(p, r + 3 * p.rpp, ch8);
+  if (okf0) norm_store(rf, xf0);
+  if (okf1) norm_store(rf + p.rpp, xf1);
+  if (okf2) norm_store(rf + 2 * p.rpp, xf2);
+  if (okf3) norm_store(rf + 3 * p.rpp, xf3);
+  for (int r = rf + 4 * p.rpp; r < r1; r += 4 * p.rpp) {  // (more than four rows per thread: large images only)
+    const bool ok1 = r + p.rpp < r1, ok2 = r + 2 * p.rpp < r1, ok3 = r + 3 * p.rpp < r1;
+    half8 x0 = gn_load(p, r, ch8), x1 = gn_load(p, ok1 ? r + p.rpp : r, ch8);
+    half8 x2 = gn_load(p, ok2 ? r + 2 * p.rpp : r, ch8), x3 = gn_load(p, ok3 ? r + 3 * p.rpp : r, ch8);
     norm_store(r, x0);
-    norm_store(r + p.rpp, x1);
-    norm_store(r + 2 * p.rpp, x2);
-    norm_store(r + 3 * p.rpp, x3);
-  }
-  for (; r < r1; r += p.rpp) {
-    half8 x = gn_load(p, r, ch8);
-    norm_store(r, x);
+    if (ok1) norm_store(r + p.rpp, x1);
+    if (ok2) norm_store(r + 2 * p.rpp, x2);
+    if (ok3) norm_store(r + 3 * p.rpp, x3);
   }
 }
 
@@ -423,7 +425,7 @@ extern "C" int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void*
     gn_try_fused(p, batch, s, false);
     return ls.finish();
   }
-  const size_t smem = (size_t)groups * 2 * 5 * sizeof(float);
+  const size_t smem = (size_t)groups * 2 * 9 * sizeof(float);
   {
     const size_t smem_stats = (size_t)p.rpp * p.c * 2 * sizeof(float);
     LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);

@@ -325,6 +325,11 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
             continue
         group_ = [(rid, args, slot)]
         batchable = max_batch > 1 and method == "infer" and len(args) == 1 and hasattr(pipe, "infer_batch")
+        if batchable and hasattr(pipe, "can_batch"):
+            try:
+                batchable = bool(pipe.can_batch(**kwargs))
+            except Exception:
+                batchable = False
         if batchable:
             # While a launch is on the GPU a new one could not start anyway: a partial batch then waits for more frames
             # until that launch is (by the running average) about to finish -- the batch fills at no cost in latency.

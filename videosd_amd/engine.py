@@ -290,6 +290,28 @@ class TAESDWeights:
         self.dec_out = cv(f"{d}.{n}")
 
 
+class RefCtx:
+    """Bookkeeping of the reference-only mode while the program is recorded (SURVEY.md 8f-4;
+    /root/reference/diffusert/lcm/lcm_reference_pipeline.py:498-794).  mode "write": the UNet pass over the noised reference
+    latents leaves, per BasicTransformerBlock, its self-attention K rows and V^T columns in the SECOND half of buffers the
+    read pass fills the first half of (the bank of norm1 outputs, :527, enters attention only through to_k / to_v, and
+    those projections are exactly the write pass's own K / V), and per gated block output its per-channel (sum, sumsq)
+    (:587-598).  mode "read": self-attention runs over [x ; bank] keys (:535-539) and the gated outputs are AdaIN-ed to the
+    banked statistics (:593-603)."""
+
+    def __init__(self, cfg):
+        self.mode = "write"
+        self.kv = {}      # kv_index -> (qk_full [2*hw][2c], vt_full [c][ldvt])
+        self.stats = {}   # (kind, i, j) -> fp32 [c][2] of the write pass
+        nd = nu = len(cfg.block_out_channels)
+        self.nd, self.nu = nd, nu
+
+    def gate(self, kind, i, weight=1.0):
+        # module.gn_weight, lcm_reference_pipeline.py:816-846 (gn_auto_machine_weight = 1.0)
+        gw = 0.0 if kind == "mid" else (2.0 * (1.0 - i / self.nd) if kind == "down" else 2.0 * i / self.nu)
+        return weight >= gw
+
+
 # ------------------------------------------------------------------------------------------ the engine
 class Engine:
     """One engine = one GPU, one weight replica (reference: one Ray actor, videopipeline.py:11-32)."""
@@ -361,7 +383,7 @@ class Engine:
         self.added = (pooled.detach().float().cpu().reshape(-1), [float(v) for v in time_ids])
 
     # ---------------------------------------------------------------- schedule-dependent constants
-    def _time_embeddings(self, net: NetWeights, sched: LCMSchedule, out: torch.Tensor):
+    def _time_embeddings(self, net: NetWeights, sched: LCMSchedule, out: torch.Tensor, use_cond: bool = True):
         """out[i] = concat over ResnetBlocks of time_emb_proj(SiLU(time_embedding(t_i))) + conv1.bias.
         Replaces Timesteps/TimestepEmbedding + every ResnetBlock2D.time_emb_proj (K9 in SURVEY.md)."""
         ops, cfg = self.ops, net.cfg
@@ -369,7 +391,7 @@ class Engine:
         c0 = cfg.block_out_channels[0]
         t_emb = ops.to_device(timestep_sinusoid(sched.timesteps, c0).half())
         x = t_emb
-        if net.cond_proj is not None:
+        if net.cond_proj is not None and use_cond:  # (the reference-only WRITE pass passes no timestep_cond)
             wemb = ops.to_device(w_embedding(self.guidance_scale, cfg.cond_proj_dim).half().expand(n, -1).contiguous())
             x = ops.empty(n, c0)
             ops.conv(wemb, None, Geom.linear(n), net.cond_proj, x, residual=t_emb)
@@ -395,15 +417,18 @@ class Engine:
         ops.synchronize()
 
     # ---------------------------------------------------------------- network builders (record ops)
-    def _resnet(self, r, rw: ResnetW, net, step, x, x2, c0, c1, hw, geom, out=None, out2=None, add2=None, residual2=None):
-        """x (and optional concat partner x2) -> ResnetBlock2D output [batch*hw][cout]  (hw = pixels per image)."""
+    def _resnet(self, r, rw: ResnetW, net, step, x, x2, c0, c1, hw, geom, out=None, out2=None, add2=None, residual2=None,
+                temb=None, stat_out=None):
+        """x (and optional concat partner x2) -> ResnetBlock2D output [batch*hw][cout]  (hw = pixels per image).
+        temb: another time-projection table than net.temb_all; stat_out: fp32 [cout][2] to receive the output's
+        per-channel (sum, sumsq) (reference-only AdaIN)."""
         a, cfg = self.arena, net.cfg
         cin = c0 + c1
         rows = self.batch * hw
         t1 = a.alloc(rows, cin)
         self._gn(r, x, x2, c0, c1, hw, cfg.groups, 1e-5, rw.n1[0], rw.n1[1], True, t1)
         h = a.alloc(rows, rw.cout)
-        tv = net.temb_all[step, rw.temb_off:rw.temb_off + rw.cout]
+        tv = (net.temb_all if temb is None else temb)[step, rw.temb_off:rw.temb_off + rw.cout]
         r.conv(t1, None, geom, rw.conv1, h, rowvec=tv, chanstat_out=self._stat_buf(h, rw.cout))
         t2 = a.alloc(rows, rw.cout)
         self._gn(r, h, None, rw.cout, 0, hw, cfg.groups, 1e-5, rw.n2[0], rw.n2[1], True, t2)
@@ -414,10 +439,10 @@ class Engine:
             sc = x
         out = out if out is not None else a.alloc(rows, rw.cout)
         r.conv(t2, None, geom, rw.conv2, out, residual=sc, residual2=residual2, out2=out2, add2=add2,
-               chanstat_out=self._stat_buf(out, rw.cout))
+               chanstat_out=stat_out if stat_out is not None else self._stat_buf(out, rw.cout))
         return out
 
-    def _transformer(self, r, tw: TransformerW, net, x, hw, out2=None, add2=None):
+    def _transformer(self, r, tw: TransformerW, net, x, hw, out2=None, add2=None, ref: Optional[RefCtx] = None, stat_out=None):
         a, cfg = self.arena, net.cfg
         c = tw.c
         heads = cfg.heads_for(c)
@@ -438,13 +463,29 @@ class Engine:
         ldvt = B * t_img
         for bi, bw in enumerate(tw.blocks):
             # self-attention (per image: keys never cross an image boundary)
-            qk = a.alloc(rows, 2 * c)
-            vt = self._vt_buffer(c, ldvt)
-            r.conv(h, None, Geom.linear(hw, batch=B), bw.qkv, qk, ldo=2 * c, out_t=vt, ldt=ldvt, t_col0=2 * c, ln_part=rs,
-                   t_img=t_img)
             att = a.alloc(rows, c)
-            r.attention(qk, 2 * c, qk[:, c:], 2 * c, vt, ldvt, att, c, hw, hw, heads, d, d ** -0.5, batch=B, k_brows=hw,
-                        vt_bcols=t_img)
+            if ref is None:
+                qk = a.alloc(rows, 2 * c)
+                vt = self._vt_buffer(c, ldvt)
+                r.conv(h, None, Geom.linear(hw, batch=B), bw.qkv, qk, ldo=2 * c, out_t=vt, ldt=ldvt, t_col0=2 * c, ln_part=rs,
+                       t_img=t_img)
+                r.attention(qk, 2 * c, qk[:, c:], 2 * c, vt, ldvt, att, c, hw, hw, heads, d, d ** -0.5, batch=B, k_brows=hw,
+                            vt_bcols=t_img)
+            else:
+                # reference-only: K rows / V^T columns [0, hw) belong to the frame (read pass), [hw, 2 hw) to the reference
+                # (write pass); the read pass attends over all 2 hw keys (lcm_reference_pipeline.py:535-539)
+                if ref.mode == "write":
+                    ld2 = _ru(2 * hw, 64)
+                    ref.kv[bw.kv_index] = (a.alloc(2 * hw, 2 * c), self._vt_buffer(c, ld2))
+                qk_full, vt_full = ref.kv[bw.kv_index]
+                ld2 = vt_full.shape[1]
+                off = hw if ref.mode == "write" else 0
+                qk = qk_full[off:off + hw]
+                r.conv(h, None, Geom.linear(hw), bw.qkv, qk, ldo=2 * c, out_t=vt_full[:, off:], ldt=ld2, t_col0=2 * c, ln_part=rs)
+                if ref.mode == "write":
+                    r.attention(qk, 2 * c, qk[:, c:], 2 * c, vt_full[:, off:], ld2, att, c, hw, hw, heads, d, d ** -0.5)
+                else:
+                    r.attention(qk, 2 * c, qk_full[:, c:], 2 * c, vt_full, ld2, att, c, hw, 2 * hw, heads, d, d ** -0.5)
             h1 = a.alloc(rows, c)
             rs1 = stat()
             r.conv(att, None, lin, bw.out1, h1, residual=h, rowstat_out=rs1)
@@ -465,7 +506,8 @@ class Engine:
             r.conv(f, None, lin, bw.ff2, h3, residual=h2, rowstat_out=rs)
             h = h3
         out = a.alloc(rows, c)
-        r.conv(h, None, lin, tw.proj_out, out, residual=x, out2=out2, add2=add2, chanstat_out=self._stat_buf(out, c))
+        r.conv(h, None, lin, tw.proj_out, out, residual=x, out2=out2, add2=add2,
+               chanstat_out=stat_out if stat_out is not None else self._stat_buf(out, c))
         return out
 
     # ---- fused GroupNorm statistics: a conv that writes a tensor a GroupNorm will read also leaves the tensor's
@@ -499,7 +541,24 @@ class Engine:
             self._vt_pool[key] = buf
         return buf
 
-    def _down_mid(self, r, net: NetWeights, step, h, sizes):
+    def _ref_site(self, r, ref: Optional[RefCtx], kind, i, j, c):
+        """-> stat buffer the block's last conv must fill (or None) for the reference-only AdaIN at this block output"""
+        if ref is None or not ref.gate(kind, i):
+            return None
+        st = self.arena.alloc(c, 2, dtype=torch.float32)
+        if ref.mode == "write":
+            ref.stats[(kind, i, j)] = st
+        return st
+
+    def _ref_adain(self, r, ref: Optional[RefCtx], kind, i, j, h, st, rows, c):
+        """read pass: AdaIN the block output to the statistics the write pass banked for the same site"""
+        if ref is None or st is None or ref.mode != "read" or (kind, i, j) not in ref.stats:
+            return h
+        o = self.arena.alloc(rows, c)
+        r.adain(h, st, ref.stats[(kind, i, j)], rows, c, o)
+        return o
+
+    def _down_mid(self, r, net: NetWeights, step, h, sizes, ref: Optional[RefCtx] = None, temb=None):
         """conv_in output h -> (mid block output, skip list [(tensor, channels, level)])."""
         a = self.arena
         ch = net.cfg.block_out_channels
@@ -509,9 +568,11 @@ class Engine:
             hw = hh * ww
             g3 = Geom.conv(hh, ww, batch=self.batch)
             for j, (rw, tw) in enumerate(net.down[i]):
-                h = self._resnet(r, rw, net, step, h, None, rw.cin, 0, hw, g3)
+                st = self._ref_site(r, ref, "down", i, j, c)
+                h = self._resnet(r, rw, net, step, h, None, rw.cin, 0, hw, g3, temb=temb, stat_out=st if tw is None else None)
                 if tw is not None:
-                    h = self._transformer(r, tw, net, h, hw)
+                    h = self._transformer(r, tw, net, h, hw, ref=ref, stat_out=st)
+                h = self._ref_adain(r, ref, "down", i, j, h, st, self.batch * hw, c)
                 skips.append((h, c, i))
             ds = net.downsamplers[i]
             if ds is not None:
@@ -524,21 +585,23 @@ class Engine:
         hw = hh * ww
         g3 = Geom.conv(hh, ww, batch=self.batch)
         c = ch[-1]
-        h = self._resnet(r, net.mid[0], net, step, h, None, c, 0, hw, g3)
-        h = self._transformer(r, net.mid[1], net, h, hw)
-        h = self._resnet(r, net.mid[2], net, step, h, None, c, 0, hw, g3)
+        h = self._resnet(r, net.mid[0], net, step, h, None, c, 0, hw, g3, temb=temb)
+        h = self._transformer(r, net.mid[1], net, h, hw, ref=ref)
+        st = self._ref_site(r, ref, "mid", 0, 0, c)
+        h = self._resnet(r, net.mid[2], net, step, h, None, c, 0, hw, g3, temb=temb, stat_out=st)
+        h = self._ref_adain(r, ref, "mid", 0, 0, h, st, self.batch * hw, c)
         return h, skips
 
-    def _unet_encoder(self, r, step, lat, sizes):
+    def _unet_encoder(self, r, step, lat, sizes, ref: Optional[RefCtx] = None, temb=None):
         a, net = self.arena, self.unet
         ch = net.cfg.block_out_channels
         h0, w0 = sizes[0]
         x = a.alloc(self.batch * h0 * w0, ch[0])
         r.conv(lat, None, Geom.conv(h0, w0, batch=self.batch), net.conv_in, x, chanstat_out=self._stat_buf(x, ch[0]))
-        h, skips = self._down_mid(r, net, step, x, sizes)
+        h, skips = self._down_mid(r, net, step, x, sizes, ref=ref, temb=temb)
         return h, [(x, ch[0], 0)] + skips
 
-    def _unet_decoder(self, r, step, h, skips, sizes, eps_out):
+    def _unet_decoder(self, r, step, h, skips, sizes, eps_out, ref: Optional[RefCtx] = None, temb=None):
         a, net = self.arena, self.unet
         ch = net.cfg.block_out_channels
         h0, w0 = sizes[0]
@@ -554,10 +617,12 @@ class Engine:
             for j, (rw, tw) in enumerate(net.up[i]):
                 s, sc, slvl = skips.pop()
                 assert slvl == lvl and rw.cin == cprev + sc, (slvl, lvl, rw.cin, cprev, sc)
-                h = self._resnet(r, rw, net, step, h, s, cprev, sc, hw, g3)
+                st = self._ref_site(r, ref, "up", i, j, rw.cout)
+                h = self._resnet(r, rw, net, step, h, s, cprev, sc, hw, g3, temb=temb, stat_out=st if tw is None else None)
                 cprev = rw.cout
                 if tw is not None:
-                    h = self._transformer(r, tw, net, h, hw)
+                    h = self._transformer(r, tw, net, h, hw, ref=ref, stat_out=st)
+                h = self._ref_adain(r, ref, "up", i, j, h, st, self.batch * hw, cprev)
             up = net.upsamplers[i]
             if up is not None:
                 h2, w2 = sizes[lvl - 1]
@@ -685,9 +750,14 @@ class Engine:
         return seen
 
     def prepare(self, H: int, W: int, steps: int, strength: float, controlnet_scale: float = 1.0,
-                use_controlnet: bool = True, use_graph: Optional[bool] = None, autotune: bool = True, batch: int = 1):
+                use_controlnet: bool = True, use_graph: Optional[bool] = None, autotune: bool = True, batch: int = 1,
+                ref_mode: bool = False):
         """Fix the frame geometry and schedule; build the static program and capture it into a hipGraph
         (the reference's intent at videopipeline.py:35-47, `compile_model`).
+
+        ref_mode: the reference-only variant (lcm_reference_pipeline.py:855-890; no ControlNet, one frame per launch): per
+        step a WRITE pass of the UNet over the noised latents of the reference image (upload it into `ref_u8`) banks
+        self-attention keys / values and block-output statistics, the READ pass over the frame's latents uses them.
 
         batch > 1: that many frames (of independent streams / sessions, or consecutive frames of one stream) go
         through every kernel together, stacked along the GEMM M dimension: one pass over the 2.45 GB of weights and
@@ -702,6 +772,9 @@ class Engine:
             raise RuntimeError("set_text_embeds must be called before prepare")
         if use_controlnet and self.cn is None:
             raise RuntimeError("no ControlNet weights loaded")
+        if ref_mode and (batch != 1 or use_controlnet or (H // 8) * (W // 8) % 8):
+            raise ValueError("ref_mode: one frame per launch, no ControlNet (the reference-only pipeline has none), "
+                             "latent pixels a multiple of 8")
         if use_graph is not None:
             self.use_graph = use_graph
         ops = self.ops
@@ -742,11 +815,15 @@ class Engine:
             for net in [self.unet] + ([self.cn] if use_controlnet else []):
                 if getattr(net, "temb_all", None) is None or net.temb_all.shape[0] != n:
                     net.temb_all = ops.zeros(n, net.temb_proj.n)
+            self.shared["ref_mode"] = bool(ref_mode)
+            if ref_mode and (getattr(self.unet, "temb_ref", None) is None or self.unet.temb_ref.shape[0] != n):
+                self.unet.temb_ref = ops.zeros(n, self.unet.temb_proj.n)
             self._write_constants(sched, controlnet_scale, use_controlnet)
         self._cn_scale_consts = c[2 + 6 * n:]
         # noise draws: the reference resets the global CPU generator to a fresh-Generator state on every
         # frame (videopipeline.py:126), so for a fixed shape the draws are the same every frame.
-        self.noise = ops.to_device(self.host_noise(n, h0, w0))
+        draws, ref_draws = self.host_noise(n, h0, w0, ref=ref_mode)
+        self.noise = ops.to_device(draws)
         a = self.arena
         enc_in = a.alloc(B * H * W, 8)
         x0 = a.alloc(B * hw0, 8)
@@ -769,6 +846,16 @@ class Engine:
             cond_emb = self._cond_embedding(r, ctrl, H, W)
             self.buffers["control"], self.buffers["cond_emb"] = ctrl, cond_emb
         self._encode(r, enc_in, H, W, x0)
+        if ref_mode:
+            ref_b = ops.zeros(1, H, W, 3, dtype=torch.uint8)
+            self.ref_u8 = ref_b[0]
+            self.noise_ref = ops.to_device(ref_draws)
+            ref_in, ref_x0, ref_xt, ref_eps = a.alloc(H * W, 8), a.alloc(hw0, 8), a.alloc(hw0, 8), a.alloc(hw0, 8)
+            for t in (ref_x0, ref_xt, ref_eps):
+                ops.zero_(t)
+            r.preprocess_rgb(ref_b, H, W, ref_in)
+            self._encode(r, ref_in, H, W, ref_x0)
+            self.buffers["ref_x0"] = ref_x0
         # every frame gets the same draws: the reference resets its RNG per frame
         r.add_noise_dev(x0, self.noise[0], c[0:2], hw0, B, lat[0])
         mark = a.mark()
@@ -789,9 +876,18 @@ class Engine:
                 if self.overlap_controlnet:
                     r.join()
                 u_mid, u_skips = self._controlnet_merge(r, cn_mid, cn_skips, u_mid, u_skips, sizes, controlnet_scale)
+            elif ref_mode:
+                rc = RefCtx(self.ucfg)
+                # ref_xt = add_noise(ref latents, fresh draw, t_i) (lcm_reference_pipeline.py:861-871); the coefficients of
+                # timestep t_i are the first two of the step's scheduler coefficients
+                r.add_noise_dev(ref_x0, self.noise_ref[i], c[2 + 6 * i:4 + 6 * i], hw0, 1, ref_xt)
+                w_mid, w_skips = self._unet_encoder(r, i, ref_xt, sizes, ref=rc, temb=self.unet.temb_ref)
+                self._unet_decoder(r, i, w_mid, w_skips, sizes, ref_eps, ref=rc, temb=self.unet.temb_ref)
+                rc.mode = "read"
+                u_mid, u_skips = self._unet_encoder(r, i, cur, sizes, ref=rc)
             else:
                 u_mid, u_skips = self._unet_encoder(r, i, cur, sizes)
-            self._unet_decoder(r, i, u_mid, u_skips, sizes, eps)
+            self._unet_decoder(r, i, u_mid, u_skips, sizes, eps, ref=rc if ref_mode else None)
             nz = self.noise[i + 1] if sched.multistep else None
             last = i == n - 1
             r.lcm_step_dev(eps, cur, nz, c[2 + 6 * i:8 + 6 * i], hw0, B, nxt, den, dec_in if last else None)
@@ -799,6 +895,7 @@ class Engine:
         r.postprocess_rgb(dec_out, 8, B * H * W, out_b)
         self.program = r
         self.plan = dict(H=H, W=W, steps=steps, strength=strength, cn_scale=controlnet_scale, cn=use_controlnet, n=n, batch=B,
+                         ref_mode=bool(ref_mode),
                          sizes=sizes, timesteps=sched.timesteps, n_ops=len(r.calls), arena_bytes=a.peak)
         # per-shape kernel configuration (timed once per shape, cached in ops.tile_override), warm-up, capture
         torch.cuda.synchronize() if torch.cuda.is_available() else None  # allocation fills vs. kernel streams
@@ -827,6 +924,8 @@ class Engine:
         self.ops.upload(c, host)
         for net in [self.unet] + ([self.cn] if (use_controlnet and self.cn is not None) else []):
             self._time_embeddings(net, sched, net.temb_all)
+        if self.shared.get("ref_mode"):  # the reference-only WRITE pass: same timesteps, no guidance embedding
+            self._time_embeddings(self.unet, sched, self.unet.temb_ref, use_cond=False)
         self.ops.synchronize()
 
     def update_options(self, strength: float, controlnet_scale: float) -> bool:
@@ -846,23 +945,31 @@ class Engine:
         return True
 
     @staticmethod
-    def host_noise(n_steps: int, h: int, w: int) -> torch.Tensor:
+    def host_noise(n_steps: int, h: int, w: int, ref: bool = False):
         """The CPU draws of one frame, in the reference's order: draw 0 = prepare_latents noise
         (lcm_controlnet.py:331, generator not forwarded), then one torch.randn per scheduler step
-        (:1033) when the schedule has more than one step.  fp32 [(n+1), 4, h*w]."""
+        (:1033) when the schedule has more than one step.  fp32 [(n+1), 4, h*w].
+        ref=True (reference-only mode): every step first draws the noise of the reference latents
+        (lcm_reference_pipeline.py:861-863) from the same stream; returns (draws, ref_draws [n, 4, h*w])."""
         st = torch.get_rng_state()
         try:
             torch.manual_seed(0)
             torch.default_generator.set_state(torch.Generator(device="cpu").get_state())
             draws = [torch.randn(1, 4, h, w)]
-            if n_steps > 1:
-                for _ in range(n_steps):
+            ref_draws = []
+            for _ in range(n_steps):
+                if ref:
+                    ref_draws.append(torch.randn(1, 4, h, w))
+                if n_steps > 1:
                     draws.append(torch.randn(1, 4, h, w))
-            else:
+            if n_steps <= 1:
                 draws.append(torch.zeros(1, 4, h, w))
         finally:
             torch.set_rng_state(st)
-        return torch.cat(draws, dim=0).reshape(len(draws), 4, h * w).contiguous()
+        d = torch.cat(draws, dim=0).reshape(len(draws), 4, h * w).contiguous()
+        if not ref:
+            return d, None
+        return d, torch.cat(ref_draws, dim=0).reshape(n_steps, 4, h * w).contiguous()
 
     # ---------------------------------------------------------------- per frame
     def launch(self):

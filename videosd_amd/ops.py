@@ -427,6 +427,10 @@ class HipOps:
         self.ctx.call("vsd_lcm_step_dev", self._p(eps), self._p(sample), self._p(noise_f32), self._p(coef_dev), hw, batch,
                       self._p(prev), self._p(denoised), self._p(dec_in), self.s)
 
+    def adain(self, x, stats, stats_ref, rows, c, out, eps=1e-6):
+        """reference-only AdaIN: per-channel re-normalisation of x to the banked statistics (fp32 [c][2] sum / sumsq)"""
+        self.ctx.call("vsd_adain", self._p(x), self._p(stats), self._p(stats_ref), rows, c, eps, self._p(out), self.s)
+
     def postprocess_rgb(self, img, ld, hw, rgb_u8):
         self.ctx.call("vsd_postprocess_rgb", self._p(img), ld, hw, self._p(rgb_u8), self.s)
 

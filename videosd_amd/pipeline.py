@@ -56,6 +56,11 @@ class VideoSDPipeline:
     def __init__(self, *args, **kwargs):
         self.device = kwargs.get("device", 0)
         self.honor_controlnet_flag = bool(kwargs.get("honor_controlnet_flag", False))  # extension, off by default
+        # extension, off by default: `ref=True` runs the reference-only mode (lcm_reference_pipeline.py, dead code at the
+        # reference's v2 where `ref` / `style_fidelity` are accepted and ignored, videopipeline.py:84-85)
+        self.honor_ref_flag = bool(kwargs.get("honor_ref_flag", False))
+        self._ref_img = None
+        self._ref_epoch = 0
         try:
             self.load_model(kwargs["model"], kwargs["controlnet"])
         except KeyError:
@@ -142,6 +147,17 @@ class VideoSDPipeline:
             self._pooled = self.encode_pooled(key if isinstance(key, str) else list(key or ()))
             self._engines.clear()
             self._plan_key = None
+
+    def set_reference(self, img):
+        """The reference image of the reference-only mode (`honor_ref_flag=True`, `infer(..., ref=True)`).  Without one the
+        first frame seen with `ref=True` becomes the reference."""
+        self._require_idle("change the reference image")
+        self._ref_img = img
+        self._ref_epoch += 1
+
+    def can_batch(self, **options) -> bool:
+        """May the worker coalesce queued frames with these options into one launch?  (reference-only frames go alone)"""
+        return not (self.honor_ref_flag and options.get("ref", False))
 
     def _require_idle(self, what: str):
         """Prompt constants (cross-attention K / V^T) and plans are shared by every lane: rewriting them under a launch
@@ -233,15 +249,27 @@ class VideoSDPipeline:
         if self.is_xl:  # micro-conditioning: original size = target size = the frame size, no crop
             self.model.set_added_cond(self._pooled, (height, width, 0, 0, height, width))
         use_cn = False if self.is_xl else (bool(controlnet) if self.honor_controlnet_flag else True)
+        use_ref = bool(ref) and self.honor_ref_flag and not self.is_xl
+        if use_ref:
+            if len(imgs) != 1:
+                raise ValueError("ref=True: one frame per call (the reference-only program runs one frame per launch)")
+            use_cn = False  # the reference-only pipeline has no ControlNet (lcm_reference_pipeline.py:855-890)
+            if self._ref_img is None:
+                self._ref_img = imgs[0]
+                self._ref_epoch += 1
         # The captured program depends on the frame size, the NUMBER of timesteps and the ControlNet switch; `strength`
         # and `controlnet_scale` only change constants the graph reads from device memory (Engine.update_options): a
         # slider drag in the client (server.py:163-197) does not rebuild or re-capture anything.
         from .lcm import lcm_timesteps
 
         n_eff = len(lcm_timesteps(float(strength), int(steps)))  # ValueError for an empty schedule: the caller's problem
-        plan_key = (height, width, int(steps), n_eff, use_cn)
+        plan_key = (height, width, int(steps), n_eff, use_cn, use_ref)
         opts = (float(strength), float(controlnet_scale))
         eng = self._engine_for(plan_key, opts, len(imgs), lane)
+        if use_ref and getattr(eng, "_ref_epoch", None) != self._ref_epoch:
+            rf = np.asarray(center_crop_resize(self._ref_img.convert("RGB"), width, height), dtype=np.uint8)
+            eng.ops.upload(eng.ref_u8, torch.from_numpy(np.ascontiguousarray(rf)))
+            eng._ref_epoch = self._ref_epoch
         np.random.seed(seed)  # kept for parity with videopipeline.py:112 (nothing downstream consumes it)
         t0 = time.perf_counter()
         frames = np.stack([np.asarray(im if im.mode == "RGB" else im.convert("RGB"), dtype=np.uint8) for im in imgs])
@@ -271,7 +299,7 @@ class VideoSDPipeline:
         """A prepared engine per (program, batch size, lane): the parent engine serves the first one, slots (shared
         weights and constants, own arena / graph) serve the others, so switching between batch sizes costs nothing per
         frame.  `opts` = (strength, controlnet_scale): a change rewrites the shared device constants, nothing else."""
-        height, width, steps, _n, use_cn = plan_key
+        height, width, steps, _n, use_cn, use_ref = plan_key
         strength, cn_scale = opts
         if plan_key == self._plan_key and opts != self._opt_key:
             self._require_idle("change strength / controlnet_scale")
@@ -293,12 +321,16 @@ class VideoSDPipeline:
         if plan_key != self._plan_key or evict:
             self._require_idle("prepare another plan")
             self._engines.clear()
-            self.model.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch)
+            self.model.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch,
+                               ref_mode=use_ref)
             self._plan_key, self._opt_key = plan_key, opts
             eng = self.model
+            eng._ref_epoch = None
         else:  # same program and constants as the parent's current plan: a slot suffices
             eng = self.model.make_slot()
-            eng.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch)
+            eng.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch,
+                        ref_mode=use_ref)
+            eng._ref_epoch = None
         self._engines[key] = eng
         self._note("prepare", t0)
         return eng
