@@ -34,6 +34,8 @@ enum vsd_status {
 };
 
 enum vsd_act { VSD_ACT_NONE = 0, VSD_ACT_RELU = 1, VSD_ACT_SILU = 2, VSD_ACT_GEGLU = 3, VSD_ACT_QUICKGELU = 4,
+               VSD_ACT_SOFTMAX = 5 /* row softmax inside every 128-column tile over its first softmax_cols columns (tile
+                                      128-wide, N % 128 == 0, split-K only with `counters`): cross-attention probabilities, see softmax_cols */,
                VSD_ACT_POST = 256 /* flag: apply the activation AFTER the residual adds (TAESD block) */ };
 
 /* tile shapes of the implicit-GEMM kernel (BM x BN output tile per 256-thread workgroup) */
@@ -130,6 +132,11 @@ typedef struct vsd_conv_desc {
   const void* out_scale_dev; /* optional: ONE fp32 in device memory that replaces out_scale (read by the kernel at run
                              time): the ControlNet zero-convs' conditioning scale (lcm_controlnet.py:558-566) can then
                              change under a captured graph.  General epilogue only (not the halo-patch form). */
+  int32_t softmax_cols;   /* VSD_ACT_SOFTMAX: valid columns per 128-column group (1..128); the others are written as 0.
+                             With the key projections of a fixed key set folded into the query weights
+                             (scores_h = LN(x) (scale K_h Wq_h)^T, one 128-column group per head), the GEMM tile IS the score
+                             block of one head and this epilogue turns it into probabilities: cross-attention over the 77
+                             text tokens (Attention.forward of attn2 under lcm_controlnet.py:568) as two plain GEMMs. */
 } vsd_conv_desc;
 #define VSD_SPLITK_MAX_TILES 16384
 

@@ -64,7 +64,7 @@ class FakeOps:
     def conv(self, src0, src1, g, w, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None, residual2=None,
              ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0, t_col0=0, tile=None,
              split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None, ln_eps=1e-5,
-             chanstat_out=None, t_img=0, out_scale_dev=None):
+             chanstat_out=None, t_img=0, out_scale_dev=None, softmax_cols=0):
         if out_scale_dev is not None:
             out_scale = float(out_scale_dev.reshape(-1)[0])
         c0 = c0 if c0 is not None else (w.cin - c1)
@@ -105,6 +105,13 @@ class FakeOps:
         if w.geglu:
             hid, gate = y.chunk(2, dim=-1)
             y = hid * F.gelu(gate)
+            a = L.ACT_NONE
+
+        if a == L.ACT_SOFTMAX:  # row softmax inside every 128-column group over its first softmax_cols columns
+            yy = y.reshape(g.m, w.n // 128, 128)
+            pr = torch.zeros_like(yy)
+            pr[:, :, :softmax_cols] = torch.softmax(yy[:, :, :softmax_cols], dim=-1)
+            y = pr.reshape(g.m, w.n)
             a = L.ACT_NONE
 
         def fa(v):

@@ -194,3 +194,38 @@ def test_reference_only_mode_matches_oracle(mini, H, W, steps):
     assert np.abs(plain.astype(int) - ref.astype(int)).mean() > 2.0
     with pytest.raises(ValueError):
         eng.prepare(H, W, steps, 0.6, use_controlnet=True, use_graph=False, ref_mode=True)
+
+
+def test_absorbed_cross_attention_wiring(mini, monkeypatch):
+    """Cross-attention of the wide blocks as two GEMMs (text K / V folded into the query / output weights, tile softmax
+    in the first GEMM's epilogue; packing.pack_cross_attention): same frame as the three-kernel form, also after a prompt
+    change (the folded weights are rewritten in place), through the op emulator with the width threshold lowered so that
+    the reduced-width test network takes the path."""
+    import videosd_amd.engine as E
+
+    wu, wc, wv, text = mini
+    frame = _frame(64, 64)
+    monkeypatch.setattr(E, "XATTN_ABSORB_MIN_C", 1)
+    eng = Engine(FakeOps(), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
+    assert all(t.xa_raw is not None for t in eng.unet.transformers)
+    eng.set_text_embeds(text)
+    eng.prepare(64, 64, 2, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
+    n_soft = sum(1 for fn, a, k in eng.program.calls if fn.__name__ == "conv" and k.get("softmax_cols"))
+    n_attn = sum(1 for fn, a, k in eng.program.calls if fn.__name__ == "attention")
+    nblk = len(eng.unet.transformers) + len(eng.cn.transformers)
+    assert n_soft == 2 * nblk and n_attn == 2 * nblk  # every cross-attention absorbed, the self-attentions remain
+    got = eng.infer_u8(frame)
+    eng.absorb_cross_attention = False
+    eng.prepare(64, 64, 2, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
+    assert sum(1 for fn, a, k in eng.program.calls if fn.__name__ == "attention") == 4 * nblk
+    ref = eng.infer_u8(frame)
+    assert np.abs(got.astype(int) - ref.astype(int)).mean() < 0.3
+    # another prompt: the absorbed weights follow
+    text2 = (torch.randn(77, C.MINI_UNET.cross_dim, generator=torch.Generator().manual_seed(8)) * 0.5).half()
+    eng.set_text_embeds(text2)
+    ref2 = eng.infer_u8(frame)
+    eng.absorb_cross_attention = True
+    eng.set_text_embeds(text2)
+    eng.prepare(64, 64, 2, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
+    got2 = eng.infer_u8(frame)
+    assert np.abs(got2.astype(int) - ref2.astype(int)).mean() < 0.3 and np.abs(ref2.astype(int) - ref.astype(int)).mean() > 1.0

@@ -462,6 +462,48 @@ def test_attention_with_peaked_softmax_rows(ops, sq, sk, heads, d):
     check(out, attention_ref(q, k, v, heads, scale), f"peaked attention {sq}x{sk} d{d}", rel=4e-3)
 
 
+@pytest.mark.parametrize("m,c,heads", [(768, 1280, 8), (3072, 640, 8), (200, 640, 8)])
+def test_absorbed_cross_attention_matches_explicit_attention(ops, m, c, heads):
+    """Cross-attention over the 77 text tokens as two GEMMs (packing.pack_cross_attention: K folded into the query
+    weights, V into the output weights, per-head tile softmax in the first GEMM's epilogue) against the explicit
+    LayerNorm -> to_q -> softmax(q K^T / sqrt(d)) V -> to_out + residual in fp32."""
+    from videosd_amd import lib as L
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_cross_attention, pack_linear
+
+    tl, d = 77, c // heads
+    x = (rnd(m, c, seed=1).float() * 2 + 0.3).half()
+    text_k, text_v = rnd(tl, c, seed=2, scale=1.5), rnd(tl, c, seed=3)
+    wq, wo, bo = rnd(c, c, seed=4, scale=c ** -0.5), rnd(c, c, seed=5, scale=c ** -0.5), rnd(c, seed=6, scale=0.1)
+    gamma, beta = (1 + 0.1 * rnd(c, seed=7).float()).half(), rnd(c, seed=8, scale=0.1)
+    # producer: identity GEMM that leaves the rows and their LayerNorm partials
+    p0 = ops.to_device_pack(pack_linear(torch.eye(c).half(), None))
+    h = torch.zeros(m, c, dtype=torch.float16, device="cuda")
+    rs = torch.zeros(m, c // 64, 2, dtype=torch.float32, device="cuda")
+    ops.conv(x.cuda(), None, Geom.linear(m), p0, h, rowstat_out=rs, tile=2)
+    xa1, xa2 = pack_cross_attention(text_k.float(), text_v.float(), wq, wo, bo, gamma, beta, heads)
+    xa1, xa2 = ops.to_device_pack(xa1), ops.to_device_pack(xa2)
+    pr = torch.zeros(m, heads * 128, dtype=torch.float16, device="cuda")
+    out = torch.zeros(m, c, dtype=torch.float16, device="cuda")
+    for tile, split in ((0, 1), (3, 1), (3, 4), (0, 2)):
+        ops.conv(h, None, Geom.linear(m), xa1, pr, ln_part=rs, act=L.ACT_SOFTMAX, softmax_cols=tl, tile=tile, split_k=split)
+        ops.conv(pr, None, Geom.linear(m), xa2, out, residual=h)
+        ops.synchronize()
+        xf = x.float()
+        ln = F.layer_norm(xf, (c,), gamma.float(), beta.float(), 1e-5)
+        q = F.linear(ln, wq.float()).view(m, heads, d).transpose(0, 1)
+        kk = text_k.float().view(tl, heads, d).transpose(0, 1)
+        vv = text_v.float().view(tl, heads, d).transpose(0, 1)
+        att = torch.softmax(q @ kk.transpose(-1, -2) * d ** -0.5, dim=-1)
+        prob = pr.float().cpu().view(m, heads, 128)
+        assert float(prob[:, :, tl:].abs().max()) == 0.0 and torch.allclose(prob[:, :, :tl].sum(-1), torch.ones(m, heads), atol=4e-3)
+        check(prob[:, :, :tl].transpose(0, 1), att, f"probabilities tile={tile}", rel=6e-3)
+        ref = F.linear((att @ vv).transpose(0, 1).reshape(m, c), wo.float(), bo.float()) + xf
+        check(out, ref, f"absorbed cross-attention tile={tile}", rel=3e-3)
+    with pytest.raises(RuntimeError, match="softmax"):
+        ops.conv(h, None, Geom.linear(m), xa1, pr, ln_part=rs, act=L.ACT_SOFTMAX, softmax_cols=tl, tile=1, split_k=1)
+
+
 def test_preprocess_and_postprocess(ops):
     h, w = 40, 56
     rng = np.random.default_rng(0)

@@ -50,6 +50,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.ldr = d->ldr;
   p.out_scale = d->out_scale;
   p.out_scale_dev = (const float*)d->out_scale_dev;
+  p.softmax_cols = d->softmax_cols;
   p.act = d->act;
   p.out = (half_t*)d->out; p.ldo = d->ldo;
   p.out2 = (half_t*)d->out2; p.add2 = (const half_t*)d->add2;
@@ -121,6 +122,12 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   if ((p.act & 0xff) == VSD_ACT_GEGLU) {
     if (BN != 128 || p.N % 128 || p.split_k != 1 || (!p.bias && !p.ln_part) || p.out_t)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: GEGLU needs BN=128, N %% 128 == 0, bias, no split-K");
+  }
+  if ((p.act & 0xff) == VSD_ACT_SOFTMAX) {
+    if (BN != 128 || halo || p.N % 128 || (p.split_k != 1 && !d->counters) || p.out_t || p.out2 || p.residual || p.rowstat_out || p.chanstat_out ||
+        p.softmax_cols < 1 || p.softmax_cols > 128 || p.ldo % 8)
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the softmax epilogue needs BN=128, N %% 128 == 0, split-K only in the in-kernel form, a plain output and "
+                      "1 <= softmax_cols <= 128");
   }
   if (p.out_t && (p.t_col0 % BN)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: t_col0 must be a multiple of BN");
   p.tiles_m = halo ? p.batch * cdiv(p.ho, BM / 16) * cdiv(p.wo, 16) : cdiv(p.M, BM);  // halo: 8x16 / 16x16 pixel patches

@@ -71,6 +71,7 @@ struct ConvParams {
 #ifdef VSD_CONV_PROBE
   long long* probe;  // scripts/conv_probe.cpp: per-section shader-clock totals of wave 0 of workgroup 0
 #endif
+  int softmax_cols;  // VSD_ACT_SOFTMAX: valid columns of every 128-column group
   int batch;    // images stacked along M: M = batch * ho * wo, image b's source pixels start at b * hs * ws
   int hw_out;   // ho * wo
   int img_in;   // hs * ws
@@ -822,11 +823,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   constexpr int NITP = BM * CHP / 256;
   constexpr int NPRE = NITP <= 8 ? NITP : 8;
   half8 rpre[NPRE];
-  const bool use_pre = p.residual != nullptr && p.split_k == 1 && (p.act & 0xff) != VSD_ACT_GEGLU && !(p.out_t && n0 >= p.t_col0);
+  const bool use_pre = p.residual != nullptr && p.split_k == 1 && (p.act & 0xff) != VSD_ACT_GEGLU &&
+                       (p.act & 0xff) != VSD_ACT_SOFTMAX && !(p.out_t && n0 >= p.t_col0);
   // bias + rowvec of this thread's 8 columns (the same columns in every chunk it handles: 256 % CHP == 0)
   float brv[8];
   const int pre_n = n0 + (tid % CHP) * 8;
-  const bool use_brv = pre_n + 8 <= p.N && (p.act & 0xff) != VSD_ACT_GEGLU && !(p.out_t && n0 >= p.t_col0);
+  const bool use_brv = pre_n + 8 <= p.N && (p.act & 0xff) != VSD_ACT_GEGLU && (p.act & 0xff) != VSD_ACT_SOFTMAX &&
+                       !(p.out_t && n0 >= p.t_col0);
   // Issue order: the residual chunks first (they come from HBM / the Infinity Cache: the longest latency of the epilogue),
   // then bias and time vector as RAW halfs -- converting them here would make the wave wait for them before the
   // residual loads are even issued (vmcnt retires in order; measured: one L2 round trip per workgroup, serialised in
@@ -955,6 +958,54 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       }
       int n = (n0 >> 1) + c8;
       if (n < no) *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
+    }
+    return;
+  }
+
+  if ((p.act & 0xff) == VSD_ACT_SOFTMAX) {
+    // Row softmax inside each 128-column tile, over its first p.softmax_cols columns (the others become 0): the scores of
+    // ONE attention head against a short, fixed key set (the 77 text tokens) are a GEMM tile when the key projections are
+    // folded into the query weights (packing.pack_cross_attention) -- the epilogue finishes the attention probabilities.
+    // The 16 lanes that hold one row's 8-column chunks are consecutive: 4 xor-shuffles per reduction.
+    if constexpr (BN == 128) {
+      constexpr int CH = BN / 8;  // 16
+      constexpr int NIT = BM * CH / 256;
+      const int nv = p.softmax_cols;
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const int q = tid + j * 256;
+        const int r = q / CH, c8 = (q - r * CH) * 8;
+        const int m = m0 + r, n = n0 + c8;
+        float v[8];
+        load_chunk8(p, Cs, BNP, from_slabs, r, c8, m, n, v);  // (split-K: the last arriver sums the slabs, then normalises)
+        if (p.ln_part) ln_transform8(p, n, rowms[2 * r], rowms[2 * r + 1], v);
+        else if (p.bias) {
+          half8 b = *reinterpret_cast<const half8*>(p.bias + n);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += (float)b[i];
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[i] = (c8 + i < nv) ? v[i] * 1.4426950408889634f : -3.0e38f;
+          mx = fmaxf(mx, v[i]);
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[i] = (c8 + i < nv) ? __builtin_amdgcn_exp2f(v[i] - mx) : 0.f;
+          sum += v[i];
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.0f / sum;
+        half8 o8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o8[i] = (half_t)(v[i] * inv);
+        if (m < p.M) *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o8;
+      }
     }
     return;
   }

@@ -25,7 +25,8 @@ from . import lib as L
 from .config import ControlNetConfig, TAESDConfig, UNetConfig
 from .lcm import LCMSchedule, timestep_sinusoid, w_embedding
 from .ops import Geom
-from .packing import PackedConv, pack_conv, pack_geglu_ln, pack_linear, pack_linear_cat, pack_linear_ln
+from .packing import (PackedConv, pack_conv, pack_cross_attention, pack_geglu_ln, pack_linear, pack_linear_cat,
+                      pack_linear_ln)
 from .weights import skip_channels
 
 
@@ -111,6 +112,11 @@ class BlockW:
     ff1: PackedConv            # norm3 folded in, GEGLU tile-packed
     ff2: PackedConv
     kv_index: int              # slot in the per-prompt cross-attention K / V^T cache
+    # "absorbed" cross-attention (C >= XATTN_ABSORB_MIN_C): the text's key / value projections folded into the query and
+    # output weights, rebuilt per prompt (packing.pack_cross_attention); raw host copies of what that needs
+    xa_raw: Optional[tuple] = None     # (to_q weight, norm2 gamma, norm2 beta, to_out weight, to_out bias), CPU
+    xa1: Optional[PackedConv] = None   # LN-folded score weights [heads*128][C], tile-softmax epilogue
+    xa2: Optional[PackedConv] = None   # [C][heads*128] + bias
 
 
 @dataclass
@@ -121,6 +127,11 @@ class TransformerW:
     proj_in: PackedConv
     blocks: List[BlockW]
     proj_out: PackedConv
+
+
+# Cross-attention as two GEMMs pays when one 128-column tile per head is not wider than the query projection it
+# replaces: 8 heads * 128 = 1024 columns against C (SD1.5: the 640- and 1280-wide levels; see pack_cross_attention)
+XATTN_ABSORB_MIN_C = 640
 
 
 class NetWeights:
@@ -237,6 +248,11 @@ class NetWeights:
             ff1 = self._to_dev(pack_geglu_ln(w[f"{b}.ff.net.0.proj.weight"], w[f"{b}.ff.net.0.proj.bias"], *ln("norm3")))
             blk = BlockW(qkv, self._lin(b + ".attn1.to_out.0"), q2, kv2, self._lin(b + ".attn2.to_out.0"), ff1,
                          self._lin(b + ".ff.net.2"), len(self.transformers))
+            heads = self.cfg.heads_for(c)
+            if c >= XATTN_ABSORB_MIN_C and c % heads == 0:
+                cpu = lambda t: t.detach().to("cpu", torch.float16)  # noqa: E731
+                blk.xa_raw = (cpu(w[f"{b}.attn2.to_q.weight"]), cpu(ln("norm2")[0]), cpu(ln("norm2")[1]),
+                              cpu(w[f"{b}.attn2.to_out.0.weight"]), cpu(w[f"{b}.attn2.to_out.0.bias"]))
             self.transformers.append(blk)
             blocks.append(blk)
         # use_linear_projection (SDXL): Linear on the token matrix == the 1x1 conv of SD1.5 in this layout
@@ -341,6 +357,7 @@ class Engine:
         # what a slot shares with its parent besides the weights: the per-plan constant block (schedule coefficients,
         # ControlNet scales) that the captured graphs READ, so that `update_options` reaches every graph at once
         self.shared = {}
+        self.absorb_cross_attention = True  # cross-attention of the wide blocks as two GEMMs (pack_cross_attention)
 
     def make_slot(self) -> "Engine":
         """A further frame in flight on the same GPU: shares the weights and the prompt / schedule constants of
@@ -375,6 +392,27 @@ class Engine:
                     net.kv_cache.append((ops.zeros(tl, c), ops.zeros(c, ldt)))
                 k, vt = net.kv_cache[i]
                 ops.conv(self.text, None, Geom.linear(tl), t.kv2, k, ldo=c, out_t=vt, ldt=ldt, t_col0=c)
+        ops.synchronize()
+        if tl > 128 or not self.absorb_cross_attention:
+            return
+        # absorbed cross-attention: fold this prompt's K / V into the query / output weights of the wide blocks.  The
+        # device buffers keep their addresses (captured graphs read them): a new prompt rewrites them in place.
+        for net in [self.unet] + ([self.cn] if self.cn else []):
+            for i, t in enumerate(net.transformers):
+                if t.xa_raw is None:
+                    continue
+                k, vt = net.kv_cache[i]
+                kh = ops.download(k).float()
+                vh = ops.download(vt)[:, :tl].float().t().contiguous()
+                wq, ga, be, wo, bo = t.xa_raw
+                x1, x2 = pack_cross_attention(kh, vh, wq, wo, bo, ga, be, net.cfg.heads_for(k.shape[1]))
+                if t.xa1 is None:
+                    t.xa1, t.xa2 = net._to_dev(x1), net._to_dev(x2)
+                else:
+                    for dst, src in ((t.xa1, x1), (t.xa2, x2)):
+                        for f in ("weight", "bias", "ln_s", "ln_t"):
+                            if getattr(src, f) is not None:
+                                ops.upload(getattr(dst, f), getattr(src, f).contiguous())
         ops.synchronize()
 
     def set_added_cond(self, pooled: torch.Tensor, time_ids):
@@ -490,13 +528,20 @@ class Engine:
             rs1 = stat()
             r.conv(att, None, lin, bw.out1, h1, residual=h, rowstat_out=rs1)
             # cross-attention over the cached text K / V^T (shared by all images)
-            q = a.alloc(rows, c)
-            r.conv(h1, None, lin, bw.q2, q, ln_part=rs1)
             kt, vtt = net.kv_cache[bw.kv_index]
-            r.attention(q, c, kt, c, vtt, vtt.shape[1], att, c, rows, kt.shape[0], heads, d, d ** -0.5)
             h2 = a.alloc(rows, c)
             rs2 = stat()
-            r.conv(att, None, lin, bw.out2, h2, residual=h1, rowstat_out=rs2)
+            if bw.xa1 is not None and self.absorb_cross_attention:
+                # wide blocks: probabilities = softmax per head of LN(h1) G^T (one 128-column tile per head, softmax in the
+                # GEMM epilogue), then h2 = P Z^T + bias + h1 -- two launches instead of three, fewer FLOPs for C >= 1024
+                pr = a.alloc(rows, bw.xa1.n)
+                r.conv(h1, None, lin, bw.xa1, pr, ln_part=rs1, act=L.ACT_SOFTMAX, softmax_cols=kt.shape[0])
+                r.conv(pr, None, lin, bw.xa2, h2, residual=h1, rowstat_out=rs2)
+            else:
+                q = a.alloc(rows, c)
+                r.conv(h1, None, lin, bw.q2, q, ln_part=rs1)
+                r.attention(q, c, kt, c, vtt, vtt.shape[1], att, c, rows, kt.shape[0], heads, d, d ** -0.5)
+                r.conv(att, None, lin, bw.out2, h2, residual=h1, rowstat_out=rs2)
             # GEGLU feed-forward
             f = a.alloc(rows, 4 * c)
             r.conv(h2, None, lin, bw.ff1, f, ln_part=rs2)

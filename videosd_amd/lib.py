@@ -6,7 +6,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvsd.so")
 
-ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_QUICKGELU = range(5)
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_QUICKGELU, ACT_SOFTMAX = range(6)
 ACT_POST = 256
 SPLITK_MAX_TILES = 16384
 TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128, TILE_256x128, TILE_256x64 = range(6)
@@ -41,6 +41,7 @@ class ConvDesc(C.Structure):
         ("counters", C.c_void_p),
         ("batch", C.c_int32), ("t_img", C.c_int32),
         ("out_scale_dev", C.c_void_p),
+        ("softmax_cols", C.c_int32),
     ]
 
 

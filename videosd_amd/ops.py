@@ -189,7 +189,7 @@ class HipOps:
     def conv(self, src0, src1, g: Geom, w: PackedConv, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None,
              residual2=None, ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0,
              t_col0=0, tile=None, split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None,
-             ln_eps=1e-5, chanstat_out=None, t_img=0, out_scale_dev=None):
+             ln_eps=1e-5, chanstat_out=None, t_img=0, out_scale_dev=None, softmax_cols=0):
         """t_img: with g.batch > 1, columns of out_t per image (image b's pixels start at column b * t_img).
         out_scale_dev: one fp32 in device memory that replaces out_scale at run time (changeable under a captured graph)."""
         m = g.m
@@ -202,9 +202,11 @@ class HipOps:
             if key in self.tile_override:
                 tile, split_k, inkernel, pipeline = self.tile_override[key]
             else:
-                tile, sk = choose_tile(m, w.n, w.kp, w.geglu, t_col0 if out_t is not None else 0)
+                tile, sk = choose_tile(m, w.n, w.kp, w.geglu or w.tile128, t_col0 if out_t is not None else 0)
                 split_k = sk if split_k is None else split_k
         split_k = split_k or 1
+        if w.tile128:
+            inkernel = True  # (the tile softmax runs in the reducing workgroup's epilogue)
         if pipeline == 7 and (self.no_halo or out_scale_dev is not None or
                               not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out,
                                                      chanstat_out, ln_part)):
@@ -235,6 +237,7 @@ class HipOps:
         d.ldr = ldr if ldr is not None else w.n_out
         d.out_scale = out_scale
         d.out_scale_dev = self._p(out_scale_dev)
+        d.softmax_cols = softmax_cols
         d.act = act
         d.out = self._p(out)
         d.ldo = ldo if ldo is not None else w.n_out
@@ -269,7 +272,8 @@ class HipOps:
         t_col0 = kwargs.get("t_col0", 0)
         key = self.conv_key(g, w, t_col0, kwargs.get("rowstat_out") is not None or kwargs.get("chanstat_out") is not None)
         kt = w.kp // 64
-        tiles = [L.TILE_128x128, L.TILE_64x128] if w.geglu else [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64]
+        wide = w.geglu or w.tile128  # epilogues that need whole 128-column tiles and no split-K
+        tiles = [L.TILE_128x128, L.TILE_64x128] if wide else [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64]
         # the 256x128 tile (buffer-load path only: Cin % 64 == 0, no resize) pays when M is large (batched frames, TAESD)
         big_ok = w.cin % 64 == 0 and (g.hi, g.wi) == (g.hs, g.ws) and g.m >= 1024
         if big_ok:
@@ -277,7 +281,7 @@ class HipOps:
 
         plain_epi = all(kwargs.get(k) is None for k in ("out2", "residual2", "out_t", "rowstat_out", "chanstat_out", "ln_part"))
         act = kwargs.get("act", L.ACT_NONE)
-        halo_ok = (not w.geglu and g.ksize == 3 and g.stride == 1 and w.cin % 64 == 0 and
+        halo_ok = (not wide and g.ksize == 3 and g.stride == 1 and w.cin % 64 == 0 and
                    (kwargs.get("c1", 0) or 0) % 64 == 0 and w.n % 8 == 0 and plain_epi and
                    kwargs.get("out_scale", 1.0) == 1.0 and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_SILU, L.ACT_RELU | L.ACT_POST))
         cands = []
@@ -302,7 +306,7 @@ class HipOps:
                 if sp > kt // 2 or blocks * sp > 1536:
                     break
                 for pl in ((3, 5) if t == L.TILE_256x128 else (0, 3, 5)):
-                    if kwargs.get("rowstat_out") is None and kwargs.get("chanstat_out") is None:
+                    if kwargs.get("rowstat_out") is None and kwargs.get("chanstat_out") is None and not w.tile128:
                         cands.append((t, sp, False, pl))
                     cands.append((t, sp, True, pl))
         if halo_ok:  # 16x16 patches (8 waves): half the weight traffic of the 8x16 patch

@@ -21,6 +21,7 @@ class PackedConv:
     geglu: bool = False
     ln_s: Optional[torch.Tensor] = None   # fp32 [n]: sum_k (W*gamma)[n][k]   (fused input LayerNorm, include/vsd.h)
     ln_t: Optional[torch.Tensor] = None   # fp32 [n]: sum_k beta[k] W[n][k] + bias[n]
+    tile128: bool = False                 # the epilogue needs whole 128-column tiles and no split-K (tile softmax)
 
     @property
     def n_out(self) -> int:
@@ -117,3 +118,35 @@ def pack_geglu_ln(weight: torch.Tensor, bias: torch.Tensor, gamma, beta) -> Pack
     p = _finish(tile(wp), None, k, 1, geglu=True)
     p.ln_s, p.ln_t = tile(s).contiguous(), tile(t).contiguous()
     return p
+
+
+def pack_cross_attention(k: torch.Tensor, v: torch.Tensor, wq: torch.Tensor, wo: torch.Tensor, bo, gamma, beta, heads: int,
+                         group: int = 128):
+    """Cross-attention over a FIXED key set (the text tokens) as two plain GEMMs ("absorbed" form).
+
+        out = Concat_h[ softmax(scale * q_h K_h^T) V_h ] Wo^T + bo,   q = LN(x) Wq^T
+            = softmax_h( LN(x) G^T ) Z^T + bo
+        G[h*group + j, :] = scale * sum_d K_h[j, d] Wq[h*dh + d, :]      (j < tl, zero rows above)
+        Z[:, h*group + j] = sum_d Wo[:, h*dh + d] V_h[j, d]
+
+    k, v: [tl, C] key / value projections of the text (Attention.to_k / to_v of attn2), wq / wo: attn2.to_q / to_out.0,
+    gamma / beta: the LayerNorm in front (norm2), folded into G like every LN-consuming layer (pack_linear_ln).  Returns
+    (PackedConv G' with ln_s / ln_t: N = heads*group, K = C;  PackedConv Z with bias: N = C, K = heads*group).  The first
+    GEMM runs with the VSD_ACT_SOFTMAX epilogue (softmax_cols = tl), the second is an ordinary linear layer with the
+    residual in its epilogue.  One head per 128-column tile: C >= heads*group/2 keeps the FLOP count at or below the
+    three-kernel form (q projection, attention, out projection); the engine uses it for C >= 640."""
+    tl, c = k.shape
+    dh = c // heads
+    assert tl <= group and c % heads == 0
+    kf, vf, wqf, wof = k.float(), v.float(), wq.float(), wo.float()
+    scale = dh ** -0.5
+    g = torch.zeros(heads * group, c, dtype=torch.float32)
+    z = torch.zeros(c, heads * group, dtype=torch.float32)
+    for h in range(heads):
+        sl = slice(h * dh, (h + 1) * dh)
+        g[h * group:h * group + tl] = scale * (kf[:, sl] @ wqf[sl, :])
+        z[:, h * group:h * group + tl] = wof[:, sl] @ vf[:, sl].t()
+    xa1 = pack_linear_ln([g], None, gamma, beta)
+    xa1.tile128 = True
+    xa2 = pack_linear(z, bo)
+    return xa1, xa2
