@@ -363,7 +363,9 @@ def run_rank(args):
                 e.launch()
         sync_all()
     eng.overlap_controlnet = True
+    eng.use_side_stream = True  # one frame in flight: the second stream also takes the ControlNet merges (engine.py)
     plan1 = eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
+    eng.use_side_stream = False
     lat = []
     got0 = None
     for i in range(min(30, max(5, args.steps))):

@@ -27,7 +27,7 @@ eng.prepare(size, size, 4, 0.6, use_controlnet=cn, use_graph=False, batch=batch)
 meta = []
 for fn, a, k in eng.program.calls:
     name = fn.__name__
-    if name in ("fork", "join", "use_stream"):
+    if name in ("fork", "join", "use_stream", "signal", "wait"):
         continue
     m = {"op": name}
     if name == "conv":

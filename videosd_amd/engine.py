@@ -354,6 +354,20 @@ class Engine:
         self.fuse_gn_stats = False
         self._stats = {}
         self.overlap_controlnet = True  # run the ControlNet encoder on a second stream, parallel to the UNet encoder
+        # ... and, optionally, while that stream is otherwise idle: the ControlNet skip merges beside the mid block / decoder
+        # start and Sobel + conditioning embedding beside the TAESD encoder (`use_side_stream`), the 1x1 shortcut convs of
+        # the decoder's ResnetBlocks beside their main path (`side_shortcuts`).  Measured on MI355X (512x512, 4 steps): one
+        # frame alone 23.8 -> 23.2 ms (23.6 with the shortcuts too), but with two launches in flight 97 -> 81 frames/s --
+        # four busy hardware queues instead of two cost more than the filled gaps give.  So: off by default, switched on
+        # where a single frame is in flight (bench.py's latency leg).
+        self.use_side_stream = False
+        self.side_shortcuts = False
+        import os as _os
+        _v = _os.environ.get("VSD_SIDE")  # A/B switch: 0 off, 1 merges + conditioning, 2 also the shortcuts
+        if _v is not None:
+            self.use_side_stream = _v in ("1", "2")
+            self.side_shortcuts = _v == "2"
+        self._ev_count = 0
         # what a slot shares with its parent besides the weights: the per-plan constant block (schedule coefficients,
         # ControlNet scales) that the captured graphs READ, so that `update_options` reaches every graph at once
         self.shared = {}
@@ -456,10 +470,10 @@ class Engine:
 
     # ---------------------------------------------------------------- network builders (record ops)
     def _resnet(self, r, rw: ResnetW, net, step, x, x2, c0, c1, hw, geom, out=None, out2=None, add2=None, residual2=None,
-                temb=None, stat_out=None):
+                temb=None, stat_out=None, side=False):
         """x (and optional concat partner x2) -> ResnetBlock2D output [batch*hw][cout]  (hw = pixels per image).
         temb: another time-projection table than net.temb_all; stat_out: fp32 [cout][2] to receive the output's
-        per-channel (sum, sumsq) (reference-only AdaIN)."""
+        per-channel (sum, sumsq) (reference-only AdaIN); side: stream 1 is free (UNet decoder): the shortcut conv goes there."""
         a, cfg = self.arena, net.cfg
         cin = c0 + c1
         rows = self.batch * hw
@@ -472,10 +486,23 @@ class Engine:
         self._gn(r, h, None, rw.cout, 0, hw, cfg.groups, 1e-5, rw.n2[0], rw.n2[1], True, t2)
         if rw.shortcut is not None:
             sc = a.alloc(rows, rw.cout)
-            r.conv(x, x2, Geom.linear(rows), rw.shortcut, sc, c0=c0, c1=c1)
+            if side:  # the 1x1 shortcut only depends on the block's input: run it beside GroupNorm / conv1 / GroupNorm
+                ev = f"sc{self._ev_count}"
+                self._ev_count += 1
+                r.signal(ev + "a")
+                r.use_stream(1)
+                r.wait(ev + "a")
+                r.conv(x, x2, Geom.linear(rows), rw.shortcut, sc, c0=c0, c1=c1)
+                r.signal(ev + "b")
+                r.use_stream(0)
+            else:
+                r.conv(x, x2, Geom.linear(rows), rw.shortcut, sc, c0=c0, c1=c1)
         else:
             sc = x
+            side = False
         out = out if out is not None else a.alloc(rows, rw.cout)
+        if side:
+            r.wait(ev + "b")
         r.conv(t2, None, geom, rw.conv2, out, residual=sc, residual2=residual2, out2=out2, add2=add2,
                chanstat_out=stat_out if stat_out is not None else self._stat_buf(out, rw.cout))
         return out
@@ -660,10 +687,13 @@ class Engine:
             hw = hh * ww
             g3 = Geom.conv(hh, ww, batch=self.batch)
             for j, (rw, tw) in enumerate(net.up[i]):
-                s, sc, slvl = skips.pop()
+                s, sc, slvl, *ev = skips.pop()
                 assert slvl == lvl and rw.cin == cprev + sc, (slvl, lvl, rw.cin, cprev, sc)
+                if ev and ev[0]:
+                    r.wait(ev[0])  # this skip's ControlNet merge ran on the second stream
                 st = self._ref_site(r, ref, "up", i, j, rw.cout)
-                h = self._resnet(r, rw, net, step, h, s, cprev, sc, hw, g3, temb=temb, stat_out=st if tw is None else None)
+                h = self._resnet(r, rw, net, step, h, s, cprev, sc, hw, g3, temb=temb, stat_out=st if tw is None else None,
+                                 side=self.overlap_controlnet and self.use_side_stream and self.side_shortcuts)
                 cprev = rw.cout
                 if tw is not None:
                     h = self._transformer(r, tw, net, h, hw, ref=ref, stat_out=st)
@@ -698,15 +728,30 @@ class Engine:
         nres = len(cn_skips) + 1
         sc = self._cn_scale_consts  # fp32 [nres] in device memory: logspace(-1, 0, nres) * controlnet_scale
         assert sc.numel() >= nres
-        merged = []
-        for i, ((s, c, lvl), (us, uc, ulvl)) in enumerate(zip(cn_skips, u_skips)):
+        # Only the mid-block merge is on the critical path; the decoder consumes the skips deepest first, one per ResnetBlock.
+        # With the second stream free after the encoders' join, the 12 skip merges run there, in the order the decoder
+        # needs them, each followed by a named event the consuming ResnetBlock waits for.
+        side = self.overlap_controlnet and self.use_side_stream
+        merged = [None] * len(cn_skips)
+        if side:
+            r.signal("enc_done")
+            r.use_stream(1)
+            r.wait("enc_done")
+        for i in reversed(range(len(cn_skips))):
+            (s, c, lvl), (us, uc, ulvl) = cn_skips[i], u_skips[i]
             assert (c, lvl) == (uc, ulvl)
             hh, ww = sizes[lvl]
             rows = self.batch * hh * ww
             o = a.alloc(rows, c)
             r.conv(s, None, Geom.linear(rows), net.zero_convs[i], o, out_scale_dev=sc[i:i + 1], residual=us,
                    chanstat_out=self._stat_buf(o, c))
-            merged.append((o, c, lvl))
+            ev = None
+            if side:
+                ev = f"skip{i}"
+                r.signal(ev)
+            merged[i] = (o, c, lvl, ev)
+        if side:
+            r.use_stream(0)
         hh, ww = sizes[-1]
         rows = self.batch * hh * ww
         c = net.cfg.block_out_channels[-1]
@@ -884,12 +929,19 @@ class Engine:
         img = lambda t, b, n: t[b * n:(b + 1) * n]  # noqa: E731  rows of image b
         r.preprocess_rgb(frame_b, B * H, W, enc_in)
         cond_emb = None
+        self._ev_count = 0
         if use_controlnet:
             ctrl = a.alloc(B * H * W, 8)
+            side0 = self.overlap_controlnet and self.use_side_stream
+            if side0:  # Sobel + the conditioning embedding only feed the ControlNet encoder (which runs on stream 1 too)
+                r.fork()
+                r.use_stream(1)
             for b in range(B):  # the edge map is normalised by ITS frame's maximum (canny_gpu.py:39)
                 r.sobel_control(frame_b[b], H, W, 0.11, 0.8, img(self.edge_u8, b, H * W), img(ctrl, b, H * W))  # videopipeline.py:109
             cond_emb = self._cond_embedding(r, ctrl, H, W)
             self.buffers["control"], self.buffers["cond_emb"] = ctrl, cond_emb
+            if side0:
+                r.use_stream(0)
         self._encode(r, enc_in, H, W, x0)
         if ref_mode:
             ref_b = ops.zeros(1, H, W, 3, dtype=torch.uint8)

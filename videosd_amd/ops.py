@@ -91,6 +91,7 @@ class HipOps:
         self.device_id = device_id
         self.streams = [self.stream, torch.cuda.Stream(device=self.device)]
         self._sidx = 0
+        self._events = {}
         self._ws = {}
         self.tile_override = {} if tile_override is None else tile_override
         self.inkernel_splitk = True
@@ -120,6 +121,16 @@ class HipOps:
         e = torch.cuda.Event()
         e.record(self.streams[1])
         self.streams[0].wait_event(e)
+
+    # ---- named dependencies between the two streams (edges of the captured graph): `signal` marks a point of the
+    #      current stream, `wait` makes the current stream wait for it
+    def signal(self, name: str):
+        e = torch.cuda.Event()
+        e.record(self.streams[self._sidx])
+        self._events[name] = e
+
+    def wait(self, name: str):
+        self.streams[self._sidx].wait_event(self._events[name])
 
     @staticmethod
     def _p(t):
