@@ -223,6 +223,11 @@ int vsd_lcm_step_dev(vsd_ctx* ctx, const void* eps, const void* sample, const vo
 int vsd_adain(vsd_ctx* ctx, const void* x, const void* stats, const void* stats_ref, int rows, int c, float eps, void* out,
               void* stream);
 
+/* CLIP text embeddings (CLIPTextEmbeddings under lcm_controlnet.py:175): out[i] = token_emb[ids[i]] + pos_emb[i], i < n.
+ * ids: int64 [n] in device memory (clamped to [0, vocab)); token_emb fp16 [vocab][c], pos_emb fp16 [>= n][c], out fp16 [n][c]. */
+int vsd_embed_tokens(vsd_ctx* ctx, const void* ids_i64, const void* token_emb, const void* pos_emb, int n, int c, int vocab,
+                     void* out, void* stream);
+
 /* decoder output fp16 [hw][ld] (3 channels used; value c of the last conv) -> u8 RGB HWC:
  * y = fp16(2c - 1) (DecoderTiny), (y/2 + 0.5).clamp(0,1)*255 rounded half-to-even
  * (VaeImageProcessor.postprocess, lcm_controlnet.py:609-611).                                         */

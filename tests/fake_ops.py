@@ -248,6 +248,10 @@ class FakeOps:
         sd, sd_r = var.clamp_min(eps).sqrt(), var_r.clamp_min(eps).sqrt()
         out[:, :c] = (((x[:, :c].float() - mean) / sd) * sd_r + mean_r).half()
 
+    def embed_tokens(self, ids_i64, tok_emb, pos_emb, out):
+        n = out.shape[0]
+        out.copy_((tok_emb[ids_i64.long()].float() + pos_emb[:n].float()).half())
+
     def add_noise_dev(self, x0, noise_f32, coef_dev, hw, batch, out):
         sa, sb = [float(v) for v in coef_dev.reshape(-1)[:2]]
         for b in range(batch):

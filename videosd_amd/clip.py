@@ -21,8 +21,8 @@ class ClipTextEncoder:
         self.ops, self.cfg = ops, cfg
         t = "text_model"
         dev = ops.to_device
-        self.tok_emb = dev(w[f"{t}.embeddings.token_embedding.weight"].half())
-        self.pos_emb = dev(w[f"{t}.embeddings.position_embedding.weight"].half())
+        self.tok_emb = dev(w[f"{t}.embeddings.token_embedding.weight"].half().contiguous())
+        self.pos_emb = dev(w[f"{t}.embeddings.position_embedding.weight"].half().contiguous())
         self.layers = []
         for i in range(cfg.layers):
             p = f"{t}.encoder.layers.{i}"
@@ -59,8 +59,9 @@ class ClipTextEncoder:
         ops, cfg = self.ops, self.cfg
         s, c, heads = ids.numel(), cfg.width, cfg.heads
         d = c // heads
-        ids = ops.to_device(ids.reshape(-1).long())
-        x = (self.tok_emb[ids].float() + self.pos_emb[:s].float()).half().contiguous()  # embedding gather: plumbing
+        ids = ops.to_device(ids.reshape(-1).long().contiguous())
+        x = ops.empty(s, c)
+        ops.embed_tokens(ids, self.tok_emb, self.pos_emb, x)  # token gather + position add (vsd_embed_tokens)
         lin = Geom.linear(s)
         ldvt = (s + 63) // 64 * 64
         n = ops.empty(s, c)

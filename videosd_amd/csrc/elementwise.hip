@@ -227,6 +227,22 @@ __global__ void adain_kernel(const half_t* __restrict__ x, const float* __restri
   }
 }
 
+// CLIP text embeddings: out[i] = fp16(fp32(token_embedding[ids[i]]) + fp32(position_embedding[i]))
+__global__ void embed_tokens_kernel(const long long* __restrict__ ids, const half_t* __restrict__ tok, const half_t* __restrict__ pos,
+                                    int n, int c8, int vocab, half_t* __restrict__ out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n * c8) return;
+  const int i = q / c8, ch = (q - i * c8) * 8;
+  long long id = ids[i];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const half8 a = *reinterpret_cast<const half8*>(tok + (size_t)id * c8 * 8 + ch);
+  const half8 b = *reinterpret_cast<const half8*>(pos + (size_t)i * c8 * 8 + ch);
+  half8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] + (float)b[j]);
+  *reinterpret_cast<half8*>(out + (size_t)i * c8 * 8 + ch) = o;
+}
+
 __global__ void postprocess_kernel(const half_t* __restrict__ img, int ld, int hw, unsigned char* __restrict__ rgb) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= hw) return;
@@ -344,6 +360,18 @@ extern "C" int vsd_adain(vsd_ctx* ctx, const void* x, const void* stats, const v
   LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
   hipLaunchKernelGGL(adain_kernel, dim3(grid), dim3(256), 0, s, (const half_t*)x, (const float*)stats, (const float*)stats_ref,
                      rows, c / 8, eps, (half_t*)out);
+  return ls.finish();
+}
+
+extern "C" int vsd_embed_tokens(vsd_ctx* ctx, const void* ids_i64, const void* token_emb, const void* pos_emb, int n, int c,
+                                int vocab, void* out, void* stream) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (!ids_i64 || !token_emb || !pos_emb || !out || n <= 0 || c <= 0 || c % 8 || vocab <= 0)
+    return vsd_fail(ctx, VSD_ERR_ARG, "embed_tokens: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope ls(ctx, s, VSD_FAM_ELEMENTWISE, 0.0);
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(cdiv(n * (c / 8), 256)), dim3(256), 0, s, (const long long*)ids_i64,
+                     (const half_t*)token_emb, (const half_t*)pos_emb, n, c / 8, vocab, (half_t*)out);
   return ls.finish();
 }
 

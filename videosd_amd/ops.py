@@ -446,6 +446,11 @@ class HipOps:
         """reference-only AdaIN: per-channel re-normalisation of x to the banked statistics (fp32 [c][2] sum / sumsq)"""
         self.ctx.call("vsd_adain", self._p(x), self._p(stats), self._p(stats_ref), rows, c, eps, self._p(out), self.s)
 
+    def embed_tokens(self, ids_i64, tok_emb, pos_emb, out):
+        n, c = out.shape
+        self.ctx.call("vsd_embed_tokens", self._p(ids_i64), self._p(tok_emb), self._p(pos_emb), n, c, tok_emb.shape[0],
+                      self._p(out), self.s)
+
     def postprocess_rgb(self, img, ld, hw, rgb_u8):
         self.ctx.call("vsd_postprocess_rgb", self._p(img), ld, hw, self._p(rgb_u8), self.s)
 
