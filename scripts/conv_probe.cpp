@@ -23,9 +23,9 @@ int main(int argc, char** argv) {
   for (auto& x : h) x = (_Float16)((rand() % 2001 - 1000) / 4000.0f);
   _Float16 *x, *w, *o, *r; long long* probe; float* ws; int* cnt;
   hipMalloc(&x, M * cin * 2); hipMalloc(&w, cout * Kp * 2); hipMalloc(&o, M * cout * 2); hipMalloc(&r, M * cout * 2);
-  hipMalloc(&probe, 64); hipMalloc(&ws, (size_t)split * M * cout * 4 + 256); hipMalloc(&cnt, VSD_SPLITK_MAX_TILES * 4);
+  hipMalloc(&probe, 128); hipMalloc(&ws, (size_t)split * M * cout * 4 + 256); hipMalloc(&cnt, VSD_SPLITK_MAX_TILES * 4);
   hipMemcpy(x, h.data(), M * cin * 2, hipMemcpyHostToDevice); hipMemcpy(w, h.data(), cout * Kp * 2, hipMemcpyHostToDevice);
-  hipMemset(r, 0, M * cout * 2); hipMemset(probe, 0, 64); hipMemset(cnt, 0, VSD_SPLITK_MAX_TILES * 4);
+  hipMemset(r, 0, M * cout * 2); hipMemset(probe, 0, 128); hipMemset(cnt, 0, VSD_SPLITK_MAX_TILES * 4);
   vsd_conv_set_probe(probe);
   vsd_conv_desc d; memset(&d, 0, sizeof d);
   d.src0 = x; d.c0 = cin; d.hs = d.hi = d.ho = H; d.ws = d.wi = d.wo = W; d.ksize = ks; d.stride = 1; d.pad = ks / 2;
@@ -39,10 +39,13 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 20; ++i) vsd_conv_gemm(ctx, &d, s);
   hipEventRecord(e1, s); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  long long pr[8]; hipMemcpy(pr, probe, 64, hipMemcpyDeviceToHost);
+  long long pr[16]; hipMemcpy(pr, probe, 128, hipMemcpyDeviceToHost);
   long long tot = 0; for (int i = 0; i < 7; ++i) tot += pr[i];
   double us = ms / 20 * 1e3, fl = 2.0 * M * cout * K;
   printf("M=%zu N=%d K=%zu ks=%d tile=%d pl=%d split=%d: %.1f us  %.0f TF/s | wave0 clocks: prologue %lld | vmcnt-wait %lld | barrier %lld | issue %lld | lds+mfma %lld | acc->lds %lld | epilogue %lld | total %lld (%zu k-tiles)\n",
          M, cout, K, ks, tile, pl, split, us, fl / us / 1e6, pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], tot, Kp / 64 / split);
+  long long tot2 = 0; for (int i = 8; i < 15; ++i) tot2 += pr[i];
+  printf("   last workgroup (a later round when the grid exceeds the resident slots): prologue %lld | vmcnt-wait %lld | barrier %lld | issue %lld | lds+mfma %lld | acc->lds %lld | epilogue %lld | total %lld\n",
+         pr[8], pr[9], pr[10], pr[11], pr[12], pr[13], pr[14], tot2);
   return 0;
 }

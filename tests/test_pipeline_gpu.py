@@ -78,6 +78,49 @@ def test_mini_pipeline_matches_oracle(mini_setup, H, W, steps, cn):
     assert r0 <= 5e-3 and r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (r0, r1, mad, psnr)
 
 
+@pytest.mark.parametrize("kind", ["black", "white", "flat_gray", "one_bright_pixel"])
+def test_degenerate_frames_match_oracle(mini_setup, kind):
+    """Edge cases of the reference's Sobel (canny_gpu.py:39-42): an all-black / constant frame has gradient 0 everywhere,
+    `mag / mag.max()` is 0/0 = NaN, both thresholds are false for NaN and `ToPILImage` turns it into byte 0 -- the control
+    image is black and nothing non-finite may reach the networks; a single bright pixel makes its neighbours the maximum."""
+    eng, orc, text = mini_setup
+    H = W = 128
+    f = np.zeros((H, W, 3), dtype=np.uint8)
+    if kind == "white":
+        f[:] = 255
+    elif kind == "flat_gray":
+        f[:] = 117
+    elif kind == "one_bright_pixel":
+        f[40, 77] = 255
+    eng.prepare(H, W, 2, 0.6, controlnet_scale=1.5, use_controlnet=True)
+    r0, r1, mad, psnr, got = _compare(eng, orc, f, text, H, W, 2, True)
+    assert torch.isfinite(eng.buffers["denoised"].float()).all() and torch.isfinite(eng.buffers["control"].float()).all()
+    if kind != "one_bright_pixel":  # (the border of a constant non-black frame does have a gradient: zero padding)
+        pass
+    if kind == "black":
+        assert float(eng.buffers["control"].float().abs().max()) == 0.0
+    assert r0 <= 5e-3 and r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (kind, r0, r1, mad, psnr)
+
+
+@pytest.mark.parametrize("strength,steps", [(1.0, 4), (0.05, 4), (0.6, 12), (0.98, 1)])
+def test_schedule_extremes_match_oracle(mini_setup, strength, steps):
+    """The client's option ranges (index.tsx:531-546: strength 0.05-1, steps 1-12): strength 1.0 starts at t = 999,
+    strength 0.05 yields FEWER timesteps than `steps` ([39, 19]), 12 steps is the UI's maximum, 1 step draws no step noise."""
+    eng, orc, text = mini_setup
+    H, W = 96, 160
+    plan = eng.prepare(H, W, steps, strength, controlnet_scale=1.0, use_controlnet=True)
+    f = _frame(H, W, seed=17)
+    got = eng.infer_u8(f)
+    ref = np.asarray(orc.infer(Image.fromarray(f, "RGB"), text[None].float(), height=H, width=W, strength=strength, steps=steps,
+                               seed=23, controlnet_scale=1.0, use_controlnet=True))
+    assert plan["timesteps"] == orc.sched.timesteps.tolist()
+    if (strength, steps) == (0.05, 4):
+        assert plan["timesteps"] == [39, 19]
+    if strength == 1.0:
+        assert plan["timesteps"][0] == 999
+    assert np.abs(got.astype(int) - ref.astype(int)).mean() <= 1.5 and _psnr(got, ref) >= 38.0
+
+
 def test_graph_replay_is_deterministic_and_equals_eager(mini_setup):
     eng, orc, text = mini_setup
     f = _frame(128, 128, seed=3)

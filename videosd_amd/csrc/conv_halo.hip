@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
 // NSB = slots of the weight-tile ring (lead = NSB - 1 tiles).
 template <int BN, int WMN, int NSB>
 __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p) {
+  prefetch_kernargs();
   constexpr int NW = 2 * WMN, NT = 64 * NW;
   constexpr int BM = 64 * WMN, PW = 16, PH = 4 * WMN, HW_ = PW + 2;  // halo row length 18
   constexpr int HUSED = (PH + 2) * HW_;                                // 180 / 324 halo rows

@@ -88,7 +88,9 @@ inline long long* g_conv_probe = nullptr;
   }
 #define CPROBE_OUT()                                                                       \
   if (p.probe && blockIdx.x == 0 && threadIdx.x == 0)                                      \
-    for (int i_ = 0; i_ < 8; ++i_) p.probe[i_] = pacc[i_];
+    for (int i_ = 0; i_ < 8; ++i_) p.probe[i_] = pacc[i_];                                 \
+  if (p.probe && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) /* a workgroup of the LAST round: warm caches */ \
+    for (int i_ = 0; i_ < 8; ++i_) p.probe[8 + i_] = pacc[i_];
 #else
 #define CPROBE(I_)
 #define CPROBE_OUT()
@@ -293,6 +295,21 @@ __device__ __forceinline__ void load_chunk8(const ConvParams& p, const float* Cs
   }
 }
 
+// The argument block (ConvParams, ~330 bytes = 6 cache lines) is read with scalar loads wherever a field is first
+// used: the compiler spreads those loads over the prologue and every first touch of a new 64-byte line is a miss of its
+// own (ISA of round 1: 8 s_load / s_waitcnt round trips before the first barrier, ~1k of the prologue's 3.7k cycles).
+// Touching one dword of every line at the very top brings all lines in together; the later loads hit the scalar cache.
+__device__ __forceinline__ void prefetch_kernargs() {
+  typedef const __attribute__((address_space(4))) unsigned* kptr_t;
+  kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr int NL = (sizeof(ConvParams) + 63) / 64;
+  unsigned t[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) t[i] = ka[i * 16];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) asm volatile("" ::"s"(t[i]));
+}
+
 // ---------------------------------------------------------------- block -> tile (XCD-aware)
 // Workgroups b and b+8 share an XCD (round-robin dispatch) and each XCD has its own L2, so the order decides how often an
 // operand crosses the fabric.  order 0: the tiles_m workgroups that stream the SAME weight tile (same tile_n / split) get
@@ -337,6 +354,7 @@ __device__ __forceinline__ void block_to_tile(const ConvParams& p, int bid, int&
 //   zeros into LDS: the conv's zero padding), and the weight rows need no vector instruction at all.
 template <int BM, int BN, bool GENERIC, int STAGES, bool ILV, bool FAST>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+  prefetch_kernargs();
   constexpr int WM = 2, WN = 2;             // 2x2 waves
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   constexpr int FM = TM / 16, FN = TN / 16;  // 16x16 fragments per wave
