@@ -142,6 +142,21 @@ typedef struct vsd_conv_desc {
 
 int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream);
 
+/* ---- fused per-token chains of a BasicTransformerBlock at the 320-wide level (csrc/fused_tail.hip) ---------------------
+ * One workgroup owns 64 tokens for the whole chain; only the weights stream.  All matrices fp16 row-major, C = 320.
+ * Weight operands are the packed forms of videosd_amd/packing.py ([N][K]; LayerNorm-consuming layers hold W*gamma with
+ * ln_s / ln_t fp32 [N]; the GEGLU layer is tile-packed, 64 hidden + 64 gate rows per 128).  Replace, for that level, the
+ * Attention.to_out / Attention.to_q / FeedForward / proj_out launches of diffusers' BasicTransformerBlock and
+ * Transformer2DModel under lcm_controlnet.py:558,568.
+ *   vsd_tail_a:  h1 = att W_out^T + b_out + h ;  q = LN(h1) W_q'^T                      (h1, q: [m][320])
+ *   vsd_tail_b:  h2 = att2 W_out^T + b_out + h1 ;  h3 = FF2(GEGLU(LN(h2) W_ff1'^T)) + b_ff2 + h2 ;
+ *                out = h3 W_proj^T + b_proj + x                                           (out: [m][320])          */
+int vsd_tail_a(vsd_ctx* ctx, const void* att, const void* h, int m, const void* w_out, const void* b_out, const void* w_q,
+               const void* ln_s, const void* ln_t, float ln_eps, void* h1_out, void* q_out, void* stream);
+int vsd_tail_b(vsd_ctx* ctx, const void* att2, const void* h1, const void* x, int m, const void* w_out, const void* b_out,
+               const void* w_ff1, const void* ln_s, const void* ln_t, float ln_eps, const void* w_ff2, const void* b_ff2,
+               const void* w_proj, const void* b_proj, void* out, void* stream);
+
 /* ---- GroupNorm (+SiLU) over an NHWC tensor, optionally the channel-concat of two tensors ---------
  * Replaces torch.nn.GroupNorm + SiLU in ResnetBlock2D / Transformer2DModel / conv_norm_out.
  * workspace: >= vsd_groupnorm_workspace_bytes(hw, c0 + c1, groups) bytes.                            */

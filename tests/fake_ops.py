@@ -248,6 +248,33 @@ class FakeOps:
         sd, sd_r = var.clamp_min(eps).sqrt(), var_r.clamp_min(eps).sqrt()
         out[:, :c] = (((x[:, :c].float() - mean) / sd) * sd_r + mean_r).half()
 
+    TAIL_C = 320
+
+    @staticmethod
+    def _ln_rows(x16, eps):
+        xf = x16.float()
+        mean = xf.mean(dim=1, keepdim=True)
+        var = (xf * xf).mean(dim=1, keepdim=True) - mean * mean
+        return mean, torch.rsqrt(var.clamp_min(0) + eps)
+
+    def tail_a(self, att, h, m, out1, q2, h1_out, q_out, ln_eps=1e-5):
+        h1 = att[:m].float() @ out1.weight[:, :out1.k].float().t() + out1.bias.float() + h[:m].float()
+        h1_out[:m] = h1.half()
+        mean, rstd = self._ln_rows(h1_out[:m], ln_eps)
+        acc = h1_out[:m].float() @ q2.weight[:, :q2.k].float().t()
+        q_out[:m] = (rstd * (acc - mean * q2.ln_s.float()[None, :]) + q2.ln_t.float()[None, :]).half()
+
+    def tail_b(self, att2, h1, x, m, out2, ff1, ff2, proj, out, ln_eps=1e-5):
+        h2 = att2[:m].float() @ out2.weight[:, :out2.k].float().t() + out2.bias.float() + h1[:m].float()
+        h2h = h2.half()
+        mean, rstd = self._ln_rows(h2h, ln_eps)
+        acc = h2h.float() @ ff1.weight[:, :ff1.k].float().t()
+        y = rstd * (acc - mean * ff1.ln_s.float()[None, :]) + ff1.ln_t.float()[None, :]
+        yy = y.reshape(m, ff1.n // 128, 2, 64)
+        hid = (yy[:, :, 0] * F.gelu(yy[:, :, 1])).reshape(m, ff1.n // 2).half()
+        h3 = hid.float() @ ff2.weight[:, :ff2.k].float().t() + ff2.bias.float() + h2
+        out[:m] = (h3.half().float() @ proj.weight[:, :proj.k].float().t() + proj.bias.float() + x[:m].float()).half()
+
     def embed_tokens(self, ids_i64, tok_emb, pos_emb, out):
         n = out.shape[0]
         out.copy_((tok_emb[ids_i64.long()].float() + pos_emb[:n].float()).half())

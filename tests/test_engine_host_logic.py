@@ -229,3 +229,26 @@ def test_absorbed_cross_attention_wiring(mini, monkeypatch):
     eng.prepare(64, 64, 2, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
     got2 = eng.infer_u8(frame)
     assert np.abs(got2.astype(int) - ref2.astype(int)).mean() < 0.3 and np.abs(ref2.astype(int) - ref.astype(int)).mean() > 1.0
+
+
+def test_fused_tail_wiring(mini, monkeypatch):
+    """The 320-wide transformer blocks run their per-token chains as tail_a / tail_b (csrc/fused_tail.hip): through the op
+    emulator (its tail ops restate the chain in fp32) the frame equals the unfused program's, with 5 launches fewer per
+    block.  The emulator's width constant is set to the reduced-width network's first level."""
+    wu, wc, wv, text = mini
+    frame = _frame(64, 64)
+    c0 = C.MINI_UNET.block_out_channels[0]
+    outs, counts = [], []
+    for fused in (False, True):
+        ops = FakeOps()
+        ops.TAIL_C = c0
+        eng = Engine(ops, C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
+        eng.use_fused_tail = fused
+        eng.set_text_embeds(text)
+        eng.prepare(64, 64, 2, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
+        counts.append(len(eng.program.calls))
+        n_tail = sum(1 for fn, a, k in eng.program.calls if fn.__name__ in ("tail_a", "tail_b"))
+        assert (n_tail > 0) == fused
+        outs.append(eng.infer_u8(frame))
+    assert counts[1] < counts[0]
+    assert np.abs(outs[0].astype(int) - outs[1].astype(int)).mean() < 0.3

@@ -504,6 +504,57 @@ def test_absorbed_cross_attention_matches_explicit_attention(ops, m, c, heads):
         ops.conv(h, None, Geom.linear(m), xa1, pr, ln_part=rs, act=L.ACT_SOFTMAX, softmax_cols=tl, tile=1, split_k=1)
 
 
+def _tail_weights(c=320, seed=0):
+    from videosd_amd.packing import pack_conv, pack_geglu_ln, pack_linear, pack_linear_ln
+
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s_, sc=1.0: (torch.randn(*s_, generator=g) * sc).half()  # noqa: E731
+    w = dict(wo1=r(c, c, sc=c ** -0.5), bo1=r(c, sc=0.1), wq=r(c, c, sc=c ** -0.5), g2=(1 + 0.1 * r(c).float()).half(), be2=r(c, sc=0.1),
+             wo2=r(c, c, sc=c ** -0.5), bo2=r(c, sc=0.1), g3=(1 + 0.1 * r(c).float()).half(), be3=r(c, sc=0.1),
+             wf1=r(8 * c, c, sc=c ** -0.5), bf1=r(8 * c, sc=0.1), wf2=r(c, 4 * c, sc=(4 * c) ** -0.5), bf2=r(c, sc=0.1),
+             wp=r(c, c, 1, 1, sc=c ** -0.5), bp=r(c, sc=0.1))
+    from videosd_amd.packing import add_frag
+
+    packs = dict(out1=pack_linear(w["wo1"], w["bo1"]), q2=pack_linear_ln([w["wq"]], None, w["g2"], w["be2"]),
+                 out2=pack_linear(w["wo2"], w["bo2"]), ff1=pack_geglu_ln(w["wf1"], w["bf1"], w["g3"], w["be3"]),
+                 ff2=pack_linear(w["wf2"], w["bf2"]), proj=pack_conv(w["wp"], w["bp"]))
+    return w, {k: add_frag(v) for k, v in packs.items()}
+
+
+@pytest.mark.parametrize("m", [12288, 4096, 200, 64])
+def test_fused_transformer_tail_matches_the_unfused_chain(ops, m):
+    """csrc/fused_tail.hip against explicit fp32 torch: tail_a = out-projection + residual, LayerNorm, query projection;
+    tail_b = out-projection + residual, LayerNorm, GEGLU feed-forward + residual, proj_out + residual.  m = 200 has a ragged
+    last 64-token tile."""
+    c = 320
+    w, packs = _tail_weights(c)
+    pk = {k: ops.to_device_pack(v) for k, v in packs.items()}
+    att, h, x = rnd(m, c, seed=1), (rnd(m, c, seed=2).float() * 2 + 0.5).half(), rnd(m, c, seed=3)
+    h1 = torch.zeros(m, c, dtype=torch.float16, device="cuda")
+    q = torch.zeros_like(h1)
+    ops.tail_a(att.cuda(), h.cuda(), m, pk["out1"], pk["q2"], h1, q)
+    ops.synchronize()
+    h1_ref = F.linear(att.float(), w["wo1"].float(), w["bo1"].float()) + h.float()
+    check(h1, h1_ref, "tail_a h1")
+    q_ref = F.linear(F.layer_norm(h1.float().cpu(), (c,), w["g2"].float(), w["be2"].float(), 1e-5), w["wq"].float())
+    check(q, q_ref, "tail_a q", rel=3e-3)
+    att2 = rnd(m, c, seed=4)
+    out = torch.zeros_like(h1)
+    ops.tail_b(att2.cuda(), h1, x.cuda(), m, pk["out2"], pk["ff1"], pk["ff2"], pk["proj"], out)
+    ops.synchronize()
+    h2 = F.linear(att2.float(), w["wo2"].float(), w["bo2"].float()) + h1.float().cpu()
+    ln = F.layer_norm(h2.half().float(), (c,), w["g3"].float(), w["be3"].float(), 1e-5)
+    hid, gate = F.linear(ln, w["wf1"].float(), w["bf1"].float()).chunk(2, dim=-1)
+    h3 = F.linear(hid * F.gelu(gate), w["wf2"].float(), w["bf2"].float()) + h2
+    ref = F.linear(h3, w["wp"].float().reshape(c, c), w["bp"].float()) + x.float()
+    check(out, ref, "tail_b out", rel=3e-3)
+    # deterministic, and nothing written past row m
+    out2 = torch.full((m + 64, c), 7.0, dtype=torch.float16, device="cuda")
+    ops.tail_b(att2.cuda(), h1, x.cuda(), m, pk["out2"], pk["ff1"], pk["ff2"], pk["proj"], out2)
+    ops.synchronize()
+    assert torch.equal(out2[:m], out) and bool((out2[m:] == 7.0).all())
+
+
 def test_preprocess_and_postprocess(ops):
     h, w = 40, 56
     rng = np.random.default_rng(0)

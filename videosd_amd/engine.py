@@ -25,7 +25,7 @@ from . import lib as L
 from .config import ControlNetConfig, TAESDConfig, UNetConfig
 from .lcm import LCMSchedule, timestep_sinusoid, w_embedding
 from .ops import Geom
-from .packing import (PackedConv, pack_conv, pack_cross_attention, pack_geglu_ln, pack_linear, pack_linear_cat,
+from .packing import (PackedConv, add_frag, pack_conv, pack_cross_attention, pack_geglu_ln, pack_linear, pack_linear_cat,
                       pack_linear_ln)
 from .weights import skip_channels
 
@@ -207,7 +207,7 @@ class NetWeights:
 
     # --- helpers
     def _to_dev(self, p: PackedConv) -> PackedConv:
-        for f in ("weight", "bias", "ln_s", "ln_t"):
+        for f in ("weight", "bias", "ln_s", "ln_t", "weight_frag"):
             v = getattr(p, f)
             if v is not None:
                 setattr(p, f, self.ops.to_device(v.contiguous()))
@@ -257,7 +257,12 @@ class NetWeights:
             blocks.append(blk)
         # use_linear_projection (SDXL): Linear on the token matrix == the 1x1 conv of SD1.5 in this layout
         proj = self._lin if self.cfg.linear_proj else self._conv
-        return TransformerW(c, self._norm(p + ".norm"), proj(p + ".proj_in"), blocks, proj(p + ".proj_out"))
+        tw = TransformerW(c, self._norm(p + ".norm"), proj(p + ".proj_in"), blocks, proj(p + ".proj_out"))
+        if c == getattr(self.ops, "TAIL_C", 0) and depth == 1:
+            # the fused per-token chains (csrc/fused_tail.hip) read these six matrices fragment-major
+            for pc in (blocks[0].out1, blocks[0].q2, blocks[0].out2, blocks[0].ff1, blocks[0].ff2, tw.proj_out):
+                pc.weight_frag = self.ops.to_device(add_frag(PackedConv(pc.weight.cpu(), None, pc.n, pc.k, pc.kp, pc.cin, pc.ksize)).weight_frag)
+        return tw
 
 
 class TAESDWeights:
@@ -372,6 +377,7 @@ class Engine:
         # ControlNet scales) that the captured graphs READ, so that `update_options` reaches every graph at once
         self.shared = {}
         self.absorb_cross_attention = True  # cross-attention of the wide blocks as two GEMMs (pack_cross_attention)
+        self.use_fused_tail = True          # 320-wide blocks: per-token chains in two launches (csrc/fused_tail.hip)
 
     def make_slot(self) -> "Engine":
         """A further frame in flight on the same GPU: shares the weights and the prompt / schedule constants of
@@ -551,11 +557,22 @@ class Engine:
                     r.attention(qk, 2 * c, qk[:, c:], 2 * c, vt_full[:, off:], ld2, att, c, hw, hw, heads, d, d ** -0.5)
                 else:
                     r.attention(qk, 2 * c, qk_full[:, c:], 2 * c, vt_full, ld2, att, c, hw, 2 * hw, heads, d, d ** -0.5)
+            kt, vtt = net.kv_cache[bw.kv_index]
+            if (self.use_fused_tail and c == getattr(self.ops, "TAIL_C", 0) and len(tw.blocks) == 1 and ref is None and
+                    stat_out is None and out2 is None and not self.fuse_gn_stats and hasattr(self.ops, "tail_a")):
+                # the block's per-token chains as two launches around the cross-attention (csrc/fused_tail.hip): h1, q, h2, the
+                # GEGLU hidden state and h3 stay on chip, the token tile's owner streams only the weights
+                h1 = a.alloc(rows, c)
+                q = a.alloc(rows, c)
+                r.tail_a(att, h, rows, bw.out1, bw.q2, h1, q)
+                r.attention(q, c, kt, c, vtt, vtt.shape[1], att, c, rows, kt.shape[0], heads, d, d ** -0.5)
+                out = a.alloc(rows, c)
+                r.tail_b(att, h1, x, rows, bw.out2, bw.ff1, bw.ff2, tw.proj_out, out)
+                return out
             h1 = a.alloc(rows, c)
             rs1 = stat()
             r.conv(att, None, lin, bw.out1, h1, residual=h, rowstat_out=rs1)
             # cross-attention over the cached text K / V^T (shared by all images)
-            kt, vtt = net.kv_cache[bw.kv_index]
             h2 = a.alloc(rows, c)
             rs2 = stat()
             if bw.xa1 is not None and self.absorb_cross_attention:

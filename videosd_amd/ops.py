@@ -162,7 +162,7 @@ class HipOps:
             dst.copy_(src, non_blocking=True)
 
     def to_device_pack(self, p: PackedConv) -> PackedConv:
-        for f in ("weight", "bias", "ln_s", "ln_t"):
+        for f in ("weight", "bias", "ln_s", "ln_t", "weight_frag"):
             v = getattr(p, f)
             if v is not None:
                 setattr(p, f, v.to(self.device).contiguous())
@@ -387,6 +387,20 @@ class HipOps:
                 self.tile_override[key] = (int(v[0]), int(v[1]), bool(v[2]), int(v[3]))
                 n += 1
         return n
+
+    # ---- fused per-token chains of a transformer block at the 320-wide level (csrc/fused_tail.hip)
+    TAIL_C = 320
+
+    def tail_a(self, att, h, m, out1: PackedConv, q2: PackedConv, h1_out, q_out, ln_eps=1e-5):
+        """h1 = att Wo^T + b + h ; q = LN(h1) Wq'^T"""
+        self.ctx.call("vsd_tail_a", self._p(att), self._p(h), m, self._p(out1.weight_frag), self._p(out1.bias), self._p(q2.weight_frag),
+                      self._p(q2.ln_s), self._p(q2.ln_t), ln_eps, self._p(h1_out), self._p(q_out), self.s)
+
+    def tail_b(self, att2, h1, x, m, out2: PackedConv, ff1: PackedConv, ff2: PackedConv, proj: PackedConv, out, ln_eps=1e-5):
+        """h2 = att2 Wo^T + b + h1 ; h3 = GEGLU-FF(LN(h2)) + h2 ; out = h3 Wp^T + b + x"""
+        self.ctx.call("vsd_tail_b", self._p(att2), self._p(h1), self._p(x), m, self._p(out2.weight_frag), self._p(out2.bias),
+                      self._p(ff1.weight_frag), self._p(ff1.ln_s), self._p(ff1.ln_t), ln_eps, self._p(ff2.weight_frag),
+                      self._p(ff2.bias), self._p(proj.weight_frag), self._p(proj.bias), self._p(out), self.s)
 
     def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=None, batch=1):
         if batch > 1:

@@ -22,6 +22,7 @@ class PackedConv:
     ln_s: Optional[torch.Tensor] = None   # fp32 [n]: sum_k (W*gamma)[n][k]   (fused input LayerNorm, include/vsd.h)
     ln_t: Optional[torch.Tensor] = None   # fp32 [n]: sum_k beta[k] W[n][k] + bias[n]
     tile128: bool = False                 # the epilogue needs whole 128-column tiles and no split-K (tile softmax)
+    weight_frag: Optional[torch.Tensor] = None  # the same weights fragment-major (pack_mfma_frag), for csrc/fused_tail.hip
 
     @property
     def n_out(self) -> int:
@@ -150,3 +151,18 @@ def pack_cross_attention(k: torch.Tensor, v: torch.Tensor, wq: torch.Tensor, wo:
     xa1.tile128 = True
     xa2 = pack_linear(z, bo)
     return xa1, xa2
+
+
+def pack_mfma_frag(w2d: torch.Tensor) -> torch.Tensor:
+    """[N][K] fp16 (N % 16 == 0, K % 32 == 0) -> fragment-major: blocks [N/16][K/32] of [4 (k/8)][16 (n)][8] halfs, so that
+    lane l = n + 16 q of a 16x16x32 MFMA B fragment reads 16 contiguous bytes at offset 16 l of its 1 KB block
+    (csrc/fused_tail.hip load_b: one wave-instruction = one contiguous KB of weights)."""
+    n, k = w2d.shape
+    assert n % 16 == 0 and k % 32 == 0
+    v = w2d.reshape(n // 16, 16, k // 32, 4, 8)          # [nb][n][kb][q][e]
+    return v.permute(0, 2, 3, 1, 4).contiguous().reshape(-1)  # [nb][kb][q][n][e]
+
+
+def add_frag(p: PackedConv) -> PackedConv:
+    p.weight_frag = pack_mfma_frag(p.weight[:, :p.k].to(torch.float16))
+    return p
