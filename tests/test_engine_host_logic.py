@@ -239,16 +239,19 @@ def test_fused_tail_wiring(mini, monkeypatch):
     frame = _frame(64, 64)
     c0 = C.MINI_UNET.block_out_channels[0]
     outs, counts = [], []
-    for fused in (False, True):
+    for fused, min_rows in ((False, 0), (True, 1), (True, 1 << 30)):  # unfused / both chains fused / only the attention-side chain
         ops = FakeOps()
         ops.TAIL_C = c0
         eng = Engine(ops, C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
         eng.use_fused_tail = fused
+        eng.tail_b_min_rows = min_rows
         eng.set_text_embeds(text)
         eng.prepare(64, 64, 2, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
         counts.append(len(eng.program.calls))
-        n_tail = sum(1 for fn, a, k in eng.program.calls if fn.__name__ in ("tail_a", "tail_b"))
-        assert (n_tail > 0) == fused
+        names = [fn.__name__ for fn, a, k in eng.program.calls]
+        assert ("tail_a" in names) == fused and ("tail_b" in names) == (fused and min_rows == 1)
         outs.append(eng.infer_u8(frame))
+    assert counts[1] < counts[2] < counts[0]
+    assert np.abs(outs[0].astype(int) - outs[2].astype(int)).mean() < 0.3
     assert counts[1] < counts[0]
     assert np.abs(outs[0].astype(int) - outs[1].astype(int)).mean() < 0.3

@@ -76,41 +76,73 @@ __device__ __forceinline__ void load_b(BFrag<NF>& b, const half_t* wf, int kbloc
   }
 }
 
-// acc[mi][j] += A[rows of fragment mi][ka0 .. ka0 + 63] * B^T, A from the LDS tile `a` (pitch lda)
-template <int NF>
-__device__ __forceinline__ void mma_b(const half_t* a, int lda, int ka0, const BFrag<NF>& b, int lane, f32x4 (&acc)[4][NF]) {
+// Waves: WM row groups x 4 column groups.  A wave owns rows [32 wm .. ] (MI = 4 / WM accumulator row fragments) and
+// columns [80 wn, 80 wn + 80).  WM = 2 (512 threads) puts two waves on every SIMD: one's GEGLU / epilogue VALU work runs
+// under the other's MFMAs (with WM = 1 the single wave per SIMD serialises them: measured 80 vs ... us for tail_b); the two
+// waves of a column group request the same weight fragments, the second request hits the CU's L1.  Measured (us, 12288 /
+// 4096 tokens): tail_a 17.5 / 14.2 with WM = 2 against 19.4 / 16.6; tail_b 80 / 70 either way.
+// (tail_a runs WM = 2; tail_b's feed-forward loop needs ~330 registers per wave and runs WM = 1)
+
+// acc[mi][j] += A[rows of fragment mi][ka0 .. ka0 + 63] * B^T, A from the LDS tile `a` (pitch lda), rows from arow0
+template <int MI>
+struct AFrag {
+  half8 v[2][MI];  // [k-step of 32][row fragment]
+};
+
+template <int MI>
+__device__ __forceinline__ void load_a(AFrag<MI>& a, const half_t* x, int lda, int arow0, int ka0, int lane) {
   const int r = lane & 15, q = lane >> 4;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    half8 af[4];
+  for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const half8*>(a + (mi * 16 + r) * lda + ka0 + ks * 32 + q * 8);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int j = 0; j < NF; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], b.v[ks][j], acc[mi][j], 0, 0, 0);
-  }
+    for (int mi = 0; mi < MI; ++mi) a.v[ks][mi] = *reinterpret_cast<const half8*>(x + (arow0 + mi * 16 + r) * lda + ka0 + ks * 32 + q * 8);
 }
 
-// acc (64 x 80 per wave) = X[64][320] W[80 rows of this wave][320]^T: five K tiles, three fragment sets in flight
-__device__ __forceinline__ void gemm320(const half_t* X, const half_t* w, int kblocks, int kbase, int wave, int lane, f32x4 (&acc)[4][5]) {
-  const int nb[5] = {80 * wave, 80 * wave + 16, 80 * wave + 32, 80 * wave + 48, 80 * wave + 64};
+template <int MI, int NF>
+__device__ __forceinline__ void mma_ab(const AFrag<MI>& a, const BFrag<NF>& b, f32x4 (&acc)[MI][NF]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[mi][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v[ks][mi], b.v[ks][j], acc[mi][j], 0, 0, 0);
+}
+
+// acc[mi][j] += A[rows of fragment mi][ka0 .. ka0 + 63] * B^T, A from the LDS tile `a` (pitch lda), rows from arow0
+template <int MI, int NF>
+__device__ __forceinline__ void mma_b(const half_t* a, int lda, int arow0, int ka0, const BFrag<NF>& b, int lane, f32x4 (&acc)[MI][NF]) {
+  AFrag<MI> af;
+  load_a(af, a, lda, arow0, ka0, lane);
+  mma_ab(af, b, acc);
+}
+
+// acc (rows of this wave x 80) = X[.][320] W[80 rows of this wave][320]^T: five K tiles, three fragment sets in flight
+template <int MI>
+__device__ __forceinline__ void gemm320(const half_t* X, int arow0, const half_t* w, int kblocks, int wn, int lane, f32x4 (&acc)[MI][5]) {
+  const int nb[5] = {80 * wn, 80 * wn + 16, 80 * wn + 32, 80 * wn + 48, 80 * wn + 64};
   BFrag<5> b0, b1, b2;
-  load_b(b0, w, kblocks, kbase, nb, lane);
-  load_b(b1, w, kblocks, kbase + 64, nb, lane);
-  load_b(b2, w, kblocks, kbase + 128, nb, lane);
-  mma_b(X, XP, 0, b0, lane, acc);
-  load_b(b0, w, kblocks, kbase + 192, nb, lane);
-  mma_b(X, XP, 64, b1, lane, acc);
-  load_b(b1, w, kblocks, kbase + 256, nb, lane);
-  mma_b(X, XP, 128, b2, lane, acc);
-  mma_b(X, XP, 192, b0, lane, acc);
-  mma_b(X, XP, 256, b1, lane, acc);
+  load_b(b0, w, kblocks, 0, nb, lane);
+  load_b(b1, w, kblocks, 64, nb, lane);
+  load_b(b2, w, kblocks, 128, nb, lane);
+  // A fragments one K tile ahead of their MFMAs: the LDS latency (~130 cycles per fragment set) hides under a tile's MFMAs
+  AFrag<MI> a0, a1;
+  load_a(a0, X, XP, arow0, 0, lane);
+  load_a(a1, X, XP, arow0, 64, lane);
+  mma_ab(a0, b0, acc);
+  load_b(b0, w, kblocks, 192, nb, lane);
+  load_a(a0, X, XP, arow0, 128, lane);
+  mma_ab(a1, b1, acc);
+  load_b(b1, w, kblocks, 256, nb, lane);
+  load_a(a1, X, XP, arow0, 192, lane);
+  mma_ab(a0, b2, acc);
+  load_a(a0, X, XP, arow0, 256, lane);
+  mma_ab(a1, b0, acc);
+  mma_ab(a0, b1, acc);
 }
 
 // Workgroup barrier for LDS data ONLY.  __syncthreads() also waits for every outstanding vector-memory operation
-// (vmcnt(0)) -- here that would drain the weight fragments in flight for the next chunk twice per chunk (measured: 2.9 MB
-// per workgroup in 114 us = 25 GB/s per CU).  The compiler still inserts the vmcnt waits the loaded registers need.
+// (vmcnt(0)) -- here that would drain the weight fragments in flight for the next chunk.  The compiler still inserts the
+// vmcnt waits the loaded registers need.
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -118,13 +150,14 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // accumulator element (mi, j, rr) of lane -> (row, col) of the 64 x 320 tile
-#define TAIL_ROW(mi, rr) ((mi) * 16 + 4 * (lane >> 4) + (rr))
-#define TAIL_COL(j) (80 * wave + 16 * (j) + (lane & 15))
+#define TAIL_ROW(mi, rr) (arow0 + (mi) * 16 + 4 * (lane >> 4) + (rr))
+#define TAIL_COL(j) (80 * wn + 16 * (j) + (lane & 15))
 
-// residual tile in accumulator layout straight from global memory (2-byte loads; issued at kernel start, consumed later)
-__device__ __forceinline__ void load_res(const half_t* g, int m0, int M, int wave, int lane, half_t (&r)[4][5][4]) {
+// residual tile in accumulator layout straight from global memory (2-byte loads)
+template <int MI>
+__device__ __forceinline__ void load_res(const half_t* g, int m0, int M, int arow0, int wn, int lane, half_t (&r)[MI][5][4]) {
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       int m = m0 + TAIL_ROW(mi, rr);
@@ -135,11 +168,12 @@ __device__ __forceinline__ void load_res(const half_t* g, int m0, int M, int wav
 }
 
 // fp16 tile X <- v (rounded), and the per-row (mean, rstd) of the ROUNDED values -> ms[row][2]
-__device__ __forceinline__ void store_tile_and_stats(half_t* X, float* part, float* ms, float (&v)[4][5][4], int wave, int lane, int tid,
-                                                     float eps, bool want_stats) {
-  float s[4][4], q2[4][4];
+template <int MI>
+__device__ __forceinline__ void store_tile_and_stats(half_t* X, float* part, float* ms, float (&v)[MI][5][4], int arow0, int wn, int lane,
+                                                     int tid, float eps, bool want_stats) {
+  float s[MI][4], q2[MI][4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       float ss = 0.f, qq = 0.f;
@@ -156,7 +190,7 @@ __device__ __forceinline__ void store_tile_and_stats(half_t* X, float* part, flo
     }
   if (!want_stats) return;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
@@ -165,8 +199,8 @@ __device__ __forceinline__ void store_tile_and_stats(half_t* X, float* part, flo
         q2[mi][rr] += __shfl_xor(q2[mi][rr], o);
       }
       if ((lane & 15) == 0) {
-        part[(TAIL_ROW(mi, rr) * 4 + wave) * 2] = s[mi][rr];
-        part[(TAIL_ROW(mi, rr) * 4 + wave) * 2 + 1] = q2[mi][rr];
+        part[(TAIL_ROW(mi, rr) * 4 + wn) * 2] = s[mi][rr];
+        part[(TAIL_ROW(mi, rr) * 4 + wn) * 2 + 1] = q2[mi][rr];
       }
     }
   lds_barrier();
@@ -181,48 +215,52 @@ __device__ __forceinline__ void store_tile_and_stats(half_t* X, float* part, flo
     ms[2 * tid] = mean;
     ms[2 * tid + 1] = rsqrtf(fmaxf(Q * (1.0f / C) - mean * mean, 0.f) + eps);
   }
-  // (the caller's next ring acquire has the barriers that publish X / ms)
 }
 
 // rows of the LDS tile -> global, 16 bytes per lane
+template <int NTH>
 __device__ __forceinline__ void write_tile(const half_t* X, half_t* g, int m0, int M, int tid) {
-  for (int q = tid; q < BM * (C / 8); q += 256) {
+  for (int q = tid; q < BM * (C / 8); q += NTH) {
     const int r = q / (C / 8), c8 = (q - r * (C / 8)) * 8;
     if (m0 + r < M) *reinterpret_cast<half8*>(g + (size_t)(m0 + r) * C + c8) = *reinterpret_cast<const half8*>(X + r * XP + c8);
   }
 }
 
+template <int NTH>
 __device__ __forceinline__ void load_a_tile(const half_t* g, half_t* X, int m0, int M, int tid) {
-  half8 v[10];
+  constexpr int NV = BM * (C / 8) / NTH;
+  half8 v[NV];
 #pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const int q = tid + i * 256;
+  for (int i = 0; i < NV; ++i) {
+    const int q = tid + i * NTH;
     const int r = q / (C / 8), c8 = (q - r * (C / 8)) * 8;
     int m = m0 + r;
     m = m < M ? m : M - 1;
     v[i] = *reinterpret_cast<const half8*>(g + (size_t)m * C + c8);
   }
 #pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const int q = tid + i * 256;
+  for (int i = 0; i < NV; ++i) {
+    const int q = tid + i * NTH;
     const int r = q / (C / 8), c8 = (q - r * (C / 8)) * 8;
     *reinterpret_cast<half8*>(X + r * XP + c8) = v[i];
   }
 }
 
-template <int KIND>
-__global__ __launch_bounds__(256) void tail_kernel(const TailParams p) {
+template <int KIND, int WM>
+__global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
+  constexpr int MI = 4 / WM, NTH = 256 * WM;
   __shared__ __attribute__((aligned(16))) half_t Xs[BM * XP];
-  __shared__ __attribute__((aligned(16))) half_t Hs[BM * HP];
+  __shared__ __attribute__((aligned(16))) half_t Hs[2 * BM * HP];
   __shared__ float part[BM * 4 * 2];
   __shared__ float ms[BM * 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 3, arow0 = (wave >> 2) * (BM / WM);
   const int m0 = blockIdx.x * BM;
 
   // ---- everything the chain needs from HBM besides the weights is requested up front
-  half_t res0[4][5][4];
-  load_res(p.res0, m0, p.M, wave, lane, res0);
-  load_a_tile(p.a_in, Xs, m0, p.M, tid);
+  half_t res0[MI][5][4];
+  load_res(p.res0, m0, p.M, arow0, wn, lane, res0);
+  load_a_tile<NTH>(p.a_in, Xs, m0, p.M, tid);
   float cb0[5], cb2[5], cb3[5], cs1[5], ct1[5];
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
@@ -230,16 +268,13 @@ __global__ __launch_bounds__(256) void tail_kernel(const TailParams p) {
     if constexpr (KIND == 0) {
       cs1[j] = p.ln_s1[TAIL_COL(j)];
       ct1[j] = p.ln_t1[TAIL_COL(j)];
-    } else {
-      cb2[j] = (float)p.b2[TAIL_COL(j)];
-      cb3[j] = (float)p.b3[TAIL_COL(j)];
     }
   }
   (void)cb2; (void)cb3; (void)cs1; (void)ct1;
-  f32x4 acc[4][5];
+  f32x4 acc[MI][5];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int j = 0; j < 5; ++j) acc[mi][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
@@ -247,26 +282,26 @@ __global__ __launch_bounds__(256) void tail_kernel(const TailParams p) {
 
   // ---- stage 1: h1 = a_in W0^T + b0 + res0
   zero_acc();
-  gemm320(Xs, p.w0, C / 32, 0, wave, lane, acc);
-  float h1[4][5][4];
+  gemm320(Xs, arow0, p.w0, C / 32, wn, lane, acc);
+  float h1[MI][5][4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int j = 0; j < 5; ++j)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) h1[mi][j][rr] = acc[mi][j][rr] + cb0[j] + (float)res0[mi][j][rr];
   lds_barrier();  // every wave has read the last A fragments of the input tile: X may be overwritten
-  store_tile_and_stats(Xs, part, ms, h1, wave, lane, tid, p.ln_eps, true);
+  store_tile_and_stats(Xs, part, ms, h1, arow0, wn, lane, tid, p.ln_eps, true);
   lds_barrier();  // X (= h1 rounded to fp16) and the row statistics are published
 
   if constexpr (KIND == 0) {
     // ---- tail_a: q = LN(h1) W1'^T  (folded LayerNorm), h1 and q to HBM
-    write_tile(Xs, p.out0, m0, p.M, tid);
+    write_tile<NTH>(Xs, p.out0, m0, p.M, tid);
     zero_acc();
-    gemm320(Xs, p.w1, C / 32, 0, wave, lane, acc);
-    float qv[4][5][4];
+    gemm320(Xs, arow0, p.w1, C / 32, wn, lane, acc);
+    float qv[MI][5][4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const float mean = ms[2 * TAIL_ROW(mi, rr)], rstd = ms[2 * TAIL_ROW(mi, rr) + 1];
@@ -274,95 +309,161 @@ __global__ __launch_bounds__(256) void tail_kernel(const TailParams p) {
         for (int j = 0; j < 5; ++j) qv[mi][j][rr] = rstd * (acc[mi][j][rr] - mean * cs1[j]) + ct1[j];
       }
     lds_barrier();
-    store_tile_and_stats(Xs, part, ms, qv, wave, lane, tid, p.ln_eps, false);
+    store_tile_and_stats(Xs, part, ms, qv, arow0, wn, lane, tid, p.ln_eps, false);
     lds_barrier();
-    write_tile(Xs, p.out1, m0, p.M, tid);
+    write_tile<NTH>(Xs, p.out1, m0, p.M, tid);
     return;
   } else {
-    // ---- tail_b: GEGLU feed-forward on LN(h2) (h2 = the tile just stored; its fp32 values stay in h1[] as residual).
-    // Per 64-wide hidden chunk c: S = X W1_c'^T (tile-packed rows: [0,64) hidden, [64,128) gate; wave w takes hidden
-    // columns [16w, 16w+16) and their gates), GEGLU -> Hc (LDS), acc3 += Hc W2[:, 64c : 64c+64]^T.  The B fragments of a
-    // chunk (5 x 2 for W1, 1 x 5 for W2) have fixed registers that are re-loaded for chunk c+1 right after their last use
-    // in chunk c: a whole chunk (30 KB per wave) is always in flight.
-    f32x4 acc3[4][5];
+    // ---- tail_b: GEGLU feed-forward on LN(h2) (h2 = the tile just stored).
+    // Per 64-wide hidden chunk c: S = X W1_c'^T (tile-packed rows: [0,64) hidden, [64,128) gate; column group wn takes
+    // hidden columns [16 wn, 16 wn + 16) and their gates), GEGLU -> Hc (LDS), acc3 += Hc W2[:, 64c : 64c+64]^T.  The B
+    // fragments (5 x 2 for W1, 1 x 5 for W2) have fixed registers that are re-loaded for a later chunk right after their
+    // last use: more than a chunk of weights (30 KB per wave) is always in flight.
+    f32x4 acc3[MI][5];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int j = 0; j < 5; ++j) acc3[mi][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nb2[5] = {80 * wave, 80 * wave + 16, 80 * wave + 32, 80 * wave + 48, 80 * wave + 64};
+    const int nb2[5] = {80 * wn, 80 * wn + 16, 80 * wn + 32, 80 * wn + 48, 80 * wn + 64};
     BFrag<2> g1[5];
     BFrag<5> g2;
     float lnc[4];  // this chunk's LayerNorm-fold constants of the lane's hidden / gate column: s_h, t_h, s_g, t_g
+    // Every workgroup streams the SAME 2.4 MB of feed-forward weights; walking the chunks in the same order makes all CUs
+    // of an XCD ask its L2 for the same lines at the same time (each line lives in one L2 channel).  The chunk order is
+    // therefore rotated per workgroup (the sum over chunks is order-independent up to fp32 rounding; a given workgroup
+    // always uses the same order, so results stay deterministic).
+    const int rot = blockIdx.x % NCHUNK;
+    auto chunk_of = [&](int i) {
+      i = i < NCHUNK ? i : NCHUNK - 1;
+      const int c = i + rot;
+      return c < NCHUNK ? c : c - NCHUNK;
+    };
     auto load_chunk_w1 = [&](int c, int kt) {
-      const int nb1[2] = {c * 128 + 16 * wave, c * 128 + 64 + 16 * wave};
+      const int nb1[2] = {c * 128 + 16 * wn, c * 128 + 64 + 16 * wn};
       load_b(g1[kt], p.w1, C / 32, kt * 64, nb1, lane);
     };
     auto load_chunk_lnc = [&](int c) {
-      const int nh = c * 128 + 16 * wave + (lane & 15);
+      const int nh = c * 128 + 16 * wn + (lane & 15);
       lnc[0] = p.ln_s1[nh]; lnc[1] = p.ln_t1[nh]; lnc[2] = p.ln_s1[nh + 64]; lnc[3] = p.ln_t1[nh + 64];
     };
 #pragma unroll
-    for (int kt = 0; kt < 5; ++kt) load_chunk_w1(0, kt);
-    load_b(g2, p.w2, FF / 32, 0, nb2, lane);
-    load_chunk_lnc(0);
-    for (int c = 0; c < NCHUNK; ++c) {
-      const int cn = c + 1 < NCHUNK ? c + 1 : c;  // (the last iteration re-loads its own chunk: harmless)
-      f32x4 sh[4][2];
+    for (int kt = 0; kt < 5; ++kt) load_chunk_w1(chunk_of(0), kt);
+    load_b(g2, p.w2, FF / 32, chunk_of(0) * 64, nb2, lane);
+    load_chunk_lnc(chunk_of(0));
+    f32x4 sh[MI][2];
+    auto zero_sh = [&](f32x4 (&t)[MI][2]) {
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        sh[mi][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        sh[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int mi = 0; mi < MI; ++mi) {
+        t[mi][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        t[mi][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
+    };
+    // t += X W1_c'^T for the chunk whose fragments are in g1 (re-loading them for chunk `cnext` as they are used); the A
+    // fragments run one K tile ahead of their MFMAs
+    auto scores = [&](f32x4 (&t)[MI][2], int cnext) {
+      AFrag<MI> a0, a1;
+      load_a(a0, Xs, XP, arow0, 0, lane);
+      load_a(a1, Xs, XP, arow0, 64, lane);
+      mma_ab(a0, g1[0], t);
+      load_chunk_w1(cnext, 0);
+      load_a(a0, Xs, XP, arow0, 128, lane);
+      mma_ab(a1, g1[1], t);
+      load_chunk_w1(cnext, 1);
+      load_a(a1, Xs, XP, arow0, 192, lane);
+      mma_ab(a0, g1[2], t);
+      load_chunk_w1(cnext, 2);
+      load_a(a0, Xs, XP, arow0, 256, lane);
+      mma_ab(a1, g1[3], t);
+      load_chunk_w1(cnext, 3);
+      mma_ab(a0, g1[4], t);
+      load_chunk_w1(cnext, 4);
+    };
+    auto geglu_to_lds = [&](f32x4 (&t)[MI][2], half_t* Hc, float s_h, float t_h, float s_g, float t_g) {
 #pragma unroll
-      for (int kt = 0; kt < 5; ++kt) {
-        mma_b(Xs, XP, kt * 64, g1[kt], lane, sh);
-        load_chunk_w1(cn, kt);
-      }
-      const float s_h = lnc[0], t_h = lnc[1], s_g = lnc[2], t_g = lnc[3];
-      load_chunk_lnc(cn);
-      if (c > 0) lds_barrier();  // every wave is done reading the previous chunk's Hc
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int row = TAIL_ROW(mi, rr);
           const float mean = ms[2 * row], rstd = ms[2 * row + 1];
-          const float hv = rstd * (sh[mi][0][rr] - mean * s_h) + t_h;
-          const float gv = rstd * (sh[mi][1][rr] - mean * s_g) + t_g;
-          Hs[row * HP + 16 * wave + (lane & 15)] = (half_t)(hv * gelu_erf_f(gv));
+          const float hv = rstd * (t[mi][0][rr] - mean * s_h) + t_h;
+          const float gv = rstd * (t[mi][1][rr] - mean * s_g) + t_g;
+          Hc[row * HP + 16 * wn + (lane & 15)] = (half_t)(hv * gelu_erf_f(gv));
         }
-      lds_barrier();  // Hc is complete
-      mma_b(Hs, HP, 0, g2, lane, acc3);
-      load_b(g2, p.w2, FF / 32, cn * 64, nb2, lane);
-    }
-    // h3 = acc3 + b2 + h2 -> X
-    float h3[4][5][4];
+    };
+    // The GEGLU output is double buffered in LDS, so ONE barrier per chunk (Hc complete) is enough: a wave writing buffer
+    // c & 1 is past the barrier of chunk c-1, which every wave reaches only after its reads of that buffer in chunk c-2.
+    if constexpr (WM == 1) {
+      // one wave per SIMD: software pipeline -- the scores of chunk c+1 (MFMA) sit in the same basic block as the GEGLU of
+      // chunk c (VALU, transcendental) so that the two pipes overlap inside the wave
+      zero_sh(sh);
+      scores(sh, chunk_of(1));
+      for (int c = 0; c < NCHUNK; ++c) {
+        const int c2 = chunk_of(c + 2);  // (the last iterations re-load the last chunk: harmless)
+        const int c1 = chunk_of(c + 1);
+        const float s_h = lnc[0], t_h = lnc[1], s_g = lnc[2], t_g = lnc[3];
+        load_chunk_lnc(c1);
+        f32x4 sn[MI][2];
+        zero_sh(sn);
+        scores(sn, c2);
+        half_t* Hc = Hs + (c & 1) * (BM * HP);
+        geglu_to_lds(sh, Hc, s_h, t_h, s_g, t_g);
+        lds_barrier();
+        mma_b(Hc, HP, arow0, 0, g2, lane, acc3);
+        load_b(g2, p.w2, FF / 32, c1 * 64, nb2, lane);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI; ++mi) {
+          sh[mi][0] = sn[mi][0];
+          sh[mi][1] = sn[mi][1];
+        }
+      }
+    } else {
+      // two waves per SIMD: the partner wave fills the other pipe; the plain order keeps the register count at 256
+      for (int c = 0; c < NCHUNK; ++c) {
+        const int c1 = chunk_of(c + 1);
+        zero_sh(sh);
+        scores(sh, c1);
+        const float s_h = lnc[0], t_h = lnc[1], s_g = lnc[2], t_g = lnc[3];
+        load_chunk_lnc(c1);
+        half_t* Hc = Hs + (c & 1) * (BM * HP);
+        geglu_to_lds(sh, Hc, s_h, t_h, s_g, t_g);
+        lds_barrier();
+        mma_b(Hc, HP, arow0, 0, g2, lane, acc3);
+        load_b(g2, p.w2, FF / 32, c1 * 64, nb2, lane);
+      }
+    }
+    // h3 = acc3 + b2 + h2 -> X.  The residual h2 is read back from the token tile (fp16, as the unfused path reads it):
+    // its fp32 registers are not held across the feed-forward loop.
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      cb2[j] = (float)p.b2[TAIL_COL(j)];
+      cb3[j] = (float)p.b3[TAIL_COL(j)];
+    }
+    float h3[MI][5][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int j = 0; j < 5; ++j)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) h3[mi][j][rr] = acc3[mi][j][rr] + cb2[j] + h1[mi][j][rr];
-    lds_barrier();  // (the last chunk's GEMM-1 reads of X are long done; this orders the X overwrite for every wave)
-    store_tile_and_stats(Xs, part, ms, h3, wave, lane, tid, p.ln_eps, false);
+        for (int rr = 0; rr < 4; ++rr) h3[mi][j][rr] = acc3[mi][j][rr] + cb2[j] + (float)Xs[TAIL_ROW(mi, rr) * XP + TAIL_COL(j)];
+    lds_barrier();  // every wave has its residual values (and is done with X as the scores' A operand)
+    store_tile_and_stats(Xs, part, ms, h3, arow0, wn, lane, tid, p.ln_eps, false);
     lds_barrier();
-    // ---- proj_out: out = h3 W3^T + b3 + x   (x requested here: its latency hides under the GEMM, and its 80 registers are
-    //      not held across the feed-forward)
-    half_t resx[4][5][4];
-    load_res(p.res_x, m0, p.M, wave, lane, resx);
+    // ---- proj_out: out = h3 W3^T + b3 + x   (x requested here: its latency hides under the GEMM)
+    half_t resx[MI][5][4];
+    load_res(p.res_x, m0, p.M, arow0, wn, lane, resx);
     zero_acc();
-    gemm320(Xs, p.w3, C / 32, 0, wave, lane, acc);
-    float ov[4][5][4];
+    gemm320(Xs, arow0, p.w3, C / 32, wn, lane, acc);
+    float ov[MI][5][4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int j = 0; j < 5; ++j)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) ov[mi][j][rr] = acc[mi][j][rr] + cb3[j] + (float)resx[mi][j][rr];
     lds_barrier();
-    store_tile_and_stats(Xs, part, ms, ov, wave, lane, tid, p.ln_eps, false);
+    store_tile_and_stats(Xs, part, ms, ov, arow0, wn, lane, tid, p.ln_eps, false);
     lds_barrier();
-    write_tile(Xs, p.out0, m0, p.M, tid);
+    write_tile<NTH>(Xs, p.out0, m0, p.M, tid);
   }
 }
 
@@ -382,7 +483,7 @@ extern "C" int vsd_tail_a(vsd_ctx* ctx, const void* att, const void* h, int m, c
   p.out0 = (half_t*)h1_out; p.out1 = (half_t*)q_out; p.ln_eps = ln_eps;
   hipStream_t s = (hipStream_t)stream;
   LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * m * 2.0 * C * C);
-  hipLaunchKernelGGL((tail_kernel<0>), dim3(cdiv(m, BM)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((tail_kernel<0, 2>), dim3(cdiv(m, BM)), dim3(512), 0, s, p);
   return ls.finish();
 }
 
@@ -402,6 +503,8 @@ extern "C" int vsd_tail_b(vsd_ctx* ctx, const void* att2, const void* h1, const 
   p.out0 = (half_t*)out; p.ln_eps = ln_eps;
   hipStream_t s = (hipStream_t)stream;
   LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * m * (2.0 * C * C + 3.0 * C * FF));
-  hipLaunchKernelGGL((tail_kernel<1>), dim3(cdiv(m, BM)), dim3(256), 0, s, p);
+  static const int wm_b = getenv("VSD_TAIL_WM") ? atoi(getenv("VSD_TAIL_WM")) : 1;  // (A/B switch: 2 = eight waves, measured equal)
+  if (wm_b == 2) hipLaunchKernelGGL((tail_kernel<1, 2>), dim3(cdiv(m, BM)), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((tail_kernel<1, 1>), dim3(cdiv(m, BM)), dim3(256), 0, s, p);
   return ls.finish();
 }

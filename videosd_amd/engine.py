@@ -377,7 +377,8 @@ class Engine:
         # ControlNet scales) that the captured graphs READ, so that `update_options` reaches every graph at once
         self.shared = {}
         self.absorb_cross_attention = True  # cross-attention of the wide blocks as two GEMMs (pack_cross_attention)
-        self.use_fused_tail = True          # 320-wide blocks: per-token chains in two launches (csrc/fused_tail.hip)
+        self.use_fused_tail = True          # 320-wide blocks: per-token chains as fused launches (csrc/fused_tail.hip)
+        self.tail_b_min_rows = 6144         # ... the feed-forward chain from this many tokens per launch on (see _transformer)
 
     def make_slot(self) -> "Engine":
         """A further frame in flight on the same GPU: shares the weights and the prompt / schedule constants of
@@ -558,17 +559,31 @@ class Engine:
                 else:
                     r.attention(qk, 2 * c, qk_full[:, c:], 2 * c, vt_full, ld2, att, c, hw, 2 * hw, heads, d, d ** -0.5)
             kt, vtt = net.kv_cache[bw.kv_index]
-            if (self.use_fused_tail and c == getattr(self.ops, "TAIL_C", 0) and len(tw.blocks) == 1 and ref is None and
-                    stat_out is None and out2 is None and not self.fuse_gn_stats and hasattr(self.ops, "tail_a")):
-                # the block's per-token chains as two launches around the cross-attention (csrc/fused_tail.hip): h1, q, h2, the
-                # GEGLU hidden state and h3 stay on chip, the token tile's owner streams only the weights
+            fused = (self.use_fused_tail and c == getattr(self.ops, "TAIL_C", 0) and len(tw.blocks) == 1 and ref is None and
+                     stat_out is None and out2 is None and not self.fuse_gn_stats and hasattr(self.ops, "tail_a"))
+            if fused:
+                # the block's per-token chains as fused launches around the cross-attention (csrc/fused_tail.hip): the token
+                # tile's owner streams only the weights; h1 / q (and in tail_b h2, the GEGLU hidden state, h3) stay on chip.
+                # Measured on MI355X (us, fused vs the launches it replaces): tail_a 14 vs 20 at 4096 tokens, 17 vs 31 at
+                # 12288; tail_b 71 vs 59 at 4096 (every workgroup streams all 2.9 MB of feed-forward weights whatever the
+                # token count), 80 vs 117 at 12288 -- so the feed-forward chain is fused from two frames per launch on.
                 h1 = a.alloc(rows, c)
                 q = a.alloc(rows, c)
                 r.tail_a(att, h, rows, bw.out1, bw.q2, h1, q)
                 r.attention(q, c, kt, c, vtt, vtt.shape[1], att, c, rows, kt.shape[0], heads, d, d ** -0.5)
-                out = a.alloc(rows, c)
-                r.tail_b(att, h1, x, rows, bw.out2, bw.ff1, bw.ff2, tw.proj_out, out)
-                return out
+                if rows >= self.tail_b_min_rows:
+                    out = a.alloc(rows, c)
+                    r.tail_b(att, h1, x, rows, bw.out2, bw.ff1, bw.ff2, tw.proj_out, out)
+                    return out
+                h2 = a.alloc(rows, c)
+                rs2 = stat()
+                r.conv(att, None, lin, bw.out2, h2, residual=h1, rowstat_out=rs2)
+                f = a.alloc(rows, 4 * c)
+                r.conv(h2, None, lin, bw.ff1, f, ln_part=rs2)
+                h3 = a.alloc(rows, c)
+                r.conv(f, None, lin, bw.ff2, h3, residual=h2)
+                h = h3
+                continue
             h1 = a.alloc(rows, c)
             rs1 = stat()
             r.conv(att, None, lin, bw.out1, h1, residual=h, rowstat_out=rs1)
