@@ -4,7 +4,7 @@ import collections, csv, json, sys
 
 trace, opsf = sys.argv[1], sys.argv[2]
 ops = json.load(open(opsf))
-ours = ("conv_gemm_kernel", "conv_halo_kernel", "splitk_reduce", "gn_stats", "gn_apply", "gn_fused", "layernorm_kernel", "attention_kernel",
+ours = ("conv_gemm_kernel", "conv_halo_kernel", "tail_kernel", "adain_kernel", "splitk_reduce", "gn_stats", "gn_apply", "gn_fused", "layernorm_kernel", "attention_kernel",
         "preprocess_rgb", "sobel_max", "sobel_apply", "add_noise", "lcm_step", "postprocess")
 rows = [r for r in csv.DictReader(open(trace)) if any(o in r["Kernel_Name"] for o in ours)]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -29,6 +29,9 @@ for m in ops:
     if m["op"] == "conv":
         key = ("conv", m["M"], m["N"], m["K"], m["ks"], m["tile"], m["split"])
         assert "conv_gemm" in ks[0]["Kernel_Name"] or "conv_halo" in ks[0]["Kernel_Name"], (m, ks[0]["Kernel_Name"][:60])
+    elif m["op"] in ("tail_a", "tail_b"):
+        key = (m["op"], m["M"])
+        assert "tail_kernel" in ks[0]["Kernel_Name"], (m, ks[0]["Kernel_Name"][:60])
     elif m["op"] == "groupnorm":
         key = ("gn", m["hw"], m["C"])
     elif m["op"] == "layernorm":
@@ -48,7 +51,7 @@ frame_ns = int(last[pos - 1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])
 print(f"frame span {frame_ns/1e6:.2f} ms, kernel busy {busy/1e6:.2f} ms, {total} kernels")
 fam = collections.Counter()
 for k, a in agg.items():
-    fam[k[0]] += a["ns"] + a["ns2"]
+    fam["conv" if k[0] in ("tail_a", "tail_b") else k[0]] += a["ns"] + a["ns2"]
 print({k: round(v / 1e6, 2) for k, v in fam.items()})
 print(f"{'op':48s} {'cnt':>4s} {'tot ms':>8s} {'avg us':>8s} {'2nd us':>7s} {'TF/s':>7s} {'wGB/s':>7s}")
 for k, a in sorted(agg.items(), key=lambda kv: -(kv[1]["ns"] + kv[1]["ns2"])):

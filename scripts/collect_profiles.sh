@@ -7,7 +7,7 @@ TAG=${1:-r1}
 mkdir -p gpurun_out
 # 1. the bench command under the kernel tracer
 rm -rf /tmp/prof_bench
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 bench.py --steps 30 --warmup 6 --no-cpu-baseline > gpurun_out/${TAG}_bench_under_rocprof.json 2>/tmp/err_bench.log
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-api > gpurun_out/${TAG}_bench_under_rocprof.json 2>/tmp/err_bench.log
 python3 scripts/shorten_stats.py /tmp/prof_bench/*/*_kernel_stats.csv gpurun_out/${TAG}_bench_kernel_stats.csv
 tail -c 600 gpurun_out/${TAG}_bench_under_rocprof.json; echo
 head -8 gpurun_out/${TAG}_bench_kernel_stats.csv | cut -c1-160

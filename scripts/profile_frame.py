@@ -45,6 +45,10 @@ for fn, a, k in eng.program.calls:
         split = min(split, kt); per = -(-kt // split); split = -(-kt // per)
         m.update(M=g.m, N=w.n, K=w.k, ks=g.ksize, stride=g.stride, resize=(g.hi != g.hs), tile=tile, split=split if not ink else -split,
                  flops=2.0 * g.m * w.n * w.k, wbytes=2 * w.n * w.kp, geglu=w.geglu)
+    elif name == "tail_a":
+        m.update(M=a[2], flops=2.0 * a[2] * 2 * 320 * 320, wbytes=2 * 2 * 320 * 320)
+    elif name == "tail_b":
+        m.update(M=a[3], flops=2.0 * a[3] * (2 * 320 * 320 + 3 * 320 * 1280), wbytes=2 * (2 * 320 * 320 + 3 * 320 * 1280))
     elif name == "groupnorm":
         m.update(C=a[2] + a[3], hw=a[4])
     elif name == "layernorm":
