@@ -116,3 +116,14 @@ class OrderCheckingPipeline(FakePipeline):
     def collect_batch(self, handle):
         self.live.pop(0)
         return super().collect_batch(handle)
+
+
+class WarmFakePipeline(FakePipeline):
+    """A stand-in that has `warm_up`, like VideoSDPipeline: records what it was warmed with."""
+
+    def warm_up(self, batches=(1,), lanes=1, **options):
+        self.warmed = {"batches": tuple(batches), "lanes": lanes, "options": sorted(options)}
+        return len(tuple(batches)) * lanes
+
+    def warm_state(self):
+        return getattr(self, "warmed", None)

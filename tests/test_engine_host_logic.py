@@ -167,6 +167,25 @@ def test_update_options_equals_a_fresh_prepare(mini):
     assert eng.update_options(0.03, 1.0) is False  # int(50 * 0.03) = 1 candidate timestep: a 1-step schedule, another program
 
 
+def test_a_slot_owns_its_staging_buffers_and_events(mini):
+    """Two launches in flight (a parent engine and its slot) must not share pinned host buffers or timing events: a slot
+    made AFTER the parent's first frame used to inherit them (found on the GPU: `elapsed_time` on an event the other
+    lane had re-recorded)."""
+    wu, wc, wv, text = mini
+    eng = Engine(FakeOps(), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
+    eng.set_text_embeds(text)
+    eng.prepare(64, 64, 2, 0.6, use_controlnet=True, use_graph=False)
+    a, b = _frame(64, 64, seed=1), _frame(64, 64, seed=2)
+    out_a = eng.infer_u8(a)                      # the parent's staging exists now
+    slot = eng.make_slot()
+    slot.prepare(64, 64, 2, 0.6, use_controlnet=True, use_graph=False)
+    eng.submit_u8(a)
+    slot.submit_u8(b)
+    assert slot._staging()[1] is not eng._staging()[1] and slot._staging()[2] is not eng._staging()[2]
+    assert np.array_equal(eng.collect_u8(), out_a)
+    assert not np.array_equal(slot.collect_u8(), out_a)
+
+
 @pytest.mark.parametrize("H,W,steps", [(64, 64, 2), (64, 64, 1)])
 def test_reference_only_mode_matches_oracle(mini, H, W, steps):
     """SURVEY 8f-4 (lcm_reference_pipeline.py:498-794, 855-890): per step a WRITE pass over the noised reference latents

@@ -323,3 +323,22 @@ def test_soak_two_launches_in_flight_full_size_bit_identical(batch):
     soak = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(soak)
     assert soak.run(n=60 if batch == 1 else 30, batch=batch, verbose=False) == 0
+
+
+def test_no_kernel_reads_uninitialised_memory():
+    """VSD_POISON=1 fills everything the engine allocates "uninitialised" with NaN bytes: the live program and the
+    reference-only program still match the oracle, at sizes whose token counts are ragged against the 64-key attention
+    tile at every level.  (Found this way: the reference-only WRITE pass read the masked tail of its last key tile from
+    the next V^T row, and 0 x NaN poisoned the banked statistics whenever the allocator handed out dirty memory.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, VSD_POISON="1")
+    res = subprocess.run([sys.executable, os.path.join(here, "poison_check.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    diffs = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert set(diffs) == {"live", "reference_only", "reference_only_64"}
+    assert all(v < 1.5 for v in diffs.values()), diffs

@@ -181,3 +181,28 @@ def test_changing_options_waits_for_the_launches_in_flight():
         assert [int(np.asarray(o)[1, 1, 0]) for o in outs] == [245 - k for k in range(8)]
     finally:
         p.close()
+
+
+def test_a_respawned_batching_worker_is_warmed_for_every_batch_size_and_lane():
+    """The replacement of a coalescing worker (batch=3) prepares all (batch size, lane) engines before it rejoins
+    (VideoSDPipeline.warm_up), so the stream never pays a `prepare` on a live frame."""
+    warm = FAKE.replace("FakePipeline", "WarmFakePipeline")
+    ps = [RemotePipeline(factory=warm, model="m", controlnet="c", device=0, crash_on=66, batch=3)]
+    try:
+        async def go():
+            d = FrameDispatcher(ps, respawn=True, depth=3, warm_options=dict(OPTS))
+            d.submit(_img(66), **OPTS)
+            assert isinstance((await asyncio.wait_for(d.next_result(), timeout=60))[1], WorkerDied)
+            for _ in range(400):
+                if d.healthy[0]:
+                    break
+                await asyncio.sleep(0.05)
+            assert d.healthy == [True] and d.respawns == 1
+            st = d.pipelines[0].method("warm_state")()
+            assert st["batches"] == (1, 2, 3) and st["lanes"] == 2 and "height" in st["options"]
+            return True
+
+        assert asyncio.run(go())
+    finally:
+        for p in ps:  # (the dispatcher put the replacement into this list)
+            p.close()

@@ -420,6 +420,7 @@ class RemotePipeline:
                           shm_slots=shm_slots, shm_slot_bytes=shm_slot_bytes, **config)
         self.group = group
         self.call_timeout = call_timeout
+        self.max_batch = int(batch)
         self.dead = False
         self.death: Optional[BaseException] = None
         self._start_timeout = start_timeout
@@ -435,6 +436,7 @@ class RemotePipeline:
         self._proc.start()
         child.close()
         self._lock = threading.Lock()
+        self._proc_lock = threading.Lock()
         self._next = 0
         self._pending: Dict[int, Any] = {}
         self._ready = False
@@ -521,11 +523,12 @@ class RemotePipeline:
             try:
                 rid, ok, payload = self._conn.recv()
             except (EOFError, OSError, ValueError):
-                try:
-                    self._proc.join(timeout=5)  # (so that `exitcode` / `is_alive` are settled when the callers wake up)
-                except Exception:
-                    pass
-                code = self._proc.exitcode
+                with self._proc_lock:  # (one thread at a time reaps: a concurrent waitpid leaves `exitcode` unset)
+                    try:
+                        self._proc.join(timeout=5)  # `exitcode` / `is_alive` are settled when the callers wake up
+                    except Exception:
+                        pass
+                    code = self._proc.exitcode
                 self._fail_all(WorkerDied(f"pipeline worker (pid {self._proc.pid}) died (exit code {code})"))
                 return
             with self._lock:
@@ -604,12 +607,13 @@ class RemotePipeline:
         return RemotePipeline(**kw)
 
     def _kill(self):
-        try:
-            if self._proc.is_alive():
-                self._proc.kill()  # exactly this PID
-                self._proc.join(timeout=5)
-        except Exception:
-            pass
+        with self._proc_lock:
+            try:
+                if self._proc.is_alive():
+                    self._proc.kill()  # exactly this PID
+                    self._proc.join(timeout=5)
+            except Exception:
+                pass
 
     def close(self):
         try:
@@ -790,8 +794,13 @@ class FrameDispatcher:
             if self.warm_options is not None:
                 from PIL import Image
 
-                w, h = self.warm_options.get("width", 640), self.warm_options.get("height", 360)
-                await new.infer.remote(Image.new("RGB", (w, h)), **self.warm_options)
+                b = int(getattr(new, "max_batch", 1) or 1)
+                try:  # every (batch size, lane) engine the stream will use
+                    await new.method("warm_up").remote(batches=tuple(range(1, b + 1)), lanes=2 if b > 1 else 1,
+                                                       **self.warm_options)
+                except RemoteCallError:  # a pipeline without `warm_up`: one frame through `infer`
+                    w, h = self.warm_options.get("width", 640), self.warm_options.get("height", 360)
+                    await new.infer.remote(Image.new("RGB", (w, h)), **self.warm_options)
             self.pipelines[gpu] = new
             self.healthy[gpu] = True
             self.respawns += 1

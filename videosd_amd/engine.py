@@ -391,6 +391,7 @@ class Engine:
         e._vt_pool = {}
         e.graph = None
         e.plan = None
+        e._stage = None  # own pinned staging buffers and events (a copy of the parent's would be SHARED with it)
         e.is_slot = True
         return e
 
@@ -547,7 +548,10 @@ class Engine:
                 # reference-only: K rows / V^T columns [0, hw) belong to the frame (read pass), [hw, 2 hw) to the reference
                 # (write pass); the read pass attends over all 2 hw keys (lcm_reference_pipeline.py:535-539)
                 if ref.mode == "write":
-                    ld2 = _ru(2 * hw, 64)
+                    # the write pass reads whole 64-key tiles from column hw on: the row must hold hw + ru(hw, 64) columns
+                    # so that its masked tail keys are this buffer's zero padding, not the next row's read-pass columns
+                    # (masked probabilities are 0, but 0 x a stale Inf/NaN is NaN in the PV product)
+                    ld2 = _ru(hw + _ru(hw, 64), 64)
                     ref.kv[bw.kv_index] = (a.alloc(2 * hw, 2 * c), self._vt_buffer(c, ld2))
                 qk_full, vt_full = ref.kv[bw.kv_index]
                 ld2 = vt_full.shape[1]

@@ -13,6 +13,10 @@ import torch
 from . import lib as L
 from .packing import PackedConv
 
+import os as _os
+
+POISON = bool(_os.environ.get("VSD_POISON"))
+
 
 @dataclass(frozen=True)
 class Geom:
@@ -142,7 +146,10 @@ class HipOps:
 
     def empty(self, *shape, dtype=torch.float16):
         with torch.cuda.stream(self.stream):
-            return torch.empty(*shape, dtype=dtype, device=self.device)
+            t = torch.empty(*shape, dtype=dtype, device=self.device)
+            if POISON:  # VSD_POISON=1 (tests): every "uninitialised" byte is 0xFF (fp16 / fp32 NaN), so that a kernel
+                t.view(torch.uint8).fill_(255)  # relying on what the allocator happened to hand out fails every time
+            return t
 
     def zeros(self, *shape, dtype=torch.float16):
         with torch.cuda.stream(self.stream):
@@ -174,6 +181,8 @@ class HipOps:
         if cur is None or cur.numel() < nbytes:
             with torch.cuda.stream(self.stream):
                 cur = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+                if POISON:
+                    cur.fill_(255)
             self._ws[key] = cur
         return cur
 
@@ -182,8 +191,12 @@ class HipOps:
         self.stream.synchronize()
 
     def upload(self, dst: torch.Tensor, src_cpu: torch.Tensor):
+        """H2D on the kernel stream.  Asynchronous only from PINNED memory (the caller keeps that buffer alive, e.g. the
+        engine's frame staging); from pageable memory the call returns when the bytes have left the source, so a
+        temporary may be passed (an async copy from a temporary that is freed right after read freed memory: seen as
+        a garbage reference image on the MI355X)."""
         with torch.cuda.stream(self.stream):
-            dst.copy_(src_cpu.view(dst.shape), non_blocking=True)
+            dst.copy_(src_cpu.view(dst.shape), non_blocking=src_cpu.is_pinned())
 
     def download(self, src: torch.Tensor) -> torch.Tensor:
         with torch.cuda.stream(self.stream):

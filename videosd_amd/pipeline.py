@@ -229,6 +229,21 @@ class VideoSDPipeline:
                                                     style_fidelity=style_fidelity, controlnet=controlnet, seed=seed,
                                                     controlnet_scale=controlnet_scale))
 
+    def warm_up(self, batches=(1,), lanes: int = 1, **options):
+        """Prepare every (batch size, lane) engine a stream with these `infer` options will use -- plan, captured graph
+        and one replay on black frames -- so that no frame of the stream pays for a `prepare` (tens of ms each, a
+        visible stall in a 30 ms/frame stream).  A server calls it once per worker at start-up or after a respawn
+        (`FrameDispatcher(warm_options=...)`); returns how many engines are ready."""
+        w, h = options.get("width", 640), options.get("height", 360)
+        black = Image.new("RGB", (w, h))
+        ready = 0
+        for b in batches:
+            handles = [self.submit_batch([black] * int(b), lane=l, **options) for l in range(max(1, int(lanes)))]
+            for hd in handles:
+                self.collect_batch(hd)
+            ready += len(handles)
+        return ready
+
     def submit_batch(self, imgs, lane: int = 0, prompt=["pixar, cg"], height=360, width=640, strength=0.4, steps=20,
                      guidance_scale=7.5, ref=False, style_fidelity=0.0, controlnet=False, seed=42, controlnet_scale=1):
         """First half of `infer_batch`: crop / resize, upload, enqueue -- returns a handle for `collect_batch` without
@@ -268,7 +283,7 @@ class VideoSDPipeline:
         eng = self._engine_for(plan_key, opts, len(imgs), lane)
         if use_ref and getattr(eng, "_ref_epoch", None) != self._ref_epoch:
             rf = np.asarray(center_crop_resize(self._ref_img.convert("RGB"), width, height), dtype=np.uint8)
-            eng.ops.upload(eng.ref_u8, torch.from_numpy(np.ascontiguousarray(rf)))
+            eng.ops.upload(eng.ref_u8, torch.from_numpy(np.array(rf, copy=True)))  # (PIL's buffer is read-only)
             eng._ref_epoch = self._ref_epoch
         np.random.seed(seed)  # kept for parity with videopipeline.py:112 (nothing downstream consumes it)
         t0 = time.perf_counter()
