@@ -101,7 +101,11 @@ typedef struct vsd_conv_desc {
                              3x3 stride-1 convs only (Cin % 64 == 0 per source, tile 128x128, 128x64, 256x128 or
                              256x64, plain epilogue): the (8+2)x(16+2) input patch of a 64-channel block is
                              staged in LDS once and serves all nine taps; 8 = 8-stage direct-to-LDS ring (64x64 tile, Cin %
-                             64 == 0, no resize): 112 KB in flight per workgroup for the weight-streaming layers */
+                             64 == 0, no resize): 112 KB in flight per workgroup for the weight-streaming layers;
+                             9 = weight-streaming form for the small-image levels (csrc/conv_skinny.hip): M <= 192 rows,
+                             ksize 1 or 3 with stride 1 and pad ksize/2, no resize, Cin % 128 == 0 per source and >= 256,
+                             n % 64 == 0, needs weight_frag, `tile` ignored, split_k must be Cin / 128 (the slabs are
+                             reduced by the second kernel, so no rowstat_out / chanstat_out / GEGLU / softmax / out_t) */
   void* rowstat_out;      /* optional fp32 [M][n/64][2]: per output row, (sum, sum of squares) of the fp16 outputs over
                              each 64-column group -- the LayerNorm statistics of the NEXT layer, for free */
   void* chanstat_out;     /* optional fp32 [n][2]: per output CHANNEL, (sum, sum of squares) of the fp16 outputs over all M
@@ -137,6 +141,9 @@ typedef struct vsd_conv_desc {
                              (scores_h = LN(x) (scale K_h Wq_h)^T, one 128-column group per head), the GEMM tile IS the score
                              block of one head and this epilogue turns it into probabilities: cross-attention over the 77
                              text tokens (Attention.forward of attn2 under lcm_controlnet.py:568) as two plain GEMMs. */
+  const void* weight_frag; /* pipeline 9 only: the same [n][k] weights fragment-major -- blocks [n/16][k/32] of 1 KB, each
+                             [k/8 mod 4][n mod 16][8 halfs] -- so that one wave load instruction fetches one contiguous KB
+                             straight into the B operand registers of v_mfma_f32_16x16x32_f16 (k % 32 == 0, kp == k) */
 } vsd_conv_desc;
 #define VSD_SPLITK_MAX_TILES 16384
 

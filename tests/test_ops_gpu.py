@@ -893,3 +893,81 @@ def test_conv_deep_ring_pipeline8(ops, split_k, inkernel):
     w2 = rnd(72, 128, 3, 3, seed=8, scale=(128 * 9) ** -0.5)
     got, ref = run_conv(ops, [x2], 5, 7, w2, None, ksize=3, tile=2, split_k=1, pipeline=8)
     check(got, ref, "deep ring short K")
+
+
+@pytest.mark.parametrize("B,h,w,cins,cout,ksize", [
+    (3, 8, 8, (1280,), 1280, 3),      # the 8x8 level at three frames per launch (M = 192, 12 row fragments)
+    (3, 8, 8, (1280, 1280), 640, 3),  # decoder: concat sources
+    (1, 8, 8, (256,), 64, 3),         # one frame (4 row fragments), the smallest K split
+    (2, 8, 8, (384,), 128, 3),        # two frames (8 row fragments), 3 slices
+    (1, 12, 12, (512,), 192, 3),      # 768 x 768 deepest level: 144 pixels, 14 x 14 padded patch
+    (3, 5, 7, (256,), 64, 3),         # ragged image, M = 105 (rows past M inside the last fragment)
+    (3, 8, 8, (1280,), 1280, 1),      # linear layer at the same level
+    (1, 4, 4, (640, 128), 320, 1),    # 16 rows, unequal concat sources
+])
+def test_conv_weight_streaming_pipeline9(ops, B, h, w, cins, cout, ksize):
+    """pipeline 9 (csrc/conv_skinny.hip): the small-image weight-streaming form -- every weight byte loaded once,
+    fragment-major, against all M rows; 128-channel slices reduced by the split-K reducer with the layer's epilogue --
+    against F.conv2d in fp32, and bit-identical to itself across launches."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    cin = sum(cins)
+    xs = [rnd(B, c, h, w, seed=1 + i) for i, c in enumerate(cins)]
+    wt = rnd(cout, cin, ksize, ksize, seed=5, scale=(cin * ksize * ksize) ** -0.5)
+    bias, rv = rnd(cout, seed=6, scale=0.1), rnd(cout, seed=7, scale=0.1)
+    pw = ops.to_device_pack(pack_conv(wt, bias))
+    g = Geom.conv(h, w, ksize=ksize, batch=B)
+    res = rnd(g.m, cout, seed=8)
+    srcs = [x.permute(0, 2, 3, 1).reshape(B * h * w, -1).contiguous().cuda() for x in xs]
+    out = torch.zeros(g.m, cout, dtype=torch.float16, device="cuda")
+    kw = dict(c0=cins[0], c1=cins[1] if len(cins) > 1 else 0, act=2, rowvec=rv.cuda(), residual=res.cuda(), pipeline=9)
+    ops.conv(srcs[0], srcs[1] if len(srcs) > 1 else None, g, pw, out, **kw)
+    ops.synchronize()
+    assert pw.weight_frag is not None
+    ref = F.conv2d(torch.cat([x.float() for x in xs], dim=1), wt.float(), bias.float(), padding=ksize // 2) + rv.float()[None, :, None, None]
+    ref = F.silu(ref).permute(0, 2, 3, 1).reshape(g.m, cout) + res.float()
+    check(out, ref, f"weight-streaming conv B={B} {h}x{w} {cins}->{cout} k={ksize}")
+    again = torch.zeros_like(out)
+    ops.conv(srcs[0], srcs[1] if len(srcs) > 1 else None, g, pw, again, **kw)
+    ops.synchronize()
+    assert torch.equal(out, again)
+    # same sums as the general kernel's split-K over the same number of slices would give up to fp32 association: compare
+    # with the tiled kernel at tolerance, not bitwise
+    base = torch.zeros_like(out)
+    ops.conv(srcs[0], srcs[1] if len(srcs) > 1 else None, g, pw, base, **dict(kw, pipeline=3, tile=2, split_k=1))
+    ops.synchronize()
+    assert float((out.float() - base.float()).abs().max()) <= 4e-3 * max(1.0, float(base.float().abs().max()))
+
+
+def test_conv_weight_streaming_rejects_what_it_cannot_do(ops):
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    # 16 x 16 x 3 frames: M = 768 > 192 -- a tuning-table entry for pipeline 9 must not be applied to such a call
+    x = rnd(3, 256, 16, 16, seed=1)
+    wt = rnd(64, 256, 3, 3, seed=2, scale=(256 * 9) ** -0.5)
+    pw = ops.to_device_pack(pack_conv(wt, None))
+    g = Geom.conv(16, 16, batch=3)
+    out = torch.zeros(g.m, 64, dtype=torch.float16, device="cuda")
+    ops.conv(x.permute(0, 2, 3, 1).reshape(-1, 256).contiguous().cuda(), None, g, pw, out, pipeline=9)  # falls back to the tiled form
+    ops.synchronize()
+    ref = F.conv2d(x.float(), wt.float(), None, padding=1).permute(0, 2, 3, 1).reshape(g.m, 64)
+    check(out, ref, "pipeline 9 fallback")
+    # asked for directly through the C-ABI with the wrong split: an error, not a wrong answer
+    import ctypes as C
+
+    from videosd_amd import lib as L
+
+    x2 = rnd(1, 256, 8, 8, seed=3).permute(0, 2, 3, 1).reshape(64, 256).contiguous().cuda()
+    out2 = torch.zeros(64, 64, dtype=torch.float16, device="cuda")
+    ops.conv(x2, None, Geom.conv(8, 8), pw, out2, pipeline=9)
+    ops.synchronize()
+    d = L.ConvDesc()
+    d.src0, d.c0, d.hs, d.ws, d.hi, d.wi, d.ho, d.wo = x2.data_ptr(), 256, 8, 8, 8, 8, 8, 8
+    d.ksize, d.stride, d.pad, d.weight, d.n, d.k, d.kp = 3, 1, 1, pw.weight.data_ptr(), 64, 2304, 2304
+    d.out, d.ldo, d.ldr, d.out_scale, d.tile, d.split_k, d.pipeline = out2.data_ptr(), 64, 64, 1.0, 2, 3, 9
+    d.weight_frag = pw.weight_frag.data_ptr()
+    d.workspace = torch.zeros(3 * 64 * 64, device="cuda").data_ptr()
+    assert ops.ctx.lib.vsd_conv_gemm(ops.ctx.h, C.byref(d), ops.s) != 0
+    assert b"split_k must be Cin / 128" in ops.ctx.lib.vsd_last_error(ops.ctx.h)

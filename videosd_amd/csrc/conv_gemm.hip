@@ -72,8 +72,9 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.ln_s = (const float*)d->ln_s;
   p.ln_t = (const float*)d->ln_t;
   const int stages = d->pipeline;
-  if (stages != 0 && (stages < 3 || stages > 8)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..8)", stages);
+  if (stages != 0 && (stages < 3 || stages > 9)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..9)", stages);
   const bool halo = stages == 7;
+  const bool skinny = stages == 9;
 
   if (!p.src0 || !p.w || !p.out) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: null src/weight/out");
   if (p.M <= 0 || p.N <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: empty problem M=%d N=%d", p.M, p.N);
@@ -96,6 +97,34 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   if (p.ln_part && (p.ksize != 1 || !p.ln_s || !p.ln_t || p.ln_groups <= 0 || p.bias))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: fused LayerNorm needs a 1x1 layer, ln_s/ln_t and no separate bias");
   if (p.split_k > 1 && !p.ws_partial) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: split_k needs a workspace");
+  if (skinny) {
+    // weight-streaming form (conv_skinny.hip): one workgroup = 64 output channels x all M rows x 128 input channels
+    const int padded = p.batch * (p.hs + 2 * (p.ksize / 2)) * (p.ws + 2 * (p.ksize / 2));
+    const int act = p.act & 0xff;
+    if (!d->weight_frag || p.M > 192 || padded > vsd_conv_skinny_max_pixels() || p.stride != 1 || p.pad != p.ksize / 2 || p.resize ||
+        p.ho != p.hs || p.wo != p.ws || p.c0 % 128 || p.c1 % 128 || p.cin < 256 || p.N % 64 || p.Kp != p.K || p.rowstat_out || p.chanstat_out ||
+        p.out_t || act == VSD_ACT_GEGLU || act == VSD_ACT_SOFTMAX || (size_t)p.N * p.K * 2 >= 0x7fffffffull)
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the weight-streaming form (pipeline 9) needs weight_frag, M <= 192, a stride-1 same-size "
+                      "1x1 / 3x3 layer, Cin %% 128 == 0 per source (>= 256), N %% 64 == 0 and an epilogue the split-K reducer can apply");
+    if (p.split_k != p.cin / 128 || !p.ws_partial)
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline 9 splits over 128-channel slices: split_k must be Cin / 128 = %d (with a workspace)", p.cin / 128);
+    p.counters = nullptr;
+    p.tiles_m = 1;
+    p.tiles_n = p.N / 64;
+    p.kt_per_split = 0;
+    p.order = 0;
+    {
+      LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
+      vsd_launch_conv_skinny(p, (const half_t*)d->weight_frag, p.tiles_n * p.split_k, s);
+      int rc = ls.finish();
+      if (rc) return rc;
+    }
+    LaunchScope ls(ctx, s, VSD_FAM_SPLITK_REDUCE, 0.0);
+    size_t total = (size_t)p.M * ((p.N + 7) / 8);
+    int g = (int)((total + 255) / 256);
+    vsd_launch_splitk_reduce(p, g > 2048 ? 2048 : g, s);
+    return ls.finish();
+  }
   int BM, BN;
   switch (d->tile) {
     case VSD_TILE_128x128: BM = 128; BN = 128; break;

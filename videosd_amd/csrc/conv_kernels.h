@@ -105,6 +105,8 @@ void vsd_launch_conv_64x128(const ConvParams& p, int grid, int stages, hipStream
 void vsd_launch_conv_256x128(const ConvParams& p, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_halo(const ConvParams& p, int bm, int bn, int grid, hipStream_t s);
 void vsd_launch_splitk_reduce(const ConvParams& p, int grid, hipStream_t s);
+void vsd_launch_conv_skinny(const ConvParams& p, const half_t* wfrag, int grid, hipStream_t s);  // conv_skinny.hip (pipeline 9)
+int vsd_conv_skinny_max_pixels();
 
 namespace {
 

@@ -42,6 +42,7 @@ class ConvDesc(C.Structure):
         ("batch", C.c_int32), ("t_img", C.c_int32),
         ("out_scale_dev", C.c_void_p),
         ("softmax_cols", C.c_int32),
+        ("weight_frag", C.c_void_p),
     ]
 
 

@@ -231,6 +231,16 @@ class HipOps:
         split_k = split_k or 1
         if w.tile128:
             inkernel = True  # (the tile softmax runs in the reducing workgroup's epilogue)
+        if pipeline == 9 and not self._skinny_call_ok(g, w, c0, c1, act, out_t, rowstat_out, chanstat_out):
+            # a tuning-table entry found for another call of the same shape key
+            pipeline, tile, split_k, inkernel = 3, L.TILE_64x64, min(8, max(1, w.kp // 128)), True
+        if pipeline == 9:
+            split_k, inkernel = w.cin // 128, False
+            if w.weight_frag is None:  # (first use: a second, fragment-major copy of this layer's weights)
+                from .packing import pack_mfma_frag
+
+                with torch.cuda.stream(self.stream):
+                    w.weight_frag = pack_mfma_frag(w.weight[:, :w.k])
         if pipeline == 7 and (self.no_halo or out_scale_dev is not None or
                               not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out,
                                                      chanstat_out, ln_part)):
@@ -244,6 +254,7 @@ class HipOps:
         d.hs, d.ws, d.hi, d.wi, d.ho, d.wo = g.hs, g.ws, g.hi, g.wi, g.ho, g.wo
         d.ksize, d.stride, d.pad = g.ksize, g.stride, g.pad
         d.weight = self._p(w.weight)
+        d.weight_frag = self._p(w.weight_frag) if pipeline == 9 else None
         d.n, d.k, d.kp = w.n, w.k, w.kp
         d.bias = self._p(w.bias)
         if ln_part is not None:
@@ -276,6 +287,17 @@ class HipOps:
             if inkernel:
                 d.counters = self._p(self._counters[self._sidx])
         self.ctx.call("vsd_conv_gemm", C.byref(d), self.s)
+
+    SKINNY_MAX_PIXELS = 320  # csrc/conv_skinny.hip SK_MAX_PIX: padded pixels of all images its LDS panel holds
+
+    @classmethod
+    def _skinny_call_ok(cls, g, w, c0, c1, act, out_t, rowstat_out, chanstat_out) -> bool:
+        """What vsd_conv_gemm's weight-streaming form (pipeline 9) accepts."""
+        padded = g.batch * (g.hs + 2 * (g.ksize // 2)) * (g.ws + 2 * (g.ksize // 2))
+        return (g.m <= 192 and padded <= cls.SKINNY_MAX_PIXELS and g.ksize in (1, 3) and g.stride == 1 and g.pad == g.ksize // 2 and
+                (g.hi, g.wi) == (g.hs, g.ws) and (g.ho, g.wo) == (g.hs, g.ws) and c0 % 128 == 0 and (c1 or 0) % 128 == 0 and
+                w.cin >= 256 and w.n % 64 == 0 and w.kp == w.k and not w.geglu and not w.tile128 and out_t is None and
+                rowstat_out is None and chanstat_out is None and (act & 0xff) not in (L.ACT_GEGLU, L.ACT_SOFTMAX))
 
     @staticmethod
     def _halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part) -> bool:
@@ -341,6 +363,13 @@ class HipOps:
                     if sp > w.cin // 64 or (sp > 1 and hblocks * sp > 1536):
                         break
                     cands.append((t, sp, False, 7))
+        c1_ = kwargs.get("c1", 0) or 0
+        c0_ = kwargs.get("c0") if kwargs.get("c0") is not None else w.cin - c1_
+        if _os.environ.get("VSD_TUNE_STREAMING") and self._skinny_call_ok(g, w, c0_, c1_, act, kwargs.get("out_t"), kwargs.get("rowstat_out"),
+                                                                          kwargs.get("chanstat_out")):
+            # weight-streaming form (tile ignored, split = Cin / 128).  Opt-in: measured at parity with the tiled forms on
+            # the 3x3 layers and slower on the linear ones, and it cannot share a CU with another launch (conv_skinny.hip)
+            cands.append((L.TILE_64x64, w.cin // 128, False, 9))
         kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline")}
         table = []
         saved = self.tile_override.pop(key, None)
