@@ -46,7 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--slots", type=int, default=2, help="launches in flight per GPU (independent frames, one graph each)")
-    ap.add_argument("--batch", type=int, default=3, help="frames per launch (stacked along the GEMM M dimension); "
+    ap.add_argument("--batch", type=int, default=5, help="frames per launch (stacked along the GEMM M dimension); "
                     "--batch 1 --slots 3 is the one-frame-per-launch configuration of the first bench lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the leg through VideoSDPipeline.remote(...).infer.remote")
@@ -155,7 +155,7 @@ def image_parity(got, ref):
                        "tolerance: mad <= 1.5 LSB, PSNR >= 38 dB"}
 
 
-def api_leg(frames_host, n_frames=96):
+def api_leg(frames_host, n_frames=None, batch=5):
     """The drop-in class end to end: PIL in -> worker process -> PIL out through `VideoSDPipeline.remote(...)`
     (what diffusert/server.py:108 awaits), one frame at a time and as a stream the worker may coalesce."""
     import asyncio
@@ -167,17 +167,18 @@ def api_leg(frames_host, n_frames=96):
     opts = dict(prompt="pixar, cg", height=H, width=W, strength=STRENGTH, steps=LCM_STEPS, controlnet_scale=1.0, seed=23)
     imgs = [Image.fromarray(f, "RGB") for f in frames_host]
     w = VideoSDPipeline.remote(model="SimianLuo/LCM_Dreamshaper_v7", controlnet="lllyasviel/control_v11p_sd15_canny",
-                               device=0, batch=3, call_timeout=600.0)
+                               device=0, batch=batch, call_timeout=600.0, max_plans=2 * batch + 2)
+    n_frames = n_frames or 32 * batch
     try:
         # plans + graphs of every (batch size, lane) the stream will use: what a server does once at start-up
-        w.method("warm_up")(batches=(1, 2, 3), lanes=2, **opts)
+        w.method("warm_up")(batches=tuple(range(1, batch + 1)), lanes=2, **opts)
         lat = []
         for i in range(16):
             t0 = time.perf_counter()
             w.infer(imgs[i % len(imgs)], **opts)
             lat.append((time.perf_counter() - t0) * 1e3)
 
-        async def stream(depth=int(os.environ.get("VSD_API_DEPTH", "9"))):
+        async def stream(depth=int(os.environ.get("VSD_API_DEPTH", str(3 * batch)))):
             sem = asyncio.Semaphore(depth)
             done = 0
 
@@ -198,7 +199,7 @@ def api_leg(frames_host, n_frames=96):
                 "api_stage_ms_p50": m.get("pipeline", {}).get("stage_ms_p50"),
                 "api_frames_per_launch": m.get("frames_per_launch"),
                 "api_note": "PIL 512x512 in -> VideoSDPipeline.remote worker process (shared-memory frame slots) -> PIL out; "
-                            "api_fps: 9 frames outstanding (two launches of 3 on the GPU, one filling), the worker coalesces up to 3 per launch"}
+                            f"api_fps: {3 * batch} frames outstanding (two launches of {batch} on the GPU, one filling), the worker coalesces up to {batch} per launch"}
     finally:
         w.close()
 
@@ -375,28 +376,35 @@ def run_rank(args):
             got0 = o
     p50 = statistics.median(lat)
 
-    # ---- one frame per launch, three launches in flight (the configuration of round 1's first bench lines)
+    # ---- other frames-per-launch operating points of the same engine: 1 (x3 in flight: round 1's first bench lines),
+    #      3 (x2: round 1's final / round 2's earlier headline) and 8 (x2): throughput against frames in flight
     fps_b1 = None
+    fps_by_b = {}
     if extras:
         eng.overlap_controlnet = False
-        pool1 = [eng]
-        eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
-        for e in engines[1:]:
-            e.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
-            pool1.append(e)
-        while len(pool1) < 3:
-            sl = eng.make_slot()
-            sl.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
-            pool1.append(sl)
-        for i in range(6):
-            one_frame(i, pool1)
-        sync_all(pool1)
-        t1 = time.perf_counter()
-        nn = max(12, args.steps // 2)
-        for i in range(nn):
-            one_frame(i, pool1)
-        sync_all(pool1)
-        fps_b1 = nn / (time.perf_counter() - t1)
+
+        def throughput_at(b, nslots):
+            pool = [eng] + list(engines[1:nslots])
+            while len(pool) < nslots:
+                pool.append(eng.make_slot())
+            for e in pool:
+                e.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=b)
+            for i in range(2 * nslots):
+                one_frame(i, pool)
+            sync_all(pool)
+            t1 = time.perf_counter()
+            nn = max(4 * nslots, args.steps // (2 * b))
+            for i in range(nn):
+                one_frame(i, pool)
+            sync_all(pool)
+            return nn * b / (time.perf_counter() - t1)
+
+        fps_b1 = throughput_at(1, 3)
+        fps_by_b = {"1x3": round(fps_b1, 2)}
+        for b in (3, 8):
+            if b != B:
+                fps_by_b[f"{b}x2"] = round(throughput_at(b, 2), 2)
+        fps_by_b[f"{B}x{len(engines)}"] = round(fps, 2)
 
     # ---- the same graph without the ControlNet tower (engine extension)
     eng.overlap_controlnet = args.slots < 3
@@ -459,6 +467,7 @@ def run_rank(args):
         "p50_latency_ms": round(p50, 3),
         "p50_latency_ms_under_load": round(statistics.median(lat_loaded), 3) if lat_loaded else None,
         "fps_one_frame_per_launch": round(fps_b1, 3) if fps_b1 else None,
+        "fps_by_frames_per_launch_x_launches_in_flight": fps_by_b or None,
         "fps_end_to_end": round(fps_e2e, 3) if fps_e2e else None,
         "fps_without_controlnet": round(fps_nocn, 3),
         "prepare_ms": round(prepare_ms, 1), "update_options_ms": round(update_options_ms, 2),
@@ -468,7 +477,7 @@ def run_rank(args):
     if extras and not args.no_api:
         # drop the bench's own engines first: the API worker is a second process with its own weight replica
         try:
-            out.update(api_leg(frames_host))
+            out.update(api_leg(frames_host, batch=B))
         except Exception as e:  # reporting only; never lose the measured line
             out["api_fps"] = None
             out["api_note"] = f"failed: {type(e).__name__}: {e}"
