@@ -284,7 +284,7 @@ def run_rank(args):
         engines.append(sl)
 
     # this rank's shard of the synthetic stream, resident in HBM before the timed region
-    nres = 12
+    nres = max(12, B)
     frames_host = synthetic_frames(nres * world, H, W)[rank::world]
     frames_dev = ops.to_device(torch.from_numpy(frames_host))
 

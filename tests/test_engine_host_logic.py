@@ -274,3 +274,20 @@ def test_fused_tail_wiring(mini, monkeypatch):
     assert np.abs(outs[0].astype(int) - outs[2].astype(int)).mean() < 0.3
     assert counts[1] < counts[0]
     assert np.abs(outs[0].astype(int) - outs[1].astype(int)).mean() < 0.3
+
+
+def test_arena_gives_oversized_tensors_their_own_chunk_and_rewinds_to_the_same_addresses():
+    """Many frames per launch (or large frames) need buffers beyond the arena's usual chunk size: they get a chunk of their
+    own instead of an error, and mark / rewind still hands out identical addresses on every denoising step."""
+    from videosd_amd.engine import Arena
+
+    a = Arena(FakeOps(), chunk_bytes=1 << 16)
+    small = a.alloc(16, 64)
+    m = a.mark()
+    first = [a.alloc(64, 1024), a.alloc(8, 8), a.alloc(300, 512), a.alloc(16, 16)]  # 128 KB and 300 KB: both over 64 KB
+    peak = a.peak
+    a.rewind(m)
+    again = [a.alloc(64, 1024), a.alloc(8, 8), a.alloc(300, 512), a.alloc(16, 16)]
+    assert [t.data_ptr() for t in first] == [t.data_ptr() for t in again] and a.peak == peak
+    ptrs = sorted((t.data_ptr(), t.numel() * t.element_size()) for t in first + [small])
+    assert all(p0 + n0 <= p1 for (p0, n0), (p1, _) in zip(ptrs, ptrs[1:]))  # nothing overlaps

@@ -48,17 +48,17 @@ class Arena:
     def alloc(self, rows: int, cols: int, dtype=torch.float16) -> torch.Tensor:
         esz = torch.empty(0, dtype=dtype).element_size()
         nbytes = _ru(rows * cols * esz, 256)
-        if nbytes > self.chunk_bytes:
-            raise RuntimeError(f"arena: tensor of {nbytes} bytes exceeds chunk size")
-        if self.ci < len(self.chunks) and self.off + nbytes > self.chunk_bytes:
+        while True:
+            if self.ci >= len(self.chunks):  # (a tensor larger than the usual chunk gets a chunk of its own size)
+                self.chunks.append(self.ops.empty(max(self.chunk_bytes, nbytes), dtype=torch.uint8))
+                self.off = 0
+            if self.off + nbytes <= self.chunks[self.ci].numel():
+                break
             self.ci += 1
-            self.off = 0
-        if self.ci >= len(self.chunks):
-            self.chunks.append(self.ops.empty(self.chunk_bytes, dtype=torch.uint8))
             self.off = 0
         t = self.chunks[self.ci][self.off:self.off + rows * cols * esz].view(dtype).view(rows, cols)
         self.off += nbytes
-        self.peak = max(self.peak, self.ci * self.chunk_bytes + self.off)
+        self.peak = max(self.peak, sum(c.numel() for c in self.chunks[:self.ci]) + self.off)
         return t
 
     def mark(self) -> Tuple[int, int]:
