@@ -521,11 +521,12 @@ def _tail_weights(c=320, seed=0):
     return w, {k: add_frag(v) for k, v in packs.items()}
 
 
-@pytest.mark.parametrize("m", [12288, 4096, 200, 64])
+@pytest.mark.parametrize("m", [12288, 4096, 200, 64, 20480, 17000])
 def test_fused_transformer_tail_matches_the_unfused_chain(ops, m):
     """csrc/fused_tail.hip against explicit fp32 torch: tail_a = out-projection + residual, LayerNorm, query projection;
     tail_b = out-projection + residual, LayerNorm, GEGLU feed-forward + residual, proj_out + residual.  m = 200 has a ragged
-    last 64-token tile."""
+    last 64-token tile; 20480 (five frames of 64x64 tokens) and 17000 run tail_b on 80-token tiles (one round of <= 256
+    workgroups instead of two), 17000 with a ragged last one."""
     c = 320
     w, packs = _tail_weights(c)
     pk = {k: ops.to_device_pack(v) for k, v in packs.items()}

@@ -28,7 +28,7 @@
 namespace {
 
 constexpr int C = 320;        // channel width this kernel is built for
-constexpr int BM = 64;        // tokens per workgroup
+constexpr int BM0 = 64;       // tokens per workgroup (tail_b also exists with 80: see vsd_tail_b)
 constexpr int XP = 328;       // LDS pitch of the token tile (halfs)
 constexpr int HP = 72;        // LDS pitch of the 64-wide GEGLU chunk (halfs)
 constexpr int FF = 4 * C;     // GEGLU hidden width (1280)
@@ -168,7 +168,7 @@ __device__ __forceinline__ void load_res(const half_t* g, int m0, int M, int aro
 }
 
 // fp16 tile X <- v (rounded), and the per-row (mean, rstd) of the ROUNDED values -> ms[row][2]
-template <int MI>
+template <int BM, int MI>
 __device__ __forceinline__ void store_tile_and_stats(half_t* X, float* part, float* ms, float (&v)[MI][5][4], int arow0, int wn, int lane,
                                                      int tid, float eps, bool want_stats) {
   float s[MI][4], q2[MI][4];
@@ -218,7 +218,7 @@ __device__ __forceinline__ void store_tile_and_stats(half_t* X, float* part, flo
 }
 
 // rows of the LDS tile -> global, 16 bytes per lane
-template <int NTH>
+template <int NTH, int BM>
 __device__ __forceinline__ void write_tile(const half_t* X, half_t* g, int m0, int M, int tid) {
   for (int q = tid; q < BM * (C / 8); q += NTH) {
     const int r = q / (C / 8), c8 = (q - r * (C / 8)) * 8;
@@ -226,13 +226,14 @@ __device__ __forceinline__ void write_tile(const half_t* X, half_t* g, int m0, i
   }
 }
 
-template <int NTH>
+template <int NTH, int BM>
 __device__ __forceinline__ void load_a_tile(const half_t* g, half_t* X, int m0, int M, int tid) {
-  constexpr int NV = BM * (C / 8) / NTH;
+  constexpr int TOTAL = BM * (C / 8), NV = (TOTAL + NTH - 1) / NTH;
   half8 v[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int q = tid + i * NTH;
+    int q = tid + i * NTH;
+    q = q < TOTAL ? q : TOTAL - 1;  // (a ragged last pass re-reads the last piece; it is not stored)
     const int r = q / (C / 8), c8 = (q - r * (C / 8)) * 8;
     int m = m0 + r;
     m = m < M ? m : M - 1;
@@ -242,13 +243,14 @@ __device__ __forceinline__ void load_a_tile(const half_t* g, half_t* X, int m0, 
   for (int i = 0; i < NV; ++i) {
     const int q = tid + i * NTH;
     const int r = q / (C / 8), c8 = (q - r * (C / 8)) * 8;
-    *reinterpret_cast<half8*>(X + r * XP + c8) = v[i];
+    if (TOTAL % NTH == 0 || q < TOTAL) *reinterpret_cast<half8*>(X + r * XP + c8) = v[i];
   }
 }
 
-template <int KIND, int WM>
+template <int KIND, int WM, int BM = BM0>
 __global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
-  constexpr int MI = 4 / WM, NTH = 256 * WM;
+  constexpr int MI = BM / 16 / WM, NTH = 256 * WM;
+  static_assert(MI * 16 * WM == BM, "rows per workgroup = 16 x row fragments per wave x row groups");
   __shared__ __attribute__((aligned(16))) half_t Xs[BM * XP];
   __shared__ __attribute__((aligned(16))) half_t Hs[2 * BM * HP];
   __shared__ float part[BM * 4 * 2];
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
   // ---- everything the chain needs from HBM besides the weights is requested up front
   half_t res0[MI][5][4];
   load_res(p.res0, m0, p.M, arow0, wn, lane, res0);
-  load_a_tile<NTH>(p.a_in, Xs, m0, p.M, tid);
+  load_a_tile<NTH, BM>(p.a_in, Xs, m0, p.M, tid);
   float cb0[5], cb2[5], cb3[5], cs1[5], ct1[5];
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
@@ -291,12 +293,12 @@ __global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) h1[mi][j][rr] = acc[mi][j][rr] + cb0[j] + (float)res0[mi][j][rr];
   lds_barrier();  // every wave has read the last A fragments of the input tile: X may be overwritten
-  store_tile_and_stats(Xs, part, ms, h1, arow0, wn, lane, tid, p.ln_eps, true);
+  store_tile_and_stats<BM>(Xs, part, ms, h1, arow0, wn, lane, tid, p.ln_eps, true);
   lds_barrier();  // X (= h1 rounded to fp16) and the row statistics are published
 
   if constexpr (KIND == 0) {
     // ---- tail_a: q = LN(h1) W1'^T  (folded LayerNorm), h1 and q to HBM
-    write_tile<NTH>(Xs, p.out0, m0, p.M, tid);
+    write_tile<NTH, BM>(Xs, p.out0, m0, p.M, tid);
     zero_acc();
     gemm320(Xs, arow0, p.w1, C / 32, wn, lane, acc);
     float qv[MI][5][4];
@@ -309,9 +311,9 @@ __global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
         for (int j = 0; j < 5; ++j) qv[mi][j][rr] = rstd * (acc[mi][j][rr] - mean * cs1[j]) + ct1[j];
       }
     lds_barrier();
-    store_tile_and_stats(Xs, part, ms, qv, arow0, wn, lane, tid, p.ln_eps, false);
+    store_tile_and_stats<BM>(Xs, part, ms, qv, arow0, wn, lane, tid, p.ln_eps, false);
     lds_barrier();
-    write_tile<NTH>(Xs, p.out1, m0, p.M, tid);
+    write_tile<NTH, BM>(Xs, p.out1, m0, p.M, tid);
     return;
   } else {
     // ---- tail_b: GEGLU feed-forward on LN(h2) (h2 = the tile just stored).
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
     };
     // The GEGLU output is double buffered in LDS, so ONE barrier per chunk (Hc complete) is enough: a wave writing buffer
     // c & 1 is past the barrier of chunk c-1, which every wave reaches only after its reads of that buffer in chunk c-2.
-    if constexpr (WM == 1) {
+    if constexpr (WM == 1 && BM == BM0) {
       // one wave per SIMD: software pipeline -- the scores of chunk c+1 (MFMA) sit in the same basic block as the GEGLU of
       // chunk c (VALU, transcendental) so that the two pipes overlap inside the wave
       zero_sh(sh);
@@ -418,6 +420,7 @@ __global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
       }
     } else {
       // two waves per SIMD: the partner wave fills the other pipe; the plain order keeps the register count at 256
+      // (also the taller tiles: their accumulators leave no room for the second score set)
       for (int c = 0; c < NCHUNK; ++c) {
         const int c1 = chunk_of(c + 1);
         zero_sh(sh);
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) h3[mi][j][rr] = acc3[mi][j][rr] + cb2[j] + (float)Xs[TAIL_ROW(mi, rr) * XP + TAIL_COL(j)];
     lds_barrier();  // every wave has its residual values (and is done with X as the scores' A operand)
-    store_tile_and_stats(Xs, part, ms, h3, arow0, wn, lane, tid, p.ln_eps, false);
+    store_tile_and_stats<BM>(Xs, part, ms, h3, arow0, wn, lane, tid, p.ln_eps, false);
     lds_barrier();
     // ---- proj_out: out = h3 W3^T + b3 + x   (x requested here: its latency hides under the GEMM)
     half_t resx[MI][5][4];
@@ -461,9 +464,9 @@ __global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) ov[mi][j][rr] = acc[mi][j][rr] + cb3[j] + (float)resx[mi][j][rr];
     lds_barrier();
-    store_tile_and_stats(Xs, part, ms, ov, arow0, wn, lane, tid, p.ln_eps, false);
+    store_tile_and_stats<BM>(Xs, part, ms, ov, arow0, wn, lane, tid, p.ln_eps, false);
     lds_barrier();
-    write_tile<NTH>(Xs, p.out0, m0, p.M, tid);
+    write_tile<NTH, BM>(Xs, p.out0, m0, p.M, tid);
   }
 }
 
@@ -483,7 +486,12 @@ extern "C" int vsd_tail_a(vsd_ctx* ctx, const void* att, const void* h, int m, c
   p.out0 = (half_t*)h1_out; p.out1 = (half_t*)q_out; p.ln_eps = ln_eps;
   hipStream_t s = (hipStream_t)stream;
   LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * m * 2.0 * C * C);
-  hipLaunchKernelGGL((tail_kernel<0, 2>), dim3(cdiv(m, BM)), dim3(512), 0, s, p);
+  // (one 512-thread workgroup per CU: rounds of 256, as for tail_b below -- 20480 tokens run as 256 tiles of 80 rows on
+  //  four waves instead of 320 tiles of 64 on eight)
+  static const int bm_force = getenv("VSD_TAIL_BM") ? atoi(getenv("VSD_TAIL_BM")) : 0;
+  const bool tall = bm_force ? bm_force == 80 : (long)cdiv(cdiv(m, 80), 256) * 80 < (long)cdiv(cdiv(m, 64), 256) * 64;
+  if (tall) hipLaunchKernelGGL((tail_kernel<0, 1, 80>), dim3(cdiv(m, 80)), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((tail_kernel<0, 2>), dim3(cdiv(m, BM0)), dim3(512), 0, s, p);
   return ls.finish();
 }
 
@@ -504,7 +512,21 @@ extern "C" int vsd_tail_b(vsd_ctx* ctx, const void* att2, const void* h1, const 
   hipStream_t s = (hipStream_t)stream;
   LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * m * (2.0 * C * C + 3.0 * C * FF));
   static const int wm_b = getenv("VSD_TAIL_WM") ? atoi(getenv("VSD_TAIL_WM")) : 1;  // (A/B switch: 2 = eight waves, measured equal)
-  if (wm_b == 2) hipLaunchKernelGGL((tail_kernel<1, 2>), dim3(cdiv(m, BM)), dim3(512), 0, s, p);
-  else hipLaunchKernelGGL((tail_kernel<1, 1>), dim3(cdiv(m, BM)), dim3(256), 0, s, p);
+  // One workgroup per CU (330+ registers per lane): the launch runs in rounds of 256 workgroups, so 20480 tokens as 320
+  // tiles of 64 cost two rounds (measured 151 us against 77 us for 12288 tokens).  Taller tiles cost rows / 64 per round:
+  // pick the height with the least rounds x height (5 frames of 64x64 tokens: 256 tiles of 80 rows, one round).
+  static const int bm_force = getenv("VSD_TAIL_BM") ? atoi(getenv("VSD_TAIL_BM")) : 0;
+  int bm = 64;
+  {
+    long best = (long)cdiv(cdiv(m, 64), 256) * 64;
+    for (int cand : {80}) {  // (96 rows: 34 spilled registers)
+      const long cost = (long)cdiv(cdiv(m, cand), 256) * cand;
+      if (cost < best) { best = cost; bm = cand; }
+    }
+    if (bm_force == 64 || bm_force == 80) bm = bm_force;
+  }
+  if (wm_b == 2) hipLaunchKernelGGL((tail_kernel<1, 2>), dim3(cdiv(m, BM0)), dim3(512), 0, s, p);
+  else if (bm == 80) hipLaunchKernelGGL((tail_kernel<1, 1, 80>), dim3(cdiv(m, 80)), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((tail_kernel<1, 1>), dim3(cdiv(m, BM0)), dim3(256), 0, s, p);
   return ls.finish();
 }

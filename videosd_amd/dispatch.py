@@ -223,6 +223,8 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=to)
             else:
                 dist.init_process_group(group["backend"], rank=rank, world_size=world, timeout=to)
+        if max_batch > 3:  # two lanes x every batch size up to max_batch must stay cached (VideoSDPipeline evicts beyond max_plans)
+            config = dict(config, max_plans=max(int(config.get("max_plans", 8)), 2 * max_batch + 2))
         pipe = _resolve(factory)(**config)
         conn.send(("ready", None))
     except BaseException as e:  # construction errors travel to the parent (the reference re-raises KeyError)
