@@ -302,7 +302,7 @@ def run_rank(args):
             e.ops.synchronize()
 
     n_launch = -(-args.steps // B)  # K frames = ceil(K / B) launches (a ragged last launch still does B frames of work)
-    for i in range(-(-args.warmup // B)):
+    for i in range(max(-(-args.warmup // B), len(engines))):  # W warm-up frames, and at least one replay of every slot's graph
         one_frame(i)
     sync_all()
     if dist is not None:
