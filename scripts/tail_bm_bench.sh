@@ -1,3 +1,4 @@
 #!/bin/bash
-# tail_b on 64- against 80-token tiles (VSD_TAIL_BM forces one; default picks by rounds x height)
-for bm in 64 80; do echo "== VSD_TAIL_BM=$bm"; VSD_TAIL_BM=$bm python3 scripts/tail_bench.py 20480 16384 12288 32768 2>&1 | grep -v amdgpu | tail -8; done
+# fused tails at every tile height (VSD_TAIL_BM forces one; the default picks by rounds x round time, csrc/fused_tail.hip)
+for bm in 16 32 48 64 80; do echo "== VSD_TAIL_BM=$bm"; VSD_TAIL_BM=$bm python3 scripts/tail_bench.py ${@:-4096 8192 12288 16384 20480} 2>&1 | grep -v amdgpu | tail -5; done
+echo "== default choice"; python3 scripts/tail_bench.py ${@:-4096 8192 12288 16384 20480} 2>&1 | grep -v amdgpu | tail -5

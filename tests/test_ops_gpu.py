@@ -521,12 +521,13 @@ def _tail_weights(c=320, seed=0):
     return w, {k: add_frag(v) for k, v in packs.items()}
 
 
-@pytest.mark.parametrize("m", [12288, 4096, 200, 64, 20480, 17000])
+@pytest.mark.parametrize("m", [12288, 4096, 200, 64, 20480, 17000, 8000, 12000, 16384])
 def test_fused_transformer_tail_matches_the_unfused_chain(ops, m):
     """csrc/fused_tail.hip against explicit fp32 torch: tail_a = out-projection + residual, LayerNorm, query projection;
     tail_b = out-projection + residual, LayerNorm, GEGLU feed-forward + residual, proj_out + residual.  m = 200 has a ragged
-    last 64-token tile; 20480 (five frames of 64x64 tokens) and 17000 run tail_b on 80-token tiles (one round of <= 256
-    workgroups instead of two), 17000 with a ragged last one."""
+    last tile.  The library picks the tile height per token count (16 / 32 / 48 / 64 / 80 rows: the cheapest rounds of
+    <= 256 workgroups): 64, 200, 4096 -> 16; 8000 -> 32; 12000, 12288 -> 48; 16384 -> 64; 17000, 20480 -> 80; 200, 8000,
+    12000 and 17000 end in a ragged tile."""
     c = 320
     w, packs = _tail_weights(c)
     pk = {k: ops.to_device_pack(v) for k, v in packs.items()}

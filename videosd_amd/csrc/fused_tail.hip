@@ -472,6 +472,32 @@ __global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
 
 }  // namespace
 
+// Tokens per workgroup.  tail_b runs one workgroup per CU (330+ registers per lane), so a launch runs in rounds of 256
+// workgroups, and a round costs t0 + t1 x rows: every workgroup streams the chain's 2.9 MB of weights whatever its height,
+// the MFMA / VALU work grows with the rows.  Measured on MI355X (us per round, scripts/tail_bm_bench.sh): 16 rows 44,
+// 32: 49, 48: 60, 64: 74 (the software-pipelined form; the others use the plain loop), 80: 89.  4096 tokens as 64 tiles
+// of 64 rows used to take 72 us on a quarter of the chip (and lost to the four unfused launches, 59 us); as 256 tiles of
+// 16 rows they take 44; 12288 tokens: 61 us on 48-row tiles against 74; 20480: 91 us on 80-row tiles against 145.
+// tail_a (0.4 MB of weights, four-wave forms fit two per CU): 16-row tiles up to 4096 tokens (9.8 against 15 us), 32 above.
+// VSD_TAIL_BM forces a height (benchmarking).
+static int pick_tail_bm(int m, int kind) {
+  static const int force = getenv("VSD_TAIL_BM") ? atoi(getenv("VSD_TAIL_BM")) : 0;
+  if (force == 16 || force == 32 || force == 48 || force == 64 || force == 80) return force;
+  if (kind == 0) return cdiv(m, 16) <= 256 ? 16 : 32;
+  static const int cand[5] = {16, 32, 48, 64, 80};
+  static const double round_us[5] = {44.0, 49.0, 60.0, 74.0, 89.0};
+  int best = 64;
+  double best_t = 1e30;
+  for (int i = 0; i < 5; ++i) {
+    const double t = (double)cdiv(cdiv(m, cand[i]), 256) * round_us[i];
+    if (t < best_t - 1e-9) {
+      best_t = t;
+      best = cand[i];
+    }
+  }
+  return best;
+}
+
 // tokens x 320: out-projection + residual, LayerNorm (folded), query projection of the cross-attention
 extern "C" int vsd_tail_a(vsd_ctx* ctx, const void* att, const void* h, int m, const void* w_out, const void* b_out,
                           const void* w_q, const void* ln_s, const void* ln_t, float ln_eps, void* h1_out, void* q_out,
@@ -486,12 +512,14 @@ extern "C" int vsd_tail_a(vsd_ctx* ctx, const void* att, const void* h, int m, c
   p.out0 = (half_t*)h1_out; p.out1 = (half_t*)q_out; p.ln_eps = ln_eps;
   hipStream_t s = (hipStream_t)stream;
   LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * m * 2.0 * C * C);
-  // (one 512-thread workgroup per CU: rounds of 256, as for tail_b below -- 20480 tokens run as 256 tiles of 80 rows on
-  //  four waves instead of 320 tiles of 64 on eight)
-  static const int bm_force = getenv("VSD_TAIL_BM") ? atoi(getenv("VSD_TAIL_BM")) : 0;
-  const bool tall = bm_force ? bm_force == 80 : (long)cdiv(cdiv(m, 80), 256) * 80 < (long)cdiv(cdiv(m, 64), 256) * 64;
-  if (tall) hipLaunchKernelGGL((tail_kernel<0, 1, 80>), dim3(cdiv(m, 80)), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((tail_kernel<0, 2>), dim3(cdiv(m, BM0)), dim3(512), 0, s, p);
+  // tile height: see pick_tail_bm (64 = the eight-wave form; the others run four waves)
+  switch (pick_tail_bm(m, 0)) {
+    case 16: hipLaunchKernelGGL((tail_kernel<0, 1, 16>), dim3(cdiv(m, 16)), dim3(256), 0, s, p); break;
+    case 32: hipLaunchKernelGGL((tail_kernel<0, 1, 32>), dim3(cdiv(m, 32)), dim3(256), 0, s, p); break;
+    case 48: hipLaunchKernelGGL((tail_kernel<0, 1, 48>), dim3(cdiv(m, 48)), dim3(256), 0, s, p); break;
+    case 80: hipLaunchKernelGGL((tail_kernel<0, 1, 80>), dim3(cdiv(m, 80)), dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL((tail_kernel<0, 2>), dim3(cdiv(m, BM0)), dim3(512), 0, s, p);
+  }
   return ls.finish();
 }
 
@@ -511,22 +539,12 @@ extern "C" int vsd_tail_b(vsd_ctx* ctx, const void* att2, const void* h1, const 
   p.out0 = (half_t*)out; p.ln_eps = ln_eps;
   hipStream_t s = (hipStream_t)stream;
   LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * m * (2.0 * C * C + 3.0 * C * FF));
-  static const int wm_b = getenv("VSD_TAIL_WM") ? atoi(getenv("VSD_TAIL_WM")) : 1;  // (A/B switch: 2 = eight waves, measured equal)
-  // One workgroup per CU (330+ registers per lane): the launch runs in rounds of 256 workgroups, so 20480 tokens as 320
-  // tiles of 64 cost two rounds (measured 151 us against 77 us for 12288 tokens).  Taller tiles cost rows / 64 per round:
-  // pick the height with the least rounds x height (5 frames of 64x64 tokens: 256 tiles of 80 rows, one round).
-  static const int bm_force = getenv("VSD_TAIL_BM") ? atoi(getenv("VSD_TAIL_BM")) : 0;
-  int bm = 64;
-  {
-    long best = (long)cdiv(cdiv(m, 64), 256) * 64;
-    for (int cand : {80}) {  // (96 rows: 34 spilled registers)
-      const long cost = (long)cdiv(cdiv(m, cand), 256) * cand;
-      if (cost < best) { best = cost; bm = cand; }
-    }
-    if (bm_force == 64 || bm_force == 80) bm = bm_force;
+  switch (pick_tail_bm(m, 1)) {
+    case 16: hipLaunchKernelGGL((tail_kernel<1, 1, 16>), dim3(cdiv(m, 16)), dim3(256), 0, s, p); break;
+    case 32: hipLaunchKernelGGL((tail_kernel<1, 1, 32>), dim3(cdiv(m, 32)), dim3(256), 0, s, p); break;
+    case 48: hipLaunchKernelGGL((tail_kernel<1, 1, 48>), dim3(cdiv(m, 48)), dim3(256), 0, s, p); break;
+    case 80: hipLaunchKernelGGL((tail_kernel<1, 1, 80>), dim3(cdiv(m, 80)), dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL((tail_kernel<1, 1>), dim3(cdiv(m, BM0)), dim3(256), 0, s, p);
   }
-  if (wm_b == 2) hipLaunchKernelGGL((tail_kernel<1, 2>), dim3(cdiv(m, BM0)), dim3(512), 0, s, p);
-  else if (bm == 80) hipLaunchKernelGGL((tail_kernel<1, 1, 80>), dim3(cdiv(m, 80)), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((tail_kernel<1, 1>), dim3(cdiv(m, BM0)), dim3(256), 0, s, p);
   return ls.finish();
 }

@@ -378,7 +378,7 @@ class Engine:
         self.shared = {}
         self.absorb_cross_attention = True  # cross-attention of the wide blocks as two GEMMs (pack_cross_attention)
         self.use_fused_tail = True          # 320-wide blocks: per-token chains as fused launches (csrc/fused_tail.hip)
-        self.tail_b_min_rows = 6144         # ... the feed-forward chain from this many tokens per launch on (see _transformer)
+        self.tail_b_min_rows = 1024         # ... the feed-forward chain from this many tokens per launch on (see _transformer)
 
     def make_slot(self) -> "Engine":
         """A further frame in flight on the same GPU: shares the weights and the prompt / schedule constants of
@@ -568,9 +568,10 @@ class Engine:
             if fused:
                 # the block's per-token chains as fused launches around the cross-attention (csrc/fused_tail.hip): the token
                 # tile's owner streams only the weights; h1 / q (and in tail_b h2, the GEGLU hidden state, h3) stay on chip.
-                # Measured on MI355X (us, fused vs the launches it replaces): tail_a 14 vs 20 at 4096 tokens, 17 vs 31 at
-                # 12288; tail_b 71 vs 59 at 4096 (every workgroup streams all 2.9 MB of feed-forward weights whatever the
-                # token count), 80 vs 117 at 12288 -- so the feed-forward chain is fused from two frames per launch on.
+                # Measured on MI355X (us, fused vs the launches it replaces; the library picks the tile height per token count):
+                # tail_a 10 vs 19 at 4096 tokens, 15 vs 31 at 12288, 21 vs 53 at 20480; tail_b 44 vs 59 at 4096 (every
+                # workgroup streams all 2.9 MB of feed-forward weights whatever the token count), 61 vs 111 at 12288,
+                # 91 vs 214 at 20480.  Below ~2048 tokens (small frames) the separate launches win.
                 h1 = a.alloc(rows, c)
                 q = a.alloc(rows, c)
                 r.tail_a(att, h, rows, bw.out1, bw.q2, h1, q)
