@@ -332,7 +332,11 @@ def run_rank(args):
     # ---- end to end: host u8 in -> host u8 out INSIDE the timed region (pinned staging, H2D / D2H on the launch's own
     #      stream), same frames per launch and launches in flight.  PCIe inclusive: reported beside `value`, never as it.
     fps_e2e = None
+    got_batched = None
     if extras:
+        # frame 0 of one launch of the TIMED plan (B frames): its image is compared with the oracle's below (`parity_batched`)
+        got_batched = engines[0].infer_u8(np.ascontiguousarray(frames_host[:B]) if B > 1 else frames_host[0])
+        got_batched = (got_batched[0] if B > 1 else got_batched).copy()
         nl = max(2 * len(engines), n_launch)
         fb = [np.ascontiguousarray(frames_host[(i * B) % (nres - B + 1):(i * B) % (nres - B + 1) + B]) for i in range(4)]
         for i in range(len(engines)):
@@ -485,7 +489,9 @@ def run_rank(args):
         try:
             out["cpu_baseline"], ref0 = cpu_baseline(weights, text.cpu(), frames_host[0])
             if got0 is not None:
-                out["parity"] = image_parity(got0, ref0)
+                out["parity"] = image_parity(got0, ref0)  # the one-frame plan of the latency leg
+            if got_batched is not None:
+                out["parity_batched"] = dict(image_parity(got_batched, ref0), frames_per_launch=B)  # the timed plan
         except Exception as e:  # the baseline is reporting only; never lose the measured line
             out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"failed: {e}"}
