@@ -1,4 +1,8 @@
-"""Development: phase stamps (shader clock, ~100 MHz... s_memtime) of the weight-streaming kernel built with -DSK_PROBE."""
+"""Development: phase stamps (shader clock) of the weight-streaming kernel (csrc/conv_skinny.hip) built with -DSK_PROBE.
+Build the probe library first (not part of libvsd.so):
+  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -DSK_PROBE -c videosd_amd/csrc/conv_skinny.hip -o /tmp/skinny_probe.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o build_exp/lib_skprobe.so $(ls videosd_amd/build/*.o | grep -v "conv_skinny.o\|probe") /tmp/skinny_probe.o
+"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
