@@ -100,6 +100,31 @@ def test_slider_options_do_not_rebuild_the_plan(pipe):
         pipe.infer(img, **{**OPTS, "strength": 0.01})  # empty schedule: the caller's error, typed as such
 
 
+def test_warm_up_prepares_every_batch_size_and_lane_and_two_lanes_do_not_share_staging():
+    """`warm_up` (what a server calls once per worker, and the dispatcher for a respawned one): every (batch size, lane)
+    engine of the stream is prepared and captured, so the frames that follow add no `prepare`; and two launches in flight on
+    the two lanes return their own frames (a slot made after the parent's first frame used to share the parent's pinned
+    staging buffers and timing events)."""
+    from videosd_amd.pipeline import VideoSDPipeline
+
+    p = VideoSDPipeline(**CFG)
+    assert p.warm_up(batches=(1, 2), lanes=2, **OPTS) == 4
+    n_prep = len(p._host_ms["prepare"])
+    assert n_prep == 4 and len(p._engines) == 4
+    a, b = _photo(300, 200, 31), _photo(280, 210, 32)
+    alone = [np.asarray(p.infer(x, **OPTS)) for x in (a, b)]
+    h0 = p.submit_batch([a], lane=0, **OPTS)
+    h1 = p.submit_batch([b], lane=1, **OPTS)
+    got = [np.asarray(p.collect_batch(h0)[0]), np.asarray(p.collect_batch(h1)[0])]
+    assert np.array_equal(got[0], alone[0])                                  # lane 0 is the engine `infer` used
+    assert np.abs(got[1].astype(int) - alone[1].astype(int)).mean() < 0.5      # lane 1: same program on its own slot
+    assert not np.array_equal(got[0], got[1])
+    pair = p.infer_batch([a, b], **OPTS)                                      # the batch-2 plan is warm too
+    assert np.abs(np.asarray(pair[1]).astype(int) - alone[1].astype(int)).mean() < 0.5
+    assert len(p._host_ms["prepare"]) == n_prep                               # nothing was prepared after warm_up
+    assert p._host_ms["gpu"] and all(0.0 < v < 1e4 for v in p._host_ms["gpu"])  # per-launch device ms from the lane's own events
+
+
 def test_reference_only_mode_through_the_drop_in_class():
     """`infer(..., ref=True)` with `honor_ref_flag=True` runs the reference-only program (banked
     self-attention + AdaIN, lcm_reference_pipeline.py:498-794) on the HIP kernels, against the oracle restatement; with
