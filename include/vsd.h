@@ -105,7 +105,11 @@ typedef struct vsd_conv_desc {
                              9 = weight-streaming form for the small-image levels (csrc/conv_skinny.hip): M <= 192 rows,
                              ksize 1 or 3 with stride 1 and pad ksize/2, no resize, Cin % 128 == 0 per source and >= 256,
                              n % 64 == 0, needs weight_frag, `tile` ignored, split_k must be Cin / 128 (the slabs are
-                             reduced by the second kernel, so no rowstat_out / chanstat_out / GEGLU / softmax / out_t) */
+                             reduced by the second kernel, so no rowstat_out / chanstat_out / GEGLU / softmax / out_t);
+                             10 = weights-resident persistent form (csrc/conv_resident.hip): 3x3 stride-1 conv with exactly 64 input
+                             (one source) and 64 output channels (the TAESD blocks), plain epilogue as for 7, split_k 1, `tile`
+                             ignored: every wave keeps the nine taps' weights of its 32 output channels in registers, persistent workgroups
+                             walk the 8x16-pixel patches, results bit-identical to 7 */
   void* rowstat_out;      /* optional fp32 [M][n/64][2]: per output row, (sum, sum of squares) of the fp16 outputs over
                              each 64-column group -- the LayerNorm statistics of the NEXT layer, for free */
   void* chanstat_out;     /* optional fp32 [n][2]: per output CHANNEL, (sum, sum of squares) of the fp16 outputs over all M

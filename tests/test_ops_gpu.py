@@ -973,3 +973,73 @@ def test_conv_weight_streaming_rejects_what_it_cannot_do(ops):
     d.workspace = torch.zeros(3 * 64 * 64, device="cuda").data_ptr()
     assert ops.ctx.lib.vsd_conv_gemm(ops.ctx.h, C.byref(d), ops.s) != 0
     assert b"split_k must be Cin / 128" in ops.ctx.lib.vsd_last_error(ops.ctx.h)
+
+
+@pytest.mark.parametrize("B,hs,ws,up,act,with_res", [
+    (1, 16, 16, None, 1, False),          # two patches, bias + ReLU
+    (3, 24, 40, None, 1 | 256, True),     # patches hanging over the right edge, residual then ReLU (the TAESD block's last conv)
+    (2, 27, 19, None, 2, True),           # ragged both ways, SiLU + residual
+    (5, 64, 128, None, 1, True),          # 320 patches > 256 workgroups: the persistent loop, double-buffered halo prefetch
+    (2, 16, 24, (32, 48), 0, False),      # the decoder's Upsample(2x) folded into the conv
+    (1, 8, 8, None, 0, False),            # a single patch
+])
+def test_conv_weights_resident_pipeline10(ops, B, hs, ws, up, act, with_res):
+    """pipeline 10 (csrc/conv_resident.hip): the 64 -> 64 channel 3x3 convs of TAESD with all nine weight tiles resident in
+    LDS and one persistent workgroup per CU -- against F.conv2d in fp32, and bit-identical to the halo-patch kernel (same
+    fragments, same summation order)."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    cin = cout = 64
+    x = rnd(B, cin, hs, ws, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
+    bias, rv = rnd(cout, seed=3, scale=0.1), rnd(cout, seed=4, scale=0.1)
+    pw = ops.to_device_pack(pack_conv(wt, bias))
+    g = Geom.conv(hs, ws, up_to=up, batch=B)
+    res = rnd(g.m, cout, seed=5) if with_res else None
+    xs = x.permute(0, 2, 3, 1).reshape(B * hs * ws, cin).contiguous().cuda()
+    kw = dict(act=act, rowvec=rv.cuda())
+    if with_res:
+        kw["residual"] = res.cuda()
+    out = torch.zeros(g.m, cout, dtype=torch.float16, device="cuda")
+    ops.conv(xs, None, g, pw, out, pipeline=10, tile=1, **kw)
+    halo = torch.zeros_like(out)
+    ops.conv(xs, None, g, pw, halo, pipeline=7, tile=1, split_k=1, **kw)
+    ops.synchronize()
+    xin = x.float() if up is None else F.interpolate(x.float(), size=up, mode="nearest")
+    ref = F.conv2d(xin, wt.float(), bias.float(), padding=1) + rv.float()[None, :, None, None]
+    a = act & 0xff
+    post = bool(act & 256)
+    if a == 1 and not post:
+        ref = F.relu(ref)
+    elif a == 2:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1).reshape(g.m, cout)
+    if with_res:
+        ref = ref + res.float()
+    if post:
+        ref = F.relu(ref)
+    check(out, ref, f"weights-resident conv B={B} {hs}x{ws} up={up} act={act}")
+    if a == 2:  # (the SiLU epilogue is compiled in another context: the exp / rcp sequence may round differently by an fp16 ulp)
+        assert float((out.float() - halo.float()).abs().max()) <= 2e-3 * max(1.0, float(halo.float().abs().max()))
+    else:
+        assert torch.equal(out, halo)
+    again = torch.full_like(out, 3.0)
+    ops.conv(xs, None, g, pw, again, pipeline=10, tile=1, **kw)
+    ops.synchronize()
+    assert torch.equal(out, again)
+
+
+def test_conv_weights_resident_falls_back_for_other_shapes(ops):
+    """A tuning-table entry for pipeline 10 must never be applied to a call it cannot serve (other channel counts)."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    x = rnd(1, 128, 16, 16, seed=1)
+    wt = rnd(64, 128, 3, 3, seed=2, scale=(128 * 9) ** -0.5)
+    pw = ops.to_device_pack(pack_conv(wt, None))
+    g = Geom.conv(16, 16)
+    out = torch.zeros(g.m, 64, dtype=torch.float16, device="cuda")
+    ops.conv(x.permute(0, 2, 3, 1).reshape(-1, 128).contiguous().cuda(), None, g, pw, out, pipeline=10, tile=1)
+    ops.synchronize()
+    check(out, F.conv2d(x.float(), wt.float(), None, padding=1).permute(0, 2, 3, 1).reshape(g.m, 64), "pipeline 10 fallback")

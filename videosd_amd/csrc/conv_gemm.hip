@@ -72,7 +72,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.ln_s = (const float*)d->ln_s;
   p.ln_t = (const float*)d->ln_t;
   const int stages = d->pipeline;
-  if (stages != 0 && (stages < 3 || stages > 9)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..9)", stages);
+  if (stages != 0 && (stages < 3 || stages > 10)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..10)", stages);
   const bool halo = stages == 7;
   const bool skinny = stages == 9;
 
@@ -97,6 +97,23 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   if (p.ln_part && (p.ksize != 1 || !p.ln_s || !p.ln_t || p.ln_groups <= 0 || p.bias))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: fused LayerNorm needs a 1x1 layer, ln_s/ln_t and no separate bias");
   if (p.split_k > 1 && !p.ws_partial) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: split_k needs a workspace");
+  if (stages == 10) {
+    // weights-resident persistent form (conv_resident.hip): 3x3 stride-1 conv, 64 -> 64 channels, the halo kernel's plain epilogue
+    const int act = p.act & 0xff;
+    const bool simple_epi = !p.out2 && !p.residual2 && !p.out_t && !p.rowstat_out && !p.chanstat_out && !p.ln_part && p.out_scale == 1.0f &&
+                            !p.out_scale_dev && (act == VSD_ACT_NONE || act == VSD_ACT_RELU || act == VSD_ACT_SILU) &&
+                            !((p.act & VSD_ACT_POST) && act != VSD_ACT_RELU);
+    if (!p.halo_ok || p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.c0 != 64 || p.c1 != 0 || p.N != 64 || p.Kp != 576 || !simple_epi ||
+        p.split_k != 1 || p.ldo % 8)
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the weights-resident form (pipeline 10) is a 3x3 stride-1 conv with 64 input and 64 output "
+                      "channels, the plain epilogue and no split-K");
+    p.counters = nullptr;
+    p.tiles_m = p.batch * cdiv(p.ho, 8) * cdiv(p.wo, 16);
+    p.tiles_n = 1;
+    LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
+    vsd_launch_conv_resident(p, p.tiles_m, s);
+    return ls.finish();
+  }
   if (skinny) {
     // weight-streaming form (conv_skinny.hip): one workgroup = 64 output channels x all M rows x 128 input channels
     const int padded = p.batch * (p.hs + 2 * (p.ksize / 2)) * (p.ws + 2 * (p.ksize / 2));

@@ -107,6 +107,7 @@ void vsd_launch_conv_halo(const ConvParams& p, int bm, int bn, int grid, hipStre
 void vsd_launch_splitk_reduce(const ConvParams& p, int grid, hipStream_t s);
 void vsd_launch_conv_skinny(const ConvParams& p, const half_t* wfrag, int grid, hipStream_t s);  // conv_skinny.hip (pipeline 9)
 int vsd_conv_skinny_max_pixels();
+void vsd_launch_conv_resident(const ConvParams& p, int patches, hipStream_t s);  // conv_resident.hip (pipeline 10)
 
 namespace {
 

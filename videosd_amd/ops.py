@@ -231,6 +231,11 @@ class HipOps:
         split_k = split_k or 1
         if w.tile128:
             inkernel = True  # (the tile softmax runs in the reducing workgroup's epilogue)
+        if pipeline == 10 and (out_scale_dev is not None or w.cin != 64 or w.n != 64 or (c1 or 0) != 0 or
+                               not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part)):
+            pipeline, tile, split_k, inkernel = 3, L.TILE_128x64, 1, True  # (a table entry found for another call of the shape)
+        if pipeline == 10:
+            split_k, inkernel = 1, False
         if pipeline == 9 and not self._skinny_call_ok(g, w, c0, c1, act, out_t, rowstat_out, chanstat_out):
             # a tuning-table entry found for another call of the same shape key
             pipeline, tile, split_k, inkernel = 3, L.TILE_64x64, min(8, max(1, w.kp // 128)), True
@@ -286,6 +291,8 @@ class HipOps:
             d.workspace = self._p(ws)
             if inkernel:
                 d.counters = self._p(self._counters[self._sidx])
+        elif workspace is not None:  # (development probes pass a buffer through)
+            d.workspace = self._p(workspace)
         self.ctx.call("vsd_conv_gemm", C.byref(d), self.s)
 
     SKINNY_MAX_PIXELS = 320  # csrc/conv_skinny.hip SK_MAX_PIX: padded pixels of all images its LDS panel holds
@@ -370,6 +377,10 @@ class HipOps:
             # weight-streaming form (tile ignored, split = Cin / 128).  Opt-in: measured at parity with the tiled forms on
             # the 3x3 layers and slower on the linear ones, and it cannot share a CU with another launch (conv_skinny.hip)
             cands.append((L.TILE_64x64, w.cin // 128, False, 9))
+        if _os.environ.get("VSD_TUNE_RESIDENT") and halo_ok and w.cin == 64 and w.n == 64 and c1_ == 0 and kwargs.get("out_scale_dev") is None:
+            # weights resident in registers, persistent workgroups (conv_resident.hip).  Opt-in: measured 7 % ahead of the halo
+            # kernel at 5 x 512 x 512 only, behind it at every smaller size
+            cands.append((L.TILE_128x64, 1, False, 10))
         kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline")}
         table = []
         saved = self.tile_override.pop(key, None)
