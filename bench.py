@@ -155,7 +155,7 @@ def image_parity(got, ref):
                        "tolerance: mad <= 1.5 LSB, PSNR >= 38 dB"}
 
 
-def api_leg(frames_host, n_frames=None, batch=5):
+def api_leg(frames_host, n_frames=None, batch=5, lanes=int(os.environ.get("VSD_API_LANES", "2"))):
     """The drop-in class end to end: PIL in -> worker process -> PIL out through `VideoSDPipeline.remote(...)`
     (what diffusert/server.py:108 awaits), one frame at a time and as a stream the worker may coalesce."""
     import asyncio
@@ -167,18 +167,18 @@ def api_leg(frames_host, n_frames=None, batch=5):
     opts = dict(prompt="pixar, cg", height=H, width=W, strength=STRENGTH, steps=LCM_STEPS, controlnet_scale=1.0, seed=23)
     imgs = [Image.fromarray(f, "RGB") for f in frames_host]
     w = VideoSDPipeline.remote(model="SimianLuo/LCM_Dreamshaper_v7", controlnet="lllyasviel/control_v11p_sd15_canny",
-                               device=0, batch=batch, call_timeout=600.0, max_plans=2 * batch + 2)
+                               device=0, batch=batch, lanes=lanes, shm_slots=(lanes + 1) * batch + 4, call_timeout=600.0)
     n_frames = n_frames or 32 * batch
     try:
         # plans + graphs of every (batch size, lane) the stream will use: what a server does once at start-up
-        w.method("warm_up")(batches=tuple(range(1, batch + 1)), lanes=2, **opts)
+        w.method("warm_up")(batches=tuple(range(1, batch + 1)), lanes=lanes, **opts)
         lat = []
         for i in range(16):
             t0 = time.perf_counter()
             w.infer(imgs[i % len(imgs)], **opts)
             lat.append((time.perf_counter() - t0) * 1e3)
 
-        async def stream(depth=int(os.environ.get("VSD_API_DEPTH", str(3 * batch)))):
+        async def stream(depth=int(os.environ.get("VSD_API_DEPTH", str((lanes + 1) * batch)))):
             sem = asyncio.Semaphore(depth)
             done = 0
 
@@ -199,7 +199,7 @@ def api_leg(frames_host, n_frames=None, batch=5):
                 "api_stage_ms_p50": m.get("pipeline", {}).get("stage_ms_p50"),
                 "api_frames_per_launch": m.get("frames_per_launch"),
                 "api_note": "PIL 512x512 in -> VideoSDPipeline.remote worker process (shared-memory frame slots) -> PIL out; "
-                            f"api_fps: {3 * batch} frames outstanding (two launches of {batch} on the GPU, one filling), the worker coalesces up to {batch} per launch"}
+                            f"api_fps: {(lanes + 1) * batch} frames outstanding ({lanes} launches of up to {batch} on the GPU, one filling), the worker coalesces up to {batch} per launch"}
     finally:
         w.close()
 

@@ -2,6 +2,7 @@
 logic, on CPU: signatures/defaults, crop+resize, schedule helpers, awaitable `.infer.remote`, round-robin
 sharding with in-order release and drop-if-busy, RCCL-broadcast logic with gloo standing in (world_size 2)."""
 import asyncio
+import time
 import inspect
 import os
 import socket
@@ -192,6 +193,25 @@ def test_worker_coalesces_queued_frames_into_batched_launches():
 
         errs = asyncio.run(bad())
         assert all(e and "negative strength" in e for e in errs), errs
+    finally:
+        p.close()
+
+
+def test_worker_with_three_lanes_keeps_three_launches_in_flight_and_answers_in_order():
+    """RemotePipeline(lanes=3): consecutive launches rotate over three engine lanes, at most three are on the 'GPU' at once,
+    and every caller still gets its own frame, in request order."""
+    p = RemotePipeline(factory=FAKE, model="m", controlnet="c", device=1, delay=0.15, batch=2, lanes=3)
+    try:
+        async def go():
+            futs = [p.infer.remote(_img(10 * (k + 1)), height=12, width=16) for k in range(12)]
+            return [await f for f in futs]
+
+        t0 = time.time()
+        outs = asyncio.run(go())
+        dt = time.time() - t0
+        assert [int(np.asarray(o)[1, 1, 0]) for o in outs] == [255 - 10 * (k + 1) for k in range(12)]
+        assert {int(np.asarray(o)[0, 0, 2]) for o in outs} == {0, 1, 2}  # all three lanes were used
+        assert dt < 12 * 0.15  # launches overlapped (one at a time would take >= 6 launches x 0.15 s + the first frame alone)
     finally:
         p.close()
 

@@ -196,7 +196,7 @@ class _Stats:
 
 
 def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1, group: Optional[Dict[str, Any]] = None,
-                 shm: Optional[Dict[str, Any]] = None):
+                 shm: Optional[Dict[str, Any]] = None, lanes: int = 2):
     """Serve calls in order, like a Ray actor.  With max_batch > 1, `infer` calls that are ALREADY queued behind the one
     being taken (frames of other sessions, or of the same stream submitted ahead) and carry the same options are
     coalesced into one `infer_batch` launch: no waiting for a batch to fill, so a lone frame is never delayed.  When
@@ -223,8 +223,9 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=to)
             else:
                 dist.init_process_group(group["backend"], rank=rank, world_size=world, timeout=to)
-        if max_batch > 3:  # two lanes x every batch size up to max_batch must stay cached (VideoSDPipeline evicts beyond max_plans)
-            config = dict(config, max_plans=max(int(config.get("max_plans", 8)), 2 * max_batch + 2))
+        lanes = max(1, int(lanes))
+        if lanes * max_batch + 2 > 8:  # every (batch size, lane) engine must stay cached (VideoSDPipeline evicts beyond max_plans)
+            config = dict(config, max_plans=max(int(config.get("max_plans", 8)), lanes * max_batch + 2))
         pipe = _resolve(factory)(**config)
         conn.send(("ready", None))
     except BaseException as e:  # construction errors travel to the parent (the reference re-raises KeyError)
@@ -363,9 +364,9 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
                 drain()
                 fail(group_, e)
                 continue
-            lane ^= 1
+            lane = (lane + 1) % lanes
             inflight.append((group_, handle, t_in, kwargs))
-            if len(inflight) > 1:
+            if len(inflight) >= lanes:  # every lane has a launch on the GPU: hand back the oldest before taking more
                 finish_oldest()
             continue
         drain()  # anything else runs alone, after what is in flight
@@ -413,13 +414,16 @@ class RemotePipeline:
 
     def __init__(self, factory: str = "videosd_amd.pipeline:VideoSDPipeline", start_timeout: float = 600.0, batch: int = 1,
                  call_timeout: Optional[float] = None, group: Optional[Dict[str, Any]] = None, shm_slots: int = 16,
-                 shm_slot_bytes: int = 1024 * 1024 * 3, wait: bool = True, **config):
+                 shm_slot_bytes: int = 1024 * 1024 * 3, wait: bool = True, lanes: int = 2, **config):
         """batch > 1: the worker coalesces up to `batch` queued `infer` calls with equal options into one launch.
         call_timeout: seconds one call may take before the worker is declared hung and killed (None: no limit).
         group: {"rank", "world", "port", "backend"} -- the worker joins that torch.distributed group (`spawn_workers`).
-        shm_slots: frames in flight through shared memory (0: always pickle)."""
+        shm_slots: frames in flight through shared memory (0: always pickle).
+        lanes: launches the worker keeps on the GPU at once (engines with their own buffers / graph; default 2: one running,
+        one queued behind it while the host prepares the next; 3 also covers the host's own time per launch)."""
         self._ctor = dict(factory=factory, start_timeout=start_timeout, batch=batch, call_timeout=call_timeout,
-                          shm_slots=shm_slots, shm_slot_bytes=shm_slot_bytes, **config)
+                          shm_slots=shm_slots, shm_slot_bytes=shm_slot_bytes, lanes=lanes, **config)
+        self.lanes = max(1, int(lanes))
         self.group = group
         self.call_timeout = call_timeout
         self.max_batch = int(batch)
@@ -434,7 +438,7 @@ class RemotePipeline:
         self._free_slots = list(range(shm_slots))
         ctx = mp.get_context("spawn")
         self._conn, child = ctx.Pipe()
-        self._proc = ctx.Process(target=_worker_main, args=(child, factory, config, int(batch), group, shm), daemon=True)
+        self._proc = ctx.Process(target=_worker_main, args=(child, factory, config, int(batch), group, shm, int(lanes)), daemon=True)
         self._proc.start()
         child.close()
         self._lock = threading.Lock()
@@ -798,7 +802,7 @@ class FrameDispatcher:
 
                 b = int(getattr(new, "max_batch", 1) or 1)
                 try:  # every (batch size, lane) engine the stream will use
-                    await new.method("warm_up").remote(batches=tuple(range(1, b + 1)), lanes=2 if b > 1 else 1,
+                    await new.method("warm_up").remote(batches=tuple(range(1, b + 1)), lanes=getattr(new, "lanes", 2) if b > 1 else 1,
                                                        **self.warm_options)
                 except RemoteCallError:  # a pipeline without `warm_up`: one frame through `infer`
                     w, h = self.warm_options.get("width", 640), self.warm_options.get("height", 360)
