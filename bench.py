@@ -68,21 +68,48 @@ def launch_ranks(args, argv):
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
-                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
     line = None
-    for ln in (out0 or "").splitlines():
-        if ln.startswith("{") and '"metric"' in ln:
-            line = ln
-    if line is None or any(rcs):
-        sys.stderr.write(out0 or "")
-        raise SystemExit(f"bench.py: ranks exited with {rcs}" + ("" if line else " and rank 0 printed no result line"))
+    rcs = [None] * n
+    try:
+        for r in range(n):
+            env = dict(os.environ)
+            env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                        "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        # rank 0's stdout is drained by a thread (a full pipe must never block it) while ALL children are polled: the first
+        # rank that exits non-zero ends the run at once -- the others would otherwise sit in the rendezvous / a collective
+        # until the process-group timeout before anything is reported
+        import threading
+
+        out0 = []
+        reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout), daemon=True)
+        reader.start()
+        failed = None
+        while any(rc is None for rc in rcs) and failed is None:
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    rcs[i] = p.poll()
+                    if rcs[i] not in (None, 0):
+                        failed = i
+            time.sleep(0.05)
+        reader.join(timeout=5)
+        for ln in out0:
+            if ln.startswith("{") and '"metric"' in ln:
+                line = ln.strip()
+        if failed is not None or line is None:
+            sys.stderr.write("".join(out0))
+            raise SystemExit(f"bench.py: rank {failed} exited with {rcs[failed]}; the other ranks were stopped" if failed is not None
+                             else f"bench.py: ranks exited with {rcs} and rank 0 printed no result line")
+    finally:  # (also on KeyboardInterrupt / an exception above): never leave rank processes behind -- exactly these PIDs
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
     print(line, flush=True)
 
 
@@ -215,23 +242,29 @@ def run_rank(args):
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}\n")
     if not args.dry_run and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.dry_run and os.environ.get("VSD_DRYRUN_FAIL_RANK") == str(rank):
+        raise SystemExit(7)  # (tests/test_bench_launcher.py: a rank that dies before the rendezvous)
     dist = None
     backend = os.environ.get("VSD_DIST_BACKEND", "gloo" if args.dry_run else "nccl")
     if world > 1:
         import torch.distributed as dist
 
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a rank that never arrives must not hold the others for the default 10-30 minutes
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("VSD_PG_TIMEOUT", "300")))
         if os.environ.get("VSD_SHARE_GPU"):
             local = 0
         # RCCL over xGMI.  VSD_DIST_BACKEND=gloo + VSD_SHARE_GPU=1 exist only to walk this multi-rank code path on a
         # single-GPU box (both ranks on cuda:0, collectives on host copies); the driver never sets them.
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=pg_timeout)
         else:
             if not args.dry_run:
                 torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
     ranks_seen = 1
     if dist is not None:
         seen = [None] * world

@@ -49,7 +49,12 @@ enum vsd_family {
   VSD_FAM_ATTENTION = 4, VSD_FAM_ELEMENTWISE = 5, VSD_FAM_COUNT = 6
 };
 
+/* Version of this interface (bumped whenever a struct grows or an entry point is added; round 3 = 3) and the size in
+ * bytes of vsd_conv_desc as the LIBRARY was built: a caller compares both with its own header before the first call
+ * (videosd_amd/lib.py does) instead of passing a short struct to a stale libvsd.so. */
+#define VSD_VERSION 3
 int vsd_version(void);
+int vsd_conv_desc_size(void);
 
 /* One context per GPU / per worker process (reference: one Ray actor per GPU, videopipeline.py:11,20). */
 vsd_ctx* vsd_create(int device_id);
@@ -248,6 +253,17 @@ int vsd_lcm_step_dev(vsd_ctx* ctx, const void* eps, const void* sample, const vo
  * squares) over those rows, as vsd_conv_gemm's chanstat_out writes them.  x, out: fp16 [rows][c]; may alias. */
 int vsd_adain(vsd_ctx* ctx, const void* x, const void* stats, const void* stats_ref, int rows, int c, float eps, void* out,
               void* stream);
+
+/* Per-prompt constants of the "absorbed" cross-attention (see softmax_cols above; csrc/prompt_fold.hip): for one transformer
+ * block, fold the text's key / value projections into its query / output weights.  k: fp16 [tl][ldk] (to_k of the text),
+ * vt: fp16 [c][ldvt] (to_v of the text, transposed, zero beyond tl), wq / wo: the raw fp16 [c][c] to_q / to_out.0 weights of attn2
+ * (diffusers' Attention under lcm_controlnet.py:558,568), gamma / beta: fp16 [c] of the LayerNorm in front (norm2), scale =
+ * head_dim^-0.5.  Writes xa1_w fp16 [heads*128][c] = (scale K_h Wq_h) * gamma with xa1_s / xa1_t fp32 [heads*128] (the
+ * ln_s / ln_t of a LayerNorm-consuming vsd_conv_gemm layer) and xa2_w fp16 [c][heads*128] = Wo_h V_h^T; rows / columns of the
+ * keys tl..127 of every head are zero.  c % 64 == 0, (c / heads) % 8 == 0, tl <= 128.  Runs once per prompt and layer. */
+int vsd_xattn_fold(vsd_ctx* ctx, const void* k, int ldk, const void* vt, int ldvt, int tl, const void* wq, const void* wo,
+                   const void* gamma, const void* beta, int c, int heads, float scale, void* xa1_w, void* xa1_s, void* xa1_t,
+                   void* xa2_w, void* stream);
 
 /* CLIP text embeddings (CLIPTextEmbeddings under lcm_controlnet.py:175): out[i] = token_emb[ids[i]] + pos_emb[i], i < n.
  * ids: int64 [n] in device memory (clamped to [0, vocab)); token_emb fp16 [vocab][c], pos_emb fp16 [>= n][c], out fp16 [n][c]. */

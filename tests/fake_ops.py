@@ -275,6 +275,17 @@ class FakeOps:
         h3 = hid.float() @ ff2.weight[:, :ff2.k].float().t() + ff2.bias.float() + h2
         out[:m] = (h3.half().float() @ proj.weight[:, :proj.k].float().t() + proj.bias.float() + x[:m].float()).half()
 
+    def xattn_fold(self, k, vt, tl, wq, wo, gamma, beta, c, heads, scale, xa1_w, xa1_s, xa1_t, xa2_w):
+        """vsd_xattn_fold through the host restatement of the same algebra (packing.pack_cross_attention)"""
+        from videosd_amd.packing import pack_cross_attention
+
+        x1, x2 = pack_cross_attention(k[:tl, :c].float(), vt[:c, :tl].float().t().contiguous(), wq[:, :c], wo[:, :c],
+                                      torch.zeros(c), gamma, beta, heads)
+        xa1_w.copy_(x1.weight[:, :c])
+        xa1_s.copy_(x1.ln_s)
+        xa1_t.copy_(x1.ln_t)
+        xa2_w.copy_(x2.weight[:, :heads * 128])
+
     def embed_tokens(self, ids_i64, tok_emb, pos_emb, out):
         n = out.shape[0]
         out.copy_((tok_emb[ids_i64.long()].float() + pos_emb[:n].float()).half())

@@ -127,3 +127,54 @@ class WarmFakePipeline(FakePipeline):
 
     def warm_state(self):
         return getattr(self, "warmed", None)
+
+
+class SessionFakePipeline(FakePipeline):
+    """Like VideoSDPipeline since round 3: plans and prompts are cached per key, launches of different sessions may be in
+    flight together (`needs_idle` only asks for a drain when strength changes under a running plan).  Records how many
+    launches of DIFFERENT sessions were live at once, and the tuning tables it exported / imported."""
+
+    def __init__(self, **config):
+        super().__init__(**config)
+        self.live = []
+        self.max_mixed = 0
+        self.prompts = {}
+        self.tuning = {("shape", self.device): ("tile", self.device)}
+
+    def needs_idle(self, **opts):
+        key = (opts.get("prompt"), opts.get("width"), opts.get("height"))
+        return any(k == key and s != opts.get("strength") for k, s in self.live)
+
+    def submit_batch(self, imgs, lane=0, **opts):
+        key = (opts.get("prompt"), opts.get("width"), opts.get("height"))
+        if any(k == key and s != opts.get("strength") for k, s in self.live):
+            raise RuntimeError("strength changed under a running plan")
+        self.live.append((key, opts.get("strength")))
+        self.max_mixed = max(self.max_mixed, len({k for k, _ in self.live}))
+        return super().submit_batch(imgs, lane=lane, **opts)
+
+    def collect_batch(self, handle):
+        self.live.pop(0)
+        return super().collect_batch(handle)
+
+    def set_prompt_embeds(self, embeds, key=None):
+        self.prompts[key] = float(embeds.float().sum())
+        return super().set_prompt_embeds(embeds, key=key)
+
+    def session_state(self):
+        return {"max_mixed": self.max_mixed, "prompts": sorted(self.prompts), "encodes": self.encodes, "tuning": dict(self.tuning)}
+
+    def export_tuning(self):
+        return dict(self.tuning)
+
+    def import_tuning(self, table):
+        n = 0
+        for k, v in table.items():
+            if k not in self.tuning:
+                self.tuning[k] = v
+                n += 1
+        return n
+
+    def warm_up(self, batches=(1,), lanes=1, **options):
+        self.tuning.setdefault(("warmed", tuple(batches), lanes), ("by", self.device))  # a shape this rank "measures" if it has no entry yet
+        return len(tuple(batches)) * lanes

@@ -38,6 +38,21 @@ def test_single_rank_default_and_torchrun_environment():
     assert out["n_gpus"] == 1
 
 
+def test_a_rank_that_dies_ends_the_run_at_once_and_leaves_no_process_behind():
+    """a rank other than 0 that dies at start-up used to leave rank 0 in the rendezvous until the process-group
+    timeout (minutes) before the launcher said anything.  The launcher polls every child: it exits non-zero within seconds
+    and stops the survivors."""
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update({"VSD_DIST_BACKEND": "gloo", "VSD_DRYRUN_FAIL_RANK": "1"})
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "rank 1 exited with 7" in (p.stderr + p.stdout), (p.stdout, p.stderr[-500:])
+    assert time.time() - t0 < 60
+
+
 def test_bench_refuses_to_run_the_product_path_without_a_gpu():
     import torch
 

@@ -24,7 +24,9 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vsd_version() == 1
+    # the library and the binding agree on the interface version and on the struct layout (lib.load() refuses a stale build)
+    assert lib.vsd_version() == L.VERSION == int(re.search(r"#define VSD_VERSION (\d+)", _header()).group(1))
+    assert lib.vsd_conv_desc_size() == ctypes.sizeof(L.ConvDesc)
     assert lib.vsd_create(10_000) is None  # no such device -> NULL, never aborts
 
 
@@ -60,3 +62,17 @@ def test_one_hip_runtime_in_the_process_whatever_the_import_order():
     assert out.returncode == 0, out.stderr[-2000:]
     libs = re.findall(r"'([^']+)'", out.stdout.strip().splitlines()[-1])
     assert len(libs) == 1, libs
+
+
+def test_a_stale_library_is_refused_with_the_rebuild_command(monkeypatch):
+    """vsd_conv_desc grew while vsd_version stayed the same; a stale libvsd.so must be named as such at load."""
+    import pytest
+
+    L.load()
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "VERSION", L.VERSION + 1)
+    with pytest.raises(RuntimeError, match="videosd_amd.build --force"):
+        L.load()
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "VERSION", L.VERSION - 1)
+    assert L.load() is not None

@@ -74,10 +74,11 @@ def test_slider_options_do_not_rebuild_the_plan(pipe):
     img = _photo(300, 200, 11)
     base = np.asarray(pipe.infer(img, **OPTS))
     n_prep = len(pipe._host_ms["prepare"])
-    graph = pipe.model.graph
+    eng = next(e for (pk, b_, l_), e in pipe._engines.items() if (pk[0], pk[1], b_, l_) == (192, 256, 1, 0))
+    graph = eng.graph
     a = np.asarray(pipe.infer(img, **{**OPTS, "controlnet_scale": 2.25}))
     b = np.asarray(pipe.infer(img, **{**OPTS, "strength": 0.7}))
-    assert len(pipe._host_ms["prepare"]) == n_prep and pipe.model.graph is graph  # nothing was prepared or captured
+    assert len(pipe._host_ms["prepare"]) == n_prep and eng.graph is graph  # nothing was prepared or captured
     assert len(pipe._host_ms["update_options"]) >= 2
     assert not np.array_equal(a, base) and not np.array_equal(b, base)
     # a pipeline built with those options from scratch gives the same frames (another instance times its own tile /
@@ -89,13 +90,19 @@ def test_slider_options_do_not_rebuild_the_plan(pipe):
     assert np.abs(fa.astype(int) - a.astype(int)).mean() < 0.5 and np.abs(fb.astype(int) - b.astype(int)).mean() < 0.5
     assert np.abs(fa.astype(int) - base.astype(int)).mean() > 0.5
     assert np.array_equal(np.asarray(pipe.infer(img, **OPTS)), base)  # and back
-    # two lanes: a launch in flight pins its plan / prompt
+    # two lanes: a launch in flight pins its plan's slider constants (its graph reads them) ...
     h = pipe.submit_batch([img], lane=0, **OPTS)
+    assert pipe.needs_idle(**{**OPTS, "strength": 0.8}) and not pipe.needs_idle(**{**OPTS, "prompt": "another prompt"})
     with pytest.raises(RuntimeError, match="in flight"):
         pipe.submit_batch([img], lane=1, **{**OPTS, "strength": 0.8})
-    with pytest.raises(RuntimeError, match="in flight"):
-        pipe.submit_batch([img], lane=1, **{**OPTS, "prompt": "another prompt"})
+    # ... but not the prompt: every lane reads its own copy of the prompt constants (round 3), so another session's prompt
+    # goes beside it, and the launch in flight still returns ITS frame
+    h2 = pipe.submit_batch([img], lane=1, **{**OPTS, "prompt": "another prompt"})
     assert np.array_equal(np.asarray(pipe.collect_batch(h)[0]), base)
+    other = np.asarray(pipe.collect_batch(h2)[0])
+    assert np.abs(other.astype(int) - base.astype(int)).mean() > 1.0
+    assert np.array_equal(np.asarray(pipe.infer(img, **{**OPTS, "prompt": "another prompt"})), other) or \
+        np.abs(np.asarray(pipe.infer(img, **{**OPTS, "prompt": "another prompt"})).astype(int) - other.astype(int)).mean() < 0.5
     with pytest.raises(ValueError):
         pipe.infer(img, **{**OPTS, "strength": 0.01})  # empty schedule: the caller's error, typed as such
 
@@ -123,6 +130,48 @@ def test_warm_up_prepares_every_batch_size_and_lane_and_two_lanes_do_not_share_s
     assert np.abs(np.asarray(pair[1]).astype(int) - alone[1].astype(int)).mean() < 0.5
     assert len(p._host_ms["prepare"]) == n_prep                               # nothing was prepared after warm_up
     assert p._host_ms["gpu"] and all(0.0 < v < 1e4 for v in p._host_ms["gpu"])  # per-launch device ms from the lane's own events
+
+
+def test_two_sessions_alternate_without_stalls():
+    """VERDICT r2 item 6 (server.py:90-93: options are per VideoSDTrack; :132-137: every session's frames go through the same
+    actors).  Two sessions with different prompts AND sizes alternate frame by frame: after their first frames nothing is
+    prepared, captured or re-encoded again (plans and prompt constants are LRU-cached; a lane takes a cached prompt with one
+    device copy), both lanes may hold different sessions at once, and every frame is the one its session gets alone."""
+    from videosd_amd.pipeline import VideoSDPipeline
+
+    p = VideoSDPipeline(**CFG)
+    sa = dict(OPTS, prompt="a watercolor painting", height=192, width=256)
+    sb = dict(OPTS, prompt="a charcoal sketch", height=256, width=192, steps=3)
+    imgs = [_photo(300, 200, 40 + k) for k in range(4)]
+    want_a = [np.asarray(p.infer(im, **sa)) for im in imgs]
+    want_b = [np.asarray(p.infer(im, **sb)) for im in imgs]
+    n_prep, n_prompt = len(p._host_ms["prepare"]), len(p._host_ms["prompt"])
+    assert n_prep == 2 and n_prompt == 2 and len(p._plans) == 2 and len(p._prompts) == 2
+    for k in range(4):  # A, B, A, B ... on one lane
+        assert np.array_equal(np.asarray(p.infer(imgs[k], **sa)), want_a[k])
+        assert np.array_equal(np.asarray(p.infer(imgs[k], **sb)), want_b[k])
+    # the same prompt on the OTHER program, and the other prompt on this one: still no prepare, no encode
+    x = np.asarray(p.infer(imgs[0], **dict(sa, prompt=sb["prompt"])))
+    assert np.abs(x.astype(int) - want_a[0].astype(int)).mean() > 1.0
+    assert np.array_equal(np.asarray(p.infer(imgs[0], **sa)), want_a[0])
+    assert len(p._host_ms["prepare"]) == n_prep and len(p._host_ms["prompt"]) == n_prompt
+    # both sessions in flight at once (two lanes): lane 1's engines are prepared on first use, then it is free again
+    ha = p.submit_batch([imgs[1]], lane=0, **sa)
+    hb = p.submit_batch([imgs[2]], lane=1, **sb)
+    assert not p.needs_idle(**sa) and not p.needs_idle(**sb)
+    got_b = np.asarray(p.collect_batch(hb)[0])
+    got_a = np.asarray(p.collect_batch(ha)[0])
+    assert np.array_equal(got_a, want_a[1]) and np.abs(got_b.astype(int) - want_b[2].astype(int)).mean() < 0.5
+    # prompt LRU: a third and a fourth prompt evict nothing that is needed (max_prompts = 8); programs: max_plans = 3
+    p.max_prompts = 2
+    p.infer(imgs[0], **dict(sa, prompt="third"))
+    assert list(p._prompts) == [sa["prompt"], "third"] or len(p._prompts) == 2
+    p.max_plans = 2
+    p.infer(imgs[0], **dict(sa, height=128, width=128))  # a third program: the least recently used one (sb's) goes
+    assert len(p._plans) == 2 and not any(pk[0] == 256 for pk in p._plans)
+    n_prep = len(p._host_ms["prepare"])
+    assert np.abs(np.asarray(p.infer(imgs[3], **sb)).astype(int) - want_b[3].astype(int)).mean() < 0.5  # rebuilt on demand
+    assert len(p._host_ms["prepare"]) == n_prep + 1
 
 
 def test_reference_only_mode_through_the_drop_in_class():

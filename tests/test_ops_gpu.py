@@ -504,6 +504,37 @@ def test_absorbed_cross_attention_matches_explicit_attention(ops, m, c, heads):
         ops.conv(h, None, Geom.linear(m), xa1, pr, ln_part=rs, act=L.ACT_SOFTMAX, softmax_cols=tl, tile=1, split_k=1)
 
 
+@pytest.mark.parametrize("c,heads,tl", [(640, 8, 77), (1280, 8, 77), (1280, 20, 77), (128, 8, 50), (640, 10, 128)])
+def test_xattn_fold_on_the_gpu_matches_the_host_packing(ops, c, heads, tl):
+    """vsd_xattn_fold (csrc/prompt_fold.hip: a prompt's K / V folded into the query / output weights of an absorbed
+    cross-attention block, per prompt, on the GPU) against packing.pack_cross_attention (fp32 on the host, what round 2 ran per
+    prompt change): weights to fp16 rounding, ln_s / ln_t to fp32 summation order, zero rows / columns beyond the text length."""
+    from videosd_amd.packing import pack_cross_attention
+
+    ldt = (tl + 63) // 64 * 64
+    k, v = rnd(tl, c, seed=2, scale=1.5), rnd(tl, c, seed=3)
+    wq, wo, bo = rnd(c, c, seed=4, scale=c ** -0.5), rnd(c, c, seed=5, scale=c ** -0.5), rnd(c, seed=6, scale=0.1)
+    gamma, beta = (1 + 0.1 * rnd(c, seed=7).float()).half(), rnd(c, seed=8, scale=0.1)
+    x1, x2 = pack_cross_attention(k.float(), v.float(), wq, wo, bo, gamma, beta, heads)
+    vt = torch.zeros(c, ldt, dtype=torch.float16)
+    vt[:, :tl] = v.t()
+    hg = heads * 128
+    dev = lambda t: t.cuda().contiguous()  # noqa: E731
+    w1 = torch.full((hg, c), 7.0, dtype=torch.float16, device="cuda")   # poisoned: every element must be written
+    s1, t1 = torch.full((hg,), 7.0, device="cuda"), torch.full((hg,), 7.0, device="cuda")
+    w2 = torch.full((c, hg), 7.0, dtype=torch.float16, device="cuda")
+    ops.xattn_fold(dev(k), dev(vt), tl, dev(wq), dev(wo), dev(gamma), dev(beta), c, heads, (c // heads) ** -0.5, w1, s1, t1, w2)
+    ops.synchronize()
+    check(w1, x1.weight[:, :c], "xa1 weights", rel=2e-3)
+    check(w2, x2.weight[:, :hg], "xa2 weights", rel=2e-3)
+    assert float((s1.cpu() - x1.ln_s).abs().max()) <= 2e-3 * float(x1.ln_s.abs().max()) + 1e-4
+    assert float((t1.cpu() - x1.ln_t).abs().max()) <= 1e-4 * float(x1.ln_t.abs().max()) + 1e-5
+    if tl < 128:
+        g = w1.cpu().view(heads, 128, c)
+        assert float(g[:, tl:].abs().max()) == 0.0 and float(w2.cpu().view(c, heads, 128)[:, :, tl:].abs().max()) == 0.0
+        assert float(s1.cpu().view(heads, 128)[:, tl:].abs().max()) == 0.0 and float(t1.cpu().view(heads, 128)[:, tl:].abs().max()) == 0.0
+
+
 def _tail_weights(c=320, seed=0):
     from videosd_amd.packing import pack_conv, pack_geglu_ln, pack_linear, pack_linear_ln
 

@@ -206,3 +206,86 @@ def test_a_respawned_batching_worker_is_warmed_for_every_batch_size_and_lane():
     finally:
         for p in ps:  # (the dispatcher put the replacement into this list)
             p.close()
+
+
+SESSION = FAKE.replace("FakePipeline", "SessionFakePipeline")
+
+
+def test_frames_of_two_sessions_run_beside_each_other():
+    """VERDICT r2 item 6 (server.py:90-93, 132-137): two sessions with different prompts and sizes alternate frame by frame.
+    The worker no longer drains its lanes between them (a pipeline with `needs_idle` decides): launches of both sessions
+    are in flight together; a strength change of a RUNNING plan still waits."""
+    p = RemotePipeline(factory=SESSION, model="m", controlnet="c", batch=2, lanes=2, delay=0.05)
+    try:
+        a = dict(prompt="a red fox", height=48, width=64, strength=0.5, steps=4)
+        b = dict(prompt="a blue whale", height=64, width=48, strength=0.5, steps=4)
+
+        async def go():
+            futs = [p.infer.remote(_img(10 + k), **(a if k % 2 == 0 else b)) for k in range(12)]
+            outs = [await f for f in futs]
+            futs = [p.infer.remote(_img(40 + k), **dict(a, strength=0.5 if k < 3 else 0.7)) for k in range(6)]
+            return outs, [await f for f in futs]
+
+        outs, outs2 = asyncio.run(go())
+        assert [o.size for o in outs] == [(64, 48) if k % 2 == 0 else (48, 64) for k in range(12)]
+        assert len(outs2) == 6  # the strength change drained instead of raising
+        st = p.method("session_state")()
+        assert st["max_mixed"] >= 2  # launches of both sessions were live at the same time
+    finally:
+        p.close()
+
+
+def test_a_dead_group_member_does_not_stall_a_prompt_change():
+    """VERDICT r2 item 7 / ADVICE r2: `__sync_prompt__` used to post the collective to every worker; with one of them dead the
+    survivors sat in the broadcast until the group timeout while `call_timeout` killed them.  Now the dispatcher checks every
+    member when it posts the sync: with a dead one there is no collective, the survivors encode the new prompt themselves,
+    serve it at once, and nobody is killed."""
+    import time
+
+    ws = spawn_workers(3, factory=SESSION, backend="gloo", model="m", controlnet="c", delay=0.01, call_timeout=20.0, sync_timeout=3.0,
+                       crash_on=66)
+    try:
+        async def go():
+            d = FrameDispatcher(ws, depth=4)
+            for k in range(3):
+                d.submit(_img(10 + k), prompt="a red fox", **OPTS)
+            first = [await asyncio.wait_for(d.next_result(), timeout=60) for _ in range(3)]
+            assert all(not isinstance(r[1], Exception) for r in first) and d.prompt_syncs == 1 and d.group_ok
+            # rank 1 dies on a frame (frame k goes to worker k mod 3: this is frame 3 -> worker 0, 4 -> worker 1)
+            d.submit(_img(12), prompt="a red fox", **OPTS)
+            d.submit(_img(66), prompt="a red fox", **OPTS)
+            died = [await asyncio.wait_for(d.next_result(), timeout=60) for _ in range(2)]
+            assert isinstance(died[1][1], WorkerDied) and d.healthy == [True, False, True]
+            t0 = time.time()
+            tickets = [d.submit(_img(20 + k), prompt="a blue whale", **OPTS) for k in range(4)]
+            n = sum(1 for t in tickets if t is not None)
+            res = [await asyncio.wait_for(d.next_result(), timeout=30) for _ in range(n)]
+            dt = time.time() - t0
+            assert n >= 3 and all(not isinstance(r[1], Exception) for r in res), res
+            st = [await ws[g].method("session_state").remote() for g in (0, 2)]
+            return dt, d.healthy, d.worker_faults, st, d.group_ok
+
+        dt, healthy, faults, st, group_ok = asyncio.run(go())
+        assert dt < 10.0                       # far below the 120 s group timeout and the 20 s call_timeout
+        assert healthy == [True, False, True] and faults == 1   # the survivors were not killed
+        assert group_ok is False
+        assert all("a blue whale" in s["prompts"] for s in st)  # each survivor encoded the new prompt itself
+    finally:
+        for w in ws:
+            w.close()
+
+
+def test_rank0_tuning_choices_reach_every_rank():
+    """shapes missing from the shipped table used to be tuned per worker -- two ranks could pick different
+    tiles / split-K and return different bits for the same frame.  `spawn_workers(warm_options=...)`: rank 0 warms up first,
+    its choices are broadcast (`__sync_tuning__`), the others take them before preparing their own plans."""
+    ws = spawn_workers(2, factory=SESSION, backend="gloo", model="m", controlnet="c", batch=2, warm_options=dict(OPTS))
+    try:
+        st = [w.method("session_state")() for w in ws]
+        r0 = {k: v for k, v in st[0]["tuning"].items()}
+        # everything rank 0 knew (its table entry and what its warm-up measured) is now on rank 1, unchanged
+        assert all(st[1]["tuning"].get(k) == v for k, v in r0.items())
+        assert ("warmed", (1, 2), 2) in st[1]["tuning"] and st[1]["tuning"][("warmed", (1, 2), 2)] == ("by", 0)
+    finally:
+        for w in ws:
+            w.close()

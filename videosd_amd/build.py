@@ -9,12 +9,15 @@ LIB = os.path.join(HERE, "libvsd.so")
 # the implicit-GEMM conv kernel is a template with ~60 instantiations: one translation unit per tile family, so that
 # the families compile in parallel (as one file the library took 4.5 minutes to build)
 SOURCES = ["api.hip", "conv_gemm.hip", "conv_t128x128.hip", "conv_t128x64.hip", "conv_t64x64.hip", "conv_t64x128.hip",
-           "conv_t256x128.hip", "conv_halo.hip", "conv_skinny.hip", "conv_resident.hip", "fused_tail.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+           "conv_t256x128.hip", "conv_halo.hip", "conv_skinny.hip", "conv_resident.hip", "fused_tail.hip", "norm.hip", "attention.hip", "elementwise.hip", "prompt_fold.hip"]
 HEADERS = ["common.h", "conv_kernels.h", os.path.join("..", "..", "include", "vsd.h")]
 # attention keeps its O / S accumulators live across the key loop and touches them with VALU every tile (online-softmax
 # rescale, exp): with the default AGPR placement the compiler moves them through v_accvgpr_read/write every tile
 # (~190 of 1300 instructions in the d=40 kernel); VGPR-form MFMA operands remove those moves.
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# conv_t256x128: 128 accumulator registers + 96 of fragments per wave; in the default (AGPR) form the compiler shuffled the
+# accumulators through AGPR copies inside the interleaved main loop (340 v_accvgpr moves per K tile, 396 registers);
+# VGPR form: 230 / 274 registers, 5 moves.
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "conv_t256x128.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _obj(f: str) -> str:
@@ -88,8 +91,29 @@ def build_probe(verbose: bool = False) -> str:
     return out
 
 
+def build_timeline(verbose: bool = False) -> str:
+    """videosd_amd/libvsd_tl.so: the whole library built with -DVSD_WG_TIMELINE (csrc/common.h): the conv kernels log every
+    workgroup's start / end time and placement.  Development tool (scripts/wg_timeline.py loads it through VSD_LIB)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.join(HERE, "libvsd_tl.so")
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    procs, objs = [], []
+    for f in SOURCES:
+        o = os.path.join(HERE, "build", "tl_" + f.replace(".hip", ".o"))
+        objs.append(o)
+        procs.append((subprocess.Popen([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-DVSD_WG_TIMELINE", "-w"] +
+                                       EXTRA_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", o]), f))
+    for p, f in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {f}")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 if __name__ == "__main__":
-    if "--probe" in sys.argv:
+    if "--timeline" in sys.argv:
+        print(build_timeline())
+    elif "--probe" in sys.argv:
         print(build_probe())
     else:
         build(force="--force" in sys.argv)

@@ -3,7 +3,8 @@
 
 #include "common.h"
 
-extern "C" int vsd_version(void) { return 1; }
+extern "C" int vsd_version(void) { return VSD_VERSION; }
+extern "C" int vsd_conv_desc_size(void) { return (int)sizeof(vsd_conv_desc); }
 
 extern "C" vsd_ctx* vsd_create(int device_id) {
   int n = 0;

@@ -94,3 +94,35 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 __device__ __forceinline__ float quick_gelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Workgroup timeline (development builds only: -DVSD_WG_TIMELINE, videosd_amd.build.build_timeline): every workgroup of the
+// instrumented kernels leaves its start / main-loop-done / end time (s_memrealtime, 100 MHz) and where it ran (HW_ID,
+// XCC_ID) in a log buffer, one region per launch [grid, kind, 8 words per workgroup ...], so that a launch's duration can
+// be split into dispatch ramp, workgroup life and tail (scripts/wg_timeline.py).  Never compiled into libvsd.so.
+#ifdef VSD_WG_TIMELINE
+inline unsigned long long* g_wgtl = nullptr;
+inline size_t g_wgtl_off = 0, g_wgtl_cap = 0;
+static inline unsigned long long* wgtl_claim(int grid) {  // host: the next launch's region (nullptr: logging off / log full)
+  if (!g_wgtl || g_wgtl_off + 2 + 8 * (size_t)grid > g_wgtl_cap) return nullptr;
+  unsigned long long* r = g_wgtl + g_wgtl_off + 2;
+  g_wgtl_off += 2 + 8 * (size_t)grid;
+  return r;
+}
+#define WGTL_START() const unsigned long long wgtl_t0 = __builtin_amdgcn_s_memrealtime(); unsigned long long wgtl_t1 = 0, wgtl_ta = 0, wgtl_tb = 0, wgtl_tc = 0;
+#define WGTL_LOOP() wgtl_t1 = __builtin_amdgcn_s_memrealtime();
+#define WGTL_MARK(W_) wgtl_t##W_ = __builtin_amdgcn_s_memrealtime();  /* W_ = a, b or c: further points inside the epilogue */
+#define WGTL_END(KIND_)                                                                                   \
+  if (p.wgtl && threadIdx.x == 0) {                                                                       \
+    unsigned long long* d_ = p.wgtl + 8 * (size_t)blockIdx.x;                                             \
+    d_[0] = wgtl_t0; d_[1] = wgtl_t1; d_[2] = __builtin_amdgcn_s_memrealtime();                           \
+    d_[4] = wgtl_ta; d_[5] = wgtl_tb; d_[6] = wgtl_tc;                                                    \
+    d_[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                               \
+            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);                       \
+    if (blockIdx.x == 0) { p.wgtl[-2] = gridDim.x; p.wgtl[-1] = (KIND_); }                                \
+  }
+#else
+#define WGTL_START()
+#define WGTL_LOOP()
+#define WGTL_MARK(W_)
+#define WGTL_END(KIND_)
+#endif

@@ -5,6 +5,12 @@
 #ifdef VSD_CONV_PROBE
 extern "C" void vsd_conv_set_probe(void* buf) { g_conv_probe = (long long*)buf; }
 #endif
+#ifdef VSD_WG_TIMELINE
+// development builds only (common.h): `buf` = device memory of `words` 8-byte words, zero-filled; every instrumented launch
+// appends [grid, kind, 4 words per workgroup]; returns the words used so far
+extern "C" void vsd_wgtl_set(void* buf, int64_t words) { g_wgtl = (unsigned long long*)buf; g_wgtl_cap = (size_t)words; g_wgtl_off = 0; }
+extern "C" int64_t vsd_wgtl_used(void) { return (int64_t)g_wgtl_off; }
+#endif
 
 extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream) {
   if (!ctx || !d) return VSD_ERR_ARG;
@@ -37,6 +43,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
              d->ksize * d->ksize <= 32 && !getenv("VSD_CONV_NO_FAST");
   }
   p.w = (const half_t*)d->weight;
+  p.pointwise = d->ksize == 1 && d->stride == 1 && d->pad == 0 && !p.resize && d->ho == d->hs && d->wo == d->ws;
   p.batch = d->batch < 1 ? 1 : d->batch;
   p.hw_out = d->ho * d->wo;
   p.img_in = d->hs * d->ws;
@@ -61,6 +68,9 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.zeros = (const half_t*)ctx->zero_page;
 #ifdef VSD_CONV_PROBE
   p.probe = g_conv_probe;
+#endif
+#ifdef VSD_WG_TIMELINE
+  p.wgtl = nullptr;
 #endif
   p.rowstat_out = (float*)d->rowstat_out;
   p.chanstat_part = (float*)d->chanstat_part;
@@ -198,6 +208,9 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     static const char* force = getenv("VSD_CONV_ORDER");
     p.order = force ? atoi(force) : (by_a < by_w ? 1 : 0);
   }
+#ifdef VSD_WG_TIMELINE
+  p.wgtl = wgtl_claim(grid);
+#endif
   {
     LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
     if (halo) vsd_launch_conv_halo(p, BM, BN, grid, s);

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
 template <int BN, int WMN, int NSB>
 __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p) {
   prefetch_kernargs();
+  WGTL_START()
   constexpr int NW = 2 * WMN, NT = 64 * NW;
   constexpr int BM = 64 * WMN, PW = 16, PH = 4 * WMN, HW_ = PW + 2;  // halo row length 18
   constexpr int HUSED = (PH + 2) * HW_;                                // 180 / 324 halo rows
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p
 #undef HALO_ISSUE_A_PIECE
 #undef HALO_ISSUE_B
   __syncthreads();  // every wave is done reading the tiles before the epilogue reuses the LDS
+  WGTL_LOOP()
 
   // ---- epilogue.  Residual and bias + time vector are loaded before the accumulator transpose (and any store).
   constexpr int CH = BN / 8;
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p
         *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8 + 4);
       }
     }
+    WGTL_END(1)
     return;
   }
   const int act = p.act & 0xff;
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p
   else finish(std::integral_constant<int, 0>{});
   CPROBE(6)
   CPROBE_OUT()
+  WGTL_END(1)
 }
 
 }  // namespace

@@ -36,6 +36,7 @@ struct ConvParams {
   int rshift;
   int generic;  // cin % 64 != 0: per-chunk tap computation
   int fast;     // buffer-load address path usable: !generic, no resize, every operand < 2 GB
+  int pointwise;  // ksize 1, stride 1, no padding, no resize: output row m reads source pixel m (no per-row index arithmetic)
   int halo_ok;  // the same without the "no resize" condition (the halo kernel folds the nearest resize into its patch fetch)
   const half_t* w;
   int M, N, K, Kp;
@@ -71,6 +72,9 @@ struct ConvParams {
 #ifdef VSD_CONV_PROBE
   long long* probe;  // scripts/conv_probe.cpp: per-section shader-clock totals of wave 0 of workgroup 0
 #endif
+#ifdef VSD_WG_TIMELINE
+  unsigned long long* wgtl;  // scripts/wg_timeline.py: per workgroup {start, main loop done, end} in 10 ns ticks + hardware id
+#endif
   int softmax_cols;  // VSD_ACT_SOFTMAX: valid columns of every 128-column group
   int batch;    // images stacked along M: M = batch * ho * wo, image b's source pixels start at b * hs * ws
   int hw_out;   // ho * wo
@@ -97,6 +101,7 @@ inline long long* g_conv_probe = nullptr;
 #endif
 
 
+
 // launchers of the tile families (one translation unit each; conv_gemm.hip dispatches)
 void vsd_launch_conv_128x128(const ConvParams& p, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_128x64(const ConvParams& p, int grid, int stages, hipStream_t s);
@@ -112,15 +117,23 @@ void vsd_launch_conv_resident(const ConvParams& p, int patches, hipStream_t s); 
 namespace {
 
 // ---------------------------------------------------------------- epilogue (shared with the reducer)
+// has_res / res_val, has_brv / brv_lo, brv_hi: the residual chunk / bias + rowvec of these 8 columns when the caller loaded
+// them BEFORE its first store (vmcnt counts stores too: a load issued after a store is only waited for once that store has
+// retired).  Passed BY VALUE: the earlier form took `flag ? &array[j] : nullptr`, and that conditional address-of kept the
+// caller's arrays in scratch memory (112 bytes per lane in every instantiation: the "prefetched" residual was stored to
+// scratch as soon as it was loaded -- a full memory latency exposed in front of the accumulator transpose -- and read back
+// from scratch inside the walk; found with scripts/wg_timeline.py: half of a short-K workgroup's life was its epilogue).
 __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int n, float (&v)[8], float& rsum, float& rsq,
-                                                const half8* res_pre = nullptr, const float* brv_pre = nullptr) {
+                                                const bool has_res, const half8 res_val, const bool has_brv, const f32x4 brv_lo,
+                                                const f32x4 brv_hi) {
   // n is a multiple of 8; handles n + 8 > N by scalar fallback
-  // res_pre / brv_pre: the residual chunk / bias + rowvec of these 8 columns, loaded by the caller BEFORE its first
-  // store (vmcnt counts stores too: a load issued after a store is only waited for once that store has retired)
   const bool full = (n + 8 <= p.N);
-  if (brv_pre) {
+  if (has_brv) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += brv_pre[i];
+    for (int i = 0; i < 4; ++i) {
+      v[i] += brv_lo[i];
+      v[4 + i] += brv_hi[i];
+    }
   } else {
   if (p.bias) {
     if (full) {
@@ -178,7 +191,8 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
   }
   if (full) {
     if (p.residual) {
-      half8 r = res_pre ? *res_pre : *reinterpret_cast<const half8*>(p.residual + (size_t)m * p.ldr + n);
+      half8 r = res_val;
+      if (!has_res) r = *reinterpret_cast<const half8*>(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] += (float)r[i];
     }
@@ -221,25 +235,45 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
   }
 }
 
+__device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int n, float (&v)[8], float& rsum, float& rsq) {
+  const half8 z8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+  const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  epilogue_store8(p, m, n, v, rsum, rsq, false, z8, false, z4, z4);
+}
+
 // Fused input LayerNorm: the GEMM ran on the raw rows x with W' = W*gamma, so
 //   LN(x) W^T + b = rstd * (x W'^T - mean * s) + t,   s[n] = sum_k W'[n][k],  t[n] = sum_k beta[k] W[n][k] + b[n].
 // Row mean / rstd come from the (sum, sumsq) partials the producing kernel's epilogue left per 64-column group.
 __device__ __forceinline__ void ln_row_stats(const ConvParams& p, int m, float& mean, float& rstd) {
-  // partials of one row are contiguous: [M][ln_groups][2]; ln_groups is a multiple of... anything >= 1
+  // partials of one row are contiguous: [M][ln_groups][2].  ALL of a row's loads are issued before the first is consumed
+  // (one memory round trip: the first form fetched them four at a time -- five dependent round trips for a 1280-wide row,
+  // 3-4 us in front of the main loop of every LayerNorm-consuming GEMM by scripts/wg_timeline.py); the sums run in
+  // group order either way (bit-identical).
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const f32x2* src = reinterpret_cast<const f32x2*>(p.ln_part) + (size_t)m * p.ln_groups;
   float S = 0.f, Q = 0.f;
-  int g = 0;
-  for (; g + 4 <= p.ln_groups; g += 4) {  // four independent loads in flight
-    f32x2 a = src[g], b = src[g + 1], c = src[g + 2], d = src[g + 3];
-    S += a[0]; Q += a[1];
-    S += b[0]; Q += b[1];
-    S += c[0]; Q += c[1];
-    S += d[0]; Q += d[1];
-  }
-  for (; g < p.ln_groups; ++g) {
-    f32x2 a = src[g];
-    S += a[0]; Q += a[1];
+  const int G = p.ln_groups;
+  auto batch = [&](auto n_tag) __attribute__((always_inline)) {
+    constexpr int NG = decltype(n_tag)::value;
+    f32x2 a[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) a[g] = src[g < G ? g : 0];  // (clamped: the surplus loads hit the row's first line)
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (g < G) {
+        S += a[g][0];
+        Q += a[g][1];
+      }
+  };
+  if (G <= 5) batch(std::integral_constant<int, 5>{});
+  else if (G <= 10) batch(std::integral_constant<int, 10>{});
+  else if (G <= 20) batch(std::integral_constant<int, 20>{});
+  else {
+    for (int g = 0; g < G; ++g) {
+      f32x2 a = src[g];
+      S += a[0];
+      Q += a[1];
+    }
   }
   const float inv = 1.0f / (float)p.K;
   mean = S * inv;
@@ -358,6 +392,7 @@ __device__ __forceinline__ void block_to_tile(const ConvParams& p, int bid, int&
 template <int BM, int BN, bool GENERIC, int STAGES, bool ILV, bool FAST>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   prefetch_kernargs();
+  WGTL_START()
   constexpr int WM = 2, WN = 2;             // 2x2 waves
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   constexpr int FM = TM / 16, FN = TN / 16;  // 16x16 fragments per wave
@@ -394,20 +429,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   const int lr = tid >> 3;   // 0..31
   int iy0[AR], ix0[AR], ib[AR];  // ib: first source pixel of the row's image
   bool mvalid[AR];
+  // (a pointwise layer on the buffer-load path needs none of this: its row m reads source pixel m -- two integer divisions
+  // per row, ~0.3 us of a short-K workgroup's prologue)
+  const bool pointwise = FAST && p.pointwise;
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     int m = m0 + lr + 32 * i;
     mvalid[i] = m < p.M;
-    int mm = mvalid[i] ? m : 0;
-    int b = 0;
-    if (p.batch > 1) {
-      b = mm / p.hw_out;
-      mm -= b * p.hw_out;
+    ib[i] = iy0[i] = ix0[i] = 0;
+    if (!pointwise) {
+      int mm = mvalid[i] ? m : 0;
+      int b = 0;
+      if (p.batch > 1) {
+        b = mm / p.hw_out;
+        mm -= b * p.hw_out;
+      }
+      ib[i] = b * p.img_in;
+      int oy = mm / p.wo, ox = mm - oy * p.wo;
+      iy0[i] = oy * p.stride - p.pad;
+      ix0[i] = ox * p.stride - p.pad;
     }
-    ib[i] = b * p.img_in;
-    int oy = mm / p.wo, ox = mm - oy * p.wo;
-    iy0[i] = oy * p.stride - p.pad;
-    ix0[i] = ox * p.stride - p.pad;
   }
   const half_t* wrow[BR];
   bool nvalid[BR];
@@ -557,6 +598,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     if constexpr (FAST) {
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
+        if (pointwise) {
+          apix[i] = mvalid[i] ? m0 + lr + 32 * i : 0;
+          tapmask[i] = mvalid[i] ? 1u : 0u;
+          continue;
+        }
         apix[i] = ib[i] + (iy0[i] + p.pad) * p.ws + (ix0[i] + p.pad);
         unsigned mk = 0;
         for (int ky = 0; ky < p.ksize; ++ky)
@@ -657,6 +703,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         }
       VSD_LN_ROWSTATS()
       CPROBE(0)
+      WGTL_MARK(c)
       int slot = 0;
       for (int t = 0; t < nt; ++t) {
         // tile t has landed once all but the younger tiles' loads are done; then everyone's has (barrier)
@@ -713,6 +760,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         else VSD_ISSUE_TILE(min(kt_begin + st, kt_last), st)
       }
       VSD_LN_ROWSTATS()
+      WGTL_MARK(c)
       int slot = 0;
       constexpr int NM = FM * FN * 2;       // MFMAs per tile per wave
       for (int t = 0; t < nt; ++t) {
@@ -793,7 +841,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             const half_t* g_ = ok ? src_ + ((size_t)(ib[i] + sy * p.ws + sx)) * cs_ + c_ : p.zeros;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(na + (8 * wave + 32 * i) * BK), 16, 0, 0);
           }
-          if (pc == 0) {
+          // (256-row tiles: both k-steps' fragments live at once are 96 registers on top of 128 accumulators -- the compiler then
+          //  shuffles accumulators through AGPR copies inside the loop (340 v_accvgpr moves per tile seen); their k-step-1
+          //  fragments are therefore read two pieces before they are needed instead of at the top)
+          if (pc == (BM >= 256 ? LPT / 2 - 2 : 0)) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
               int r = wm * TM + i * 16 + fr;
@@ -840,6 +891,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   // each chunk's residual inside that walk exposes one full memory round trip PER CHUNK (measured: 7.4k of the 17k
   // cycles a 128x64 workgroup of a K=320 layer lives).  The addresses do not depend on the GEMM, so the loads are
   // issued here, before the accumulator transpose, and land while it and its barrier run.
+  WGTL_LOOP()
   constexpr int CHP = BN / 8;
   constexpr int NITP = BM * CHP / 256;
   constexpr int NPRE = NITP <= 8 ? NITP : 8;
@@ -866,9 +918,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }
   }
   half8 braw = (half8){0, 0, 0, 0, 0, 0, 0, 0}, rvraw = braw;
+  f32x4 lns0 = (f32x4){0.f, 0.f, 0.f, 0.f}, lns1 = lns0, lnt0 = lns0, lnt1 = lns0;  // fused input LayerNorm: s / t of these columns
   if (use_brv) {
     if (p.bias) braw = *reinterpret_cast<const half8*>(p.bias + pre_n);
     if (p.rowvec) rvraw = *reinterpret_cast<const half8*>(p.rowvec + pre_n);
+    if (p.ln_part) {
+      lns0 = *reinterpret_cast<const f32x4*>(p.ln_s + pre_n);
+      lns1 = *reinterpret_cast<const f32x4*>(p.ln_s + pre_n + 4);
+      lnt0 = *reinterpret_cast<const f32x4*>(p.ln_t + pre_n);
+      lnt1 = *reinterpret_cast<const f32x4*>(p.ln_t + pre_n + 4);
+    }
   }
 
   // ---- epilogue: accumulators -> LDS (fp32) -> row-contiguous 8-wide chunks
@@ -884,8 +943,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       for (int r = 0; r < 4; ++r) Cs[(row + r) * BNP + col] = acc[i][j][r];
     }
   __syncthreads();
+  WGTL_MARK(a)
 #pragma unroll
   for (int i = 0; i < 8; ++i) brv[i] = (float)braw[i] + (float)rvraw[i];
+  WGTL_MARK(b)
 
   CPROBE(5)
   bool from_slabs = false;
@@ -921,7 +982,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
           }
       }
     }
-    if (!p.counters) return;  // two-kernel form: splitk_reduce_kernel finishes the job
+    if (!p.counters) { WGTL_END(0) return; }  // two-kernel form: splitk_reduce_kernel finishes the job
     // In-launch reduction: the LAST workgroup to arrive at this tile sums the slabs and runs the epilogue.
     // Write-through slab stores, every wave drains them (vmcnt(0)), barrier, one relaxed agent-scope ticket;
     // agent-scope acquire on the reducer
@@ -941,7 +1002,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       *lastflag = last;
     }
     __syncthreads();
-    if (!*lastflag) return;
+    if (!*lastflag) { WGTL_END(0) return; }
     from_slabs = true;
   }
 
@@ -980,6 +1041,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       int n = (n0 >> 1) + c8;
       if (n < no) *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
     }
+    WGTL_END(0)
     return;
   }
 
@@ -1028,67 +1090,161 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         if (m < p.M) *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o8;
       }
     }
+    WGTL_END(0)
     return;
   }
 
   const bool transposed_tile = p.out_t && n0 >= p.t_col0;
+  const bool use_brv_all = (p.act & 0xff) != VSD_ACT_GEGLU && (p.act & 0xff) != VSD_ACT_SOFTMAX;  // (brv / lns hold zeros for a thread whose columns lie beyond N: it stores nothing)
   if (transposed_tile) {
-    // lanes run along m so that the 2-byte transposed stores coalesce
-    constexpr int CH = BN / 8;
-    for (int q = tid; q < BM * CH; q += 256) {
-      int r = q % BM, c8 = (q / BM) * 8;
-      int m = m0 + r, n = n0 + c8;
-      if (m >= p.M || n >= p.N) continue;
+    // V^T tiles (the attention V operand is produced transposed: out_t[n - t_col0][column of row m]).  A thread owns ONE
+    // output column n and 8 consecutive rows m: the 8 values are one 16-byte piece of an out_t row.  The first form of
+    // this path (a thread = one row, eight 2-byte stores) issued 8x the store instructions of an ordinary tile: the V
+    // third of the qkv projection took as long as the Q and K thirds together.  Lane -> (column = lane % 16, row chunk =
+    // lane / 16): a wave's store instruction writes 16 out_t rows x 64 contiguous bytes; the LDS reads of the fp32 tile
+    // (column-wise: a row chunk is 8 * BNP floats = 0 mod 32 banks away) are 2-way conflicted ds_read_b32.
+    constexpr int MCH = BM / 8;  // row chunks of the tile
+    const int act_t = (p.act & VSD_ACT_POST) ? VSD_ACT_NONE : (p.act & 0xff);  // (as epilogue_store8: no residual, no post-activation here)
+    const float sc_t = p.out_scale_dev ? *p.out_scale_dev : p.out_scale;
+    const bool vec_ok = (p.hw_out & 7) == 0 && (p.t_img & 7) == 0 && (p.ldt & 7) == 0 && ((size_t)p.out_t & 15) == 0;
+    for (int q = tid; q < BN * MCH; q += 256) {
+      const int cl = q & 15, rest = q >> 4;
+      const int rc = rest % MCH, cg = rest / MCH;
+      const int c = cg * 16 + cl, r8 = rc * 8;
+      const int n = n0 + c, m = m0 + r8;
+      if (n >= p.N || m >= p.M) continue;
       float v[8];
       if (from_slabs) {
-        load_chunk8(p, Cs, BNP, true, r, c8, m, n, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float a = 0.f;
+          if (m + i < p.M)
+            for (int k = 0; k < p.split_k; ++k) a += p.ws_partial[((size_t)k * p.M + m + i) * p.N + n];
+          v[i] = a;
+        }
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = Cs[r * BNP + c8 + i];
+        for (int i = 0; i < 8; ++i) v[i] = Cs[(r8 + i) * BNP + c];
       }
-      if (p.ln_part) ln_transform8(p, n, rowms[2 * r], rowms[2 * r + 1], v);
-      float rs = 0.f, rq = 0.f;
-      epilogue_store8(p, m, n, v, rs, rq);
+      if (p.ln_part) {
+        const float s_n = p.ln_s[n], t_n = p.ln_t[n];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = rowms[2 * (r8 + i) + 1] * (v[i] - rowms[2 * (r8 + i)] * s_n) + t_n;
+      }
+      float add = 0.f;
+      if (p.bias) add += (float)p.bias[n];
+      if (p.rowvec) add += (float)p.rowvec[n];
+      half8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float x = v[i] + add;
+        if (act_t == VSD_ACT_RELU) x = fmaxf(x, 0.f);
+        else if (act_t == VSD_ACT_SILU) x = silu_f(x);
+        else if (act_t == VSD_ACT_QUICKGELU) x = quick_gelu_f(x);
+        o[i] = (half_t)(x * sc_t);
+      }
+      half_t* row = p.out_t + (size_t)(n - p.t_col0) * p.ldt;
+      int b = 0, mm = m;
+      if (p.batch > 1) {
+        b = m / p.hw_out;
+        mm = m - b * p.hw_out;
+      }
+      if (vec_ok && m + 8 <= p.M) {  // the 8 rows lie in one image (hw_out % 8 == 0) and the piece is 16-byte aligned
+        *reinterpret_cast<half8*>(row + (size_t)b * p.t_img + mm) = o;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int mi = m + i;
+          if (mi < p.M) {
+            int col = mi;
+            if (p.batch > 1) {
+              const int bi = mi / p.hw_out;
+              col = bi * p.t_img + (mi - bi * p.hw_out);
+            }
+            row[col] = o[i];
+          }
+        }
+      }
     }
-  } else if (!p.ln_part && !p.rowstat_out && !p.chanstat_out && !p.out2 && !p.residual2 && !from_slabs &&
-             p.out_scale == 1.0f && !p.out_scale_dev && (p.N & 7) == 0 && NITP <= NPRE && (!p.residual || use_pre)) {
-    // ---- the common epilogue (bias / time vector, one activation, one residual), specialised per activation: the
-    // general loop below tests ~25 uniform flags per 8-wide chunk and inlines every activation twice (15k instructions
-    // per kernel); for the short-K layers that walk was 40 % of the workgroup's life
+  } else if (!p.chanstat_out && !p.out2 && !p.residual2 && !from_slabs && (p.N & 7) == 0 && NITP <= NPRE &&
+             (!p.residual || use_pre) && use_brv_all &&
+             ((!p.ln_part && !p.rowstat_out) || (p.act & 0xff) == VSD_ACT_NONE)) {
+    // ---- the epilogues the networks actually run, each as its own straight-line walk: bias / time vector, one
+    // activation, a scale, one residual; and (activation none) the fused LayerNorm of the input and / or the row
+    // statistics of the output.  The general loop below tests ~25 uniform flags per 8-wide chunk, inlines every
+    // activation twice and falls back to scalar code for ragged N (15k instructions, 1.3k branches per kernel): by
+    // scripts/wg_timeline.py a 64x128 workgroup spent 4.6 us in it against 1.0 us here -- 40 % of a short-K workgroup's life.
     constexpr int CH = BN / 8;
-    auto simple = [&](auto act_tag) __attribute__((always_inline)) {
+    const float sc = p.out_scale_dev ? *p.out_scale_dev : p.out_scale;  // (x * 1.0f is exact: no separate unscaled form)
+    const float lns[8] = {lns0[0], lns0[1], lns0[2], lns0[3], lns1[0], lns1[1], lns1[2], lns1[3]};
+    const float lnt[8] = {lnt0[0], lnt0[1], lnt0[2], lnt0[3], lnt1[0], lnt1[1], lnt1[2], lnt1[3]};
+    auto walk = [&](auto act_tag, auto ln_tag, auto rs_tag) __attribute__((always_inline)) {
       constexpr int ACT = decltype(act_tag)::value;  // 0 none, 1 relu, 2 silu, 3 relu AFTER the residual, 4 quick-gelu
+      constexpr bool LN = decltype(ln_tag)::value, RS = decltype(rs_tag)::value;
 #pragma unroll
       for (int j = 0; j < NITP; ++j) {
         const int q = tid + j * 256;
         const int r = q / CH, c8 = (q - r * CH) * 8;
         const int m = m0 + r, n = n0 + c8;
-        if (m < p.M && n < p.N) {
+        const bool valid = m < p.M && n < p.N;
+        float rs = 0.f, rq = 0.f;
+        if (valid) {
           f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8);
           f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8 + 4);
           float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          float mean = 0.f, rstd = 0.f;
+          if (LN) {
+            mean = rowms[2 * r];
+            rstd = rowms[2 * r + 1];
+          }
           half8 o;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            float x = v[i] + brv[i];
+            float x = v[i];
+            if (LN) x = rstd * (x - mean * lns[i]) + lnt[i];
+            x += brv[i];
             if (ACT == 1) x = fmaxf(x, 0.f);
             if (ACT == 2) x = silu_f(x);
             if (ACT == 4) x = quick_gelu_f(x);
+            x *= sc;
             if (p.residual) x += (float)rpre[j < NPRE ? j : 0][i];
             if (ACT == 3) x = fmaxf(x, 0.f);
             o[i] = (half_t)x;
+            if (RS) {  // statistics of the STORED (rounded) values
+              const float f = (float)o[i];
+              rs += f;
+              rq += f * f;
+            }
           }
           *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
+        }
+        if (RS) {
+          // the 8 lanes of one (row, 64-column group) are consecutive: fold their sums and let the first write
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) {
+            rs += __shfl_xor(rs, o);
+            rq += __shfl_xor(rq, o);
+          }
+          if ((tid & 7) == 0 && valid) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<f32x2*>(p.rowstat_out + ((size_t)m * (p.N >> 6) + (n >> 6)) * 2) = (f32x2){rs, rq};
+          }
         }
       }
     };
     const int act = p.act & 0xff;
     const bool post = (p.act & VSD_ACT_POST) != 0;
-    if (act == VSD_ACT_NONE) simple(std::integral_constant<int, 0>{});
-    else if (act == VSD_ACT_RELU && !post) simple(std::integral_constant<int, 1>{});
-    else if (act == VSD_ACT_SILU && !post) simple(std::integral_constant<int, 2>{});
-    else if (act == VSD_ACT_RELU && post) simple(std::integral_constant<int, 3>{});
-    else if (act == VSD_ACT_QUICKGELU && !post) simple(std::integral_constant<int, 4>{});
+    using T = std::true_type;
+    using F = std::false_type;
+    if (act == VSD_ACT_NONE) {
+      if (p.ln_part && p.rowstat_out) walk(std::integral_constant<int, 0>{}, T{}, T{});
+      else if (p.ln_part) walk(std::integral_constant<int, 0>{}, T{}, F{});
+      else if (p.rowstat_out) walk(std::integral_constant<int, 0>{}, F{}, T{});
+      else walk(std::integral_constant<int, 0>{}, F{}, F{});
+    } else if (act == VSD_ACT_RELU && !post) walk(std::integral_constant<int, 1>{}, F{}, F{});
+    else if (act == VSD_ACT_SILU && !post) walk(std::integral_constant<int, 2>{}, F{}, F{});
+    else if (act == VSD_ACT_RELU && post) walk(std::integral_constant<int, 3>{}, F{}, F{});
+    else if (act == VSD_ACT_QUICKGELU && !post) walk(std::integral_constant<int, 4>{}, F{}, F{});
     else {  // (activation after the residual other than ReLU: not used by the networks; keep it correct)
 #pragma unroll
       for (int j = 0; j < NITP; ++j) {
@@ -1104,6 +1260,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }
   } else {
     constexpr int CH = BN / 8;
+    const f32x4 brv_lo = (f32x4){brv[0], brv[1], brv[2], brv[3]}, brv_hi = (f32x4){brv[4], brv[5], brv[6], brv[7]};
     float cs[8], cq[8];  // this thread's 8 columns (fixed: c8 = (tid % CH) * 8), summed over its rows
 #pragma unroll
     for (int i = 0; i < 8; ++i) cs[i] = cq[i] = 0.f;
@@ -1118,7 +1275,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         float v[8];
         load_chunk8(p, Cs, BNP, from_slabs, r, c8, m, n, v);
         if (p.ln_part) ln_transform8(p, n, rowms[2 * r], rowms[2 * r + 1], v);
-        epilogue_store8(p, m, n, v, rs, rq, (use_pre && j < NPRE) ? &rpre[j < NPRE ? j : 0] : nullptr, use_brv ? brv : nullptr);
+        epilogue_store8(p, m, n, v, rs, rq, use_pre && j < NPRE, rpre[j < NPRE ? j : 0], use_brv, brv_lo, brv_hi);
         if (p.chanstat_out) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -1197,6 +1354,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   }
   CPROBE(6)
   CPROBE_OUT()
+  WGTL_END(0)
 }
 
 // the FAST form exists for the direct-to-LDS rings only (STAGES >= 3)

@@ -82,9 +82,13 @@ PROMPT_HEADER_KEYS = ["epoch", "height", "width", "steps", "strength", "controln
 
 
 def broadcast_prompt(embeds: Optional[torch.Tensor], header: Optional[Dict[str, float]] = None, src: int = 0,
-                     device: Optional[torch.device] = None, shape=(77, 768)):
+                     device: Optional[torch.device] = None, shape=(77, 768), timeout: Optional[float] = None):
     """Rank `src` passes the prompt embeddings [77, cross_dim] (and an options header); every rank returns them.
-    One small header broadcast + one 118 KB payload broadcast; the only collective on the path."""
+    One small header broadcast + one 118 KB payload broadcast; the only collective on the path.
+    timeout (seconds): give up with a RuntimeError when a broadcast has not completed by then -- a member that died leaves
+    the others here, and a prompt change must not hold their frames for the process group's own timeout (minutes)."""
+    import datetime
+
     import torch.distributed as dist
 
     keys = PROMPT_HEADER_KEYS
@@ -95,8 +99,17 @@ def broadcast_prompt(embeds: Optional[torch.Tensor], header: Optional[Dict[str, 
         buf = embeds.to(device=device, dtype=torch.float16).reshape(shape).contiguous()
     else:
         buf = torch.zeros(shape, dtype=torch.float16, device=device)
-    dist.broadcast(hdr, src=src)
-    dist.broadcast(buf, src=src)
+    for t in (hdr, buf):
+        if timeout is None:
+            dist.broadcast(t, src=src)
+        else:
+            work = dist.broadcast(t, src=src, async_op=True)
+            try:
+                done = work.wait(datetime.timedelta(seconds=float(timeout)))
+            except Exception as e:  # gloo raises on the deadline; RCCL may too
+                raise RuntimeError(f"prompt broadcast failed or timed out after {timeout} s: {e}") from None
+            if done is False:
+                raise RuntimeError(f"prompt broadcast timed out after {timeout} s")
     return buf, {k: float(v) for k, v in zip(keys, hdr.tolist())}
 
 
@@ -217,6 +230,9 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ["MASTER_PORT"] = str(group["port"])
             to = datetime.timedelta(seconds=float(group.get("timeout", 120.0)))
+            # a collective that was given up (sync_timeout) stays queued inside the communicator: its watchdog must only log
+            # that, not take the (healthy) process down when the group timeout passes later
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
             if group["backend"] == "nccl":
                 dev = torch.device("cuda", int(config.get("device", 0)))
                 torch.cuda.set_device(dev)
@@ -224,8 +240,11 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
             else:
                 dist.init_process_group(group["backend"], rank=rank, world_size=world, timeout=to)
         lanes = max(1, int(lanes))
-        if lanes * max_batch + 2 > 8:  # every (batch size, lane) engine must stay cached (VideoSDPipeline evicts beyond max_plans)
-            config = dict(config, max_plans=max(int(config.get("max_plans", 8)), lanes * max_batch + 2))
+        if world > 1 and "tuning_mode" not in config:
+            # every rank of a group must build the SAME kernel for the same shape (round-robin sharding sends consecutive
+            # frames of one stream to different ranks): no per-rank timing of shapes the shipped table lacks; rank 0's
+            # measured choices arrive through `__sync_tuning__`
+            config = dict(config, tuning_mode="table")
         pipe = _resolve(factory)(**config)
         conn.send(("ready", None))
     except BaseException as e:  # construction errors travel to the parent (the reference re-raises KeyError)
@@ -278,13 +297,14 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
             args = (_image_from_slot(rings[0], slot, w, h, copy=False),)
         return rid, method, args, kwargs, slot
 
-    def sync_prompt(prompt, header):
-        """A new prompt for every worker of the group: rank 0 encodes (CLIP on its GPU), everyone receives."""
+    def sync_prompt(prompt, header, collective=True):
+        """A new prompt for every worker of the group: rank 0 encodes (CLIP on its GPU), everyone receives and caches it.
+        Nothing in flight is disturbed (a prompt's constants are a cache entry; a lane takes them with its next launch), so
+        there is no drain.  collective=False (the dispatcher saw an unhealthy member, or an earlier sync failed): encode here."""
         nonlocal epoch
-        drain()
         epoch += 1
         key = prompt_key(prompt)
-        if dist is None or world == 1:
+        if dist is None or world == 1 or not collective:
             emb = pipe.encode_prompt(prompt)
             pipe.set_prompt_embeds(emb, key=key)
             return {"epoch": epoch, "rank": rank, "via": "local"}
@@ -292,11 +312,19 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
         shape = tuple(getattr(pipe, "prompt_shape", (77, 768)))
         hdr = dict(header or {})
         hdr["epoch"] = epoch
-        buf, got = broadcast_prompt(emb, hdr, src=0, device=dev, shape=shape)
+        buf, got = broadcast_prompt(emb, hdr, src=0, device=dev, shape=shape, timeout=float((group or {}).get("sync_timeout", 5.0)))
         if dev.type == "cuda":
             torch.cuda.current_stream().synchronize()
         pipe.set_prompt_embeds(buf, key=key)
         return {"epoch": int(got["epoch"]), "rank": rank, "via": dist.get_backend(), "checksum": float(buf.float().sum())}
+
+    def sync_tuning():
+        """Rank 0's per-shape kernel choices (its table plus what its warm-up measured) to every rank: one object broadcast."""
+        if dist is None or world == 1 or not hasattr(pipe, "export_tuning"):
+            return {"rank": rank, "imported": 0}
+        box = [pipe.export_tuning() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, device=dev if dist.get_backend() == "nccl" else None)
+        return {"rank": rank, "imported": 0 if rank == 0 else pipe.import_tuning(box[0]), "entries": len(box[0])}
 
     while True:
         if inflight and not backlog and not conn.poll(0):  # nothing new to start: hand back the oldest launch
@@ -312,7 +340,20 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
         rid, method, args, kwargs, slot = take(msg)
         if method == "__sync_prompt__":
             try:
-                conn.send((rid, True, sync_prompt(*args)))
+                conn.send((rid, True, sync_prompt(*args, **kwargs)))
+            except BaseException as e:
+                # the collective failed (a member died, the deadline passed): this worker still serves the prompt -- it
+                # encodes it itself -- and reports the failure so that the dispatcher stops using the group
+                try:
+                    sync_prompt(args[0], None, collective=False)
+                    conn.send((rid, True, {"epoch": epoch, "rank": rank, "via": "local-after-failed-sync", "error": f"{type(e).__name__}: {e}"}))
+                except BaseException as e2:
+                    conn.send((rid, False, (type(e2).__name__, str(e2))))
+            continue
+        if method == "__sync_tuning__":
+            drain()
+            try:
+                conn.send((rid, True, sync_tuning()))
             except BaseException as e:
                 conn.send((rid, False, (type(e).__name__, str(e))))
             continue
@@ -357,7 +398,10 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
             # launches in flight run on engines of THEIR plan: anything that re-prepares (other options, another prompt)
             # waits for them (`_engine_for` / `set_text_embeds` under a running graph)
             if inflight and inflight[-1][3] != kwargs:
-                drain()
+                # another session's frame: other prompts / sizes / step counts run BESIDE what is in flight (own plan, own
+                # prompt constants per lane); only a pipeline that says so (or cannot say) makes it wait
+                if not hasattr(pipe, "needs_idle") or pipe.needs_idle(**kwargs):
+                    drain()
             try:
                 handle = pipe.submit_batch([a[0] for _, a, _s in group_], lane=lane, **kwargs)
             except BaseException as e:
@@ -450,6 +494,7 @@ class RemotePipeline:
         self.compile_model = _RemoteMethod(self, "compile_model")
         self.set_prompt_embeds = _RemoteMethod(self, "set_prompt_embeds")
         self.sync_prompt = _RemoteMethod(self, "__sync_prompt__")
+        self.sync_tuning = _RemoteMethod(self, "__sync_tuning__")
         self.metrics = _RemoteMethod(self, "__metrics__")
         if wait:
             self.wait_ready()
@@ -574,7 +619,13 @@ class RemotePipeline:
                     slot = None
                 else:
                     args = (("__shm__",) + where,)
-        deadline = time.time() + self.call_timeout if (self.call_timeout and name in ("infer", "__sync_prompt__")) else None
+        deadline = None
+        if self.call_timeout and name == "infer":
+            deadline = time.time() + self.call_timeout
+        elif self.call_timeout and name in ("__sync_prompt__", "__sync_tuning__"):
+            # the collective has its own (short) deadline inside the worker, after which the worker encodes the prompt
+            # itself: the watchdog only steps in when even that does not come back
+            deadline = time.time() + self.call_timeout + float((self.group or {}).get("sync_timeout", 5.0)) * 2 + 30.0
         with self._lock:
             rid = self._next
             self._next += 1
@@ -653,11 +704,16 @@ class RemotePipeline:
 
 
 def spawn_workers(n: int, factory: str = "videosd_amd.pipeline:VideoSDPipeline", backend: Optional[str] = "auto",
-                  devices: Optional[List[int]] = None, **kwargs) -> List[RemotePipeline]:
+                  devices: Optional[List[int]] = None, sync_timeout: float = 5.0, warm_options: Optional[Dict[str, Any]] = None,
+                  **kwargs) -> List[RemotePipeline]:
     """The reference's `for i in range(gpu_num): pipelines[i] = VideoSDPipeline.remote(**config)` (server.py:317-321):
     N worker processes, worker i on GPU `devices[i]` (default i), all in ONE process group so that a new prompt is one
     RCCL broadcast from rank 0 (`backend` "nccl" = RCCL over xGMI on the GPU box; "gloo" for CPU tests; None: no group,
-    every worker encodes for itself).  The workers start concurrently (the rendezvous needs all of them)."""
+    every worker encodes for itself).  The workers start concurrently (the rendezvous needs all of them).
+    sync_timeout: seconds a prompt broadcast may take before every worker falls back to encoding the prompt itself.
+    warm_options: `infer` options of the stream to come: rank 0 prepares (and tunes) those plans first, its per-shape kernel
+    choices go to the other ranks (`__sync_tuning__`), then they prepare theirs -- every rank runs the same kernels, so a
+    frame's bits do not depend on the rank it lands on; no frame of the stream pays for a `prepare`."""
     if backend == "auto":
         backend = "nccl" if torch.cuda.device_count() >= n and n > 1 else None
     if n == 1:
@@ -667,15 +723,32 @@ def spawn_workers(n: int, factory: str = "videosd_amd.pipeline:VideoSDPipeline",
     ws = []
     try:
         for i in range(n):
-            grp = {"rank": i, "world": n, "port": port, "backend": backend} if backend else None
+            grp = {"rank": i, "world": n, "port": port, "backend": backend, "sync_timeout": float(sync_timeout)} if backend else None
             ws.append(RemotePipeline(factory=factory, group=grp, wait=False, device=devices[i], **kwargs))
         for w in ws:
             w.wait_ready()
+        if warm_options is not None:
+            warm_group(ws, warm_options)
     except BaseException:
         for w in ws:
             w.close()
         raise
     return ws
+
+
+def warm_group(ws: List["RemotePipeline"], warm_options: Dict[str, Any]):
+    """Rank 0 warms up (plans, graphs, per-shape tuning) -> its kernel choices to every rank -> the others warm up."""
+    b = int(getattr(ws[0], "max_batch", 1) or 1)
+    kw = dict(batches=tuple(range(1, b + 1)), lanes=getattr(ws[0], "lanes", 2) if b > 1 else 1, **warm_options)
+    if len(ws) > 1 and all(getattr(w, "group", None) for w in ws):
+        ws[0].method("warm_up")(**kw)
+        for f in [w.sync_tuning.remote() for w in ws]:
+            f.result(timeout=600)
+        futs = [w.method("warm_up").remote(**kw) for w in ws[1:]]
+    else:
+        futs = [w.method("warm_up").remote(**kw) for w in ws]
+    for f in futs:
+        f.result(timeout=3600)
 
 
 # ----------------------------------------------------------------------------------------- dispatcher
@@ -719,28 +792,80 @@ class FrameDispatcher:
         self._event = asyncio.Event()
         self.avg_gen_time = 0.4               # server.py:96 prior, updated as an EMA (server.py:113)
         self.group_ok = self.n > 1 and all(getattr(p, "group", None) for p in pipelines)
-        self._prompt = object()               # nothing broadcast yet
+        self._had_group = self.group_ok
+        # prompts every worker has cached (least recently used first); sessions alternating between a few prompts cause one
+        # sync per NEW prompt, not one per alternation (the workers keep an LRU of prompt constants: pipeline.max_prompts)
+        from collections import OrderedDict
+
+        self._prompts_known = OrderedDict()
+        self._prompts_pending = set()
+        self.max_prompts_known = 4
         self.prompt_syncs = 0
+        self.prompt_sync_failures = 0
 
     # ---- prompt broadcast
+    def _member_alive(self, g) -> bool:
+        p = self.pipelines[g]
+        proc = getattr(p, "_proc", None)
+        return self.healthy[g] and not getattr(p, "dead", False) and (proc is None or proc.is_alive())
+
     def _sync_prompt(self, options):
         prompt = options.get("prompt", ["pixar, cg"])  # the reference's default (videopipeline.py:78)
         key = prompt_key(prompt)
-        if not self.group_ok or key == self._prompt:
+        if not self.group_ok and not self._had_group:
+            return  # stand-alone handles: each worker encodes a prompt when its first frame with it arrives
+        if key in self._prompts_known:
+            self._prompts_known.move_to_end(key)
             return
-        self._prompt = key
+        if key in self._prompts_pending:  # its sync is on the way (the workers serve calls in order: the frame comes after it)
+            return
+        # A collective with a dead member leaves the survivors waiting: check every member when the sync is
+        # posted; if one is gone the group is finished and every worker encodes for itself (it does so on demand, at its
+        # first frame with that prompt).  The race that remains -- a member dying inside the collective -- ends at the
+        # workers' own short deadline (`sync_timeout`), after which they encode locally and report it.
+        if self.group_ok and not all(self._member_alive(g) for g in range(self.n)):
+            self._group_broken(-1)
+        if not self.group_ok:
+            # no collective any more: tell every live worker to encode the prompt itself, ahead of its frames
+            for g, p in enumerate(self.pipelines):
+                if self._member_alive(g) and hasattr(p, "sync_prompt"):
+                    try:
+                        p.sync_prompt.remote(prompt, None, collective=False)
+                    except Exception:
+                        pass
+            return
         self.prompt_syncs += 1
+        self._prompts_pending.add(key)
         header = {k: float(options[k]) for k in PROMPT_HEADER_KEYS if k in options and isinstance(options[k], (int, float))}
+        state = {"left": self.n, "ok": True}
+
+        def done(f, g):
+            bad = f.cancelled() or f.exception() is not None
+            if not bad:
+                r = f.result()
+                bad = isinstance(r, dict) and str(r.get("via", "")).startswith("local-after")
+            if bad:
+                state["ok"] = False
+                self.prompt_sync_failures += 1
+                self._group_broken(g)
+            state["left"] -= 1
+            if state["left"] == 0:
+                self._prompts_pending.discard(key)
+                if state["ok"]:  # known only once EVERY member has it
+                    self._prompts_known[key] = True
+                    while len(self._prompts_known) > self.max_prompts_known:
+                        self._prompts_known.popitem(last=False)
+
         for g, p in enumerate(self.pipelines):
             try:
                 fut = p.sync_prompt.remote(prompt, header)
-                fut.add_done_callback(lambda f, g=g: self._prompt_done(g, f))
+                fut.add_done_callback(lambda f, g=g: done(f, g))
             except Exception:
+                state["ok"] = False
+                state["left"] -= 1
+                if state["left"] == 0:
+                    self._prompts_pending.discard(key)
                 self._group_broken(g)
-
-    def _prompt_done(self, gpu, fut):
-        if fut.cancelled() or fut.exception() is not None:
-            self._group_broken(gpu)
 
     def _group_broken(self, gpu):
         # a member is gone: the communicator cannot be repaired; every worker encodes for itself from now on
@@ -849,6 +974,7 @@ class FrameDispatcher:
             per.append(m)
         return {"submitted": self.submitted, "dropped": self.dropped, "caller_errors": self.caller_errors,
                 "worker_faults": self.worker_faults, "respawns": self.respawns, "prompt_syncs": self.prompt_syncs,
+                "prompt_sync_failures": self.prompt_sync_failures,
                 "group": bool(self.group_ok), "avg_gen_time_s": round(self.avg_gen_time, 4), "workers": per}
 
     async def metrics_lines(self) -> List[str]:

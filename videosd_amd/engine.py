@@ -25,8 +25,7 @@ from . import lib as L
 from .config import ControlNetConfig, TAESDConfig, UNetConfig
 from .lcm import LCMSchedule, timestep_sinusoid, w_embedding
 from .ops import Geom
-from .packing import (PackedConv, add_frag, pack_conv, pack_cross_attention, pack_geglu_ln, pack_linear, pack_linear_cat,
-                      pack_linear_ln)
+from .packing import PackedConv, add_frag, pack_conv, pack_geglu_ln, pack_linear, pack_linear_cat, pack_linear_ln
 from .weights import skip_channels
 
 
@@ -111,12 +110,10 @@ class BlockW:
     out2: PackedConv
     ff1: PackedConv            # norm3 folded in, GEGLU tile-packed
     ff2: PackedConv
-    kv_index: int              # slot in the per-prompt cross-attention K / V^T cache
+    kv_index: int              # index of this block's entries in a prompt's constants (PromptLayout)
     # "absorbed" cross-attention (C >= XATTN_ABSORB_MIN_C): the text's key / value projections folded into the query and
-    # output weights, rebuilt per prompt (packing.pack_cross_attention); raw host copies of what that needs
-    xa_raw: Optional[tuple] = None     # (to_q weight, norm2 gamma, norm2 beta, to_out weight, to_out bias), CPU
-    xa1: Optional[PackedConv] = None   # LN-folded score weights [heads*128][C], tile-softmax epilogue
-    xa2: Optional[PackedConv] = None   # [C][heads*128] + bias
+    # output weights, rebuilt per prompt on the GPU (vsd_xattn_fold); what that needs besides out2: device copies of
+    xa_raw: Optional[tuple] = None     # (raw to_q weight fp16 [C][C], norm2 gamma, norm2 beta)
 
 
 @dataclass
@@ -249,10 +246,9 @@ class NetWeights:
             blk = BlockW(qkv, self._lin(b + ".attn1.to_out.0"), q2, kv2, self._lin(b + ".attn2.to_out.0"), ff1,
                          self._lin(b + ".ff.net.2"), len(self.transformers))
             heads = self.cfg.heads_for(c)
-            if c >= XATTN_ABSORB_MIN_C and c % heads == 0:
-                cpu = lambda t: t.detach().to("cpu", torch.float16)  # noqa: E731
-                blk.xa_raw = (cpu(w[f"{b}.attn2.to_q.weight"]), cpu(ln("norm2")[0]), cpu(ln("norm2")[1]),
-                              cpu(w[f"{b}.attn2.to_out.0.weight"]), cpu(w[f"{b}.attn2.to_out.0.bias"]))
+            if c >= XATTN_ABSORB_MIN_C and c % heads == 0 and c % 64 == 0 and (c // heads) % 8 == 0:
+                dv = lambda t: self.ops.to_device(t.detach().to(torch.float16).contiguous())  # noqa: E731
+                blk.xa_raw = (dv(w[f"{b}.attn2.to_q.weight"]), dv(ln("norm2")[0]), dv(ln("norm2")[1]))
             self.transformers.append(blk)
             blocks.append(blk)
         # use_linear_projection (SDXL): Linear on the token matrix == the 1x1 conv of SD1.5 in this layout
@@ -309,6 +305,77 @@ class TAESDWeights:
         self.dec_last_block = blk(f"{d}.{n}")
         n += 1
         self.dec_out = cv(f"{d}.{n}")
+
+
+class PromptLayout:
+    """Byte layout of ONE prompt's device constants for a family of engines (same weights): per BasicTransformerBlock of the
+    UNet / ControlNet its cross-attention K [tl][C] and V^T [C][ldt], and for the wide blocks the "absorbed" query / output
+    weights (xa1: weights [heads*128][C] + ln_s / ln_t, xa2: weights [C][heads*128] + bias).  Everything lives in ONE
+    contiguous buffer (~40 MB for SD1.5 + ControlNet), so that switching an engine to another cached prompt is a single
+    device-to-device copy and a prompt cache entry is a single allocation."""
+
+    def __init__(self, nets, tl: int):
+        self.tl, self.ldt = tl, _ru(tl, 64)
+        self.items = {}   # (net index, block index, name) -> (offset, shape, dtype)
+        self.absorbed = set()
+        off = 0
+
+        def add(key, shape, dtype):
+            nonlocal off
+            n = 1
+            for d in shape:
+                n *= d
+            self.items[key] = (off, tuple(shape), dtype)
+            off = _ru(off + n * torch.empty(0, dtype=dtype).element_size(), 256)
+
+        for ni, net in enumerate(nets):
+            for bi, t in enumerate(net.transformers):
+                c = t.kv2.n // 2
+                add((ni, bi, "k"), (tl, c), torch.float16)
+                add((ni, bi, "vt"), (c, self.ldt), torch.float16)
+                if t.xa_raw is not None and tl <= 128:
+                    hg = net.cfg.heads_for(c) * 128
+                    self.absorbed.add((ni, bi))
+                    add((ni, bi, "xa1_w"), (hg, c), torch.float16)
+                    add((ni, bi, "xa1_s"), (hg,), torch.float32)
+                    add((ni, bi, "xa1_t"), (hg,), torch.float32)
+                    add((ni, bi, "xa2_w"), (c, hg), torch.float16)
+                    add((ni, bi, "xa2_b"), (c,), torch.float16)
+        self.nbytes = max(off, 256)
+
+
+class PromptBlock:
+    """One prompt's constants in device memory (layout: PromptLayout).  Engines read THEIR OWN block (its addresses are in
+    their captured graphs); a cached prompt is installed by copying its block over the engine's."""
+
+    def __init__(self, ops, layout: PromptLayout):
+        self.layout = layout
+        self.buf = ops.zeros(layout.nbytes, dtype=torch.uint8)  # zero: V^T key padding and the unused rows of the xa weights
+        self._xa = {}
+        self.text = None
+
+    def view(self, ni, bi, name):
+        off, shape, dtype = self.layout.items[(ni, bi, name)]
+        n = 1
+        for d in shape:
+            n *= d
+        return self.buf[off:off + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(*shape)
+
+    def kv(self, ni, bi):
+        return self.view(ni, bi, "k"), self.view(ni, bi, "vt")
+
+    def xa(self, ni, bi):
+        """(xa1, xa2) PackedConv pair of an absorbed block (views into this block), or None"""
+        if (ni, bi) not in self.layout.absorbed:
+            return None
+        got = self._xa.get((ni, bi))
+        if got is None:
+            w1, w2 = self.view(ni, bi, "xa1_w"), self.view(ni, bi, "xa2_w")
+            hg, c = w1.shape
+            x1 = PackedConv(w1, None, hg, c, c, c, 1, ln_s=self.view(ni, bi, "xa1_s"), ln_t=self.view(ni, bi, "xa1_t"), tile128=True)
+            x2 = PackedConv(w2, self.view(ni, bi, "xa2_b"), c, hg, hg, hg, 1)
+            got = self._xa[(ni, bi)] = (x1, x2)
+        return got
 
 
 class RefCtx:
@@ -376,15 +443,26 @@ class Engine:
         # what a slot shares with its parent besides the weights: the per-plan constant block (schedule coefficients,
         # ControlNet scales) that the captured graphs READ, so that `update_options` reaches every graph at once
         self.shared = {}
-        self.absorb_cross_attention = True  # cross-attention of the wide blocks as two GEMMs (pack_cross_attention)
+        # what EVERY engine made from this one shares (weights aside): the prompt-constant layout and the default prompt
+        # (`set_text_embeds`); an engine follows the default unless `use_prompt` gave it one of its own
+        self.family = {}
+        self.pblock = None      # this engine's own prompt constants (the addresses its program / graph reads)
+        self._installed = None  # the PromptBlock whose bytes `pblock` currently holds
+        self._want = None       # `use_prompt`: this engine's prompt (None: the family default)
+        self.absorb_cross_attention = True  # cross-attention of the wide blocks as two GEMMs (vsd_xattn_fold)
         self.use_fused_tail = True          # 320-wide blocks: per-token chains as fused launches (csrc/fused_tail.hip)
         self.tail_b_min_rows = 1024         # ... the feed-forward chain from this many tokens per launch on (see _transformer)
 
-    def make_slot(self) -> "Engine":
-        """A further frame in flight on the same GPU: shares the weights and the prompt / schedule constants of
-        this engine, owns its streams, arena, I/O buffers and graph.  Call `prepare` on the parent first, then on
-        the slot with the same arguments.  (The reference keeps one frame in flight per Ray actor; frames are
-        independent, so a second one fills the gaps the first leaves between its small dependent kernels.)"""
+    def make_slot(self, share_plan: bool = True) -> "Engine":
+        """A further engine on the same GPU and the same weights, with its own streams, arena, I/O buffers, prompt constants
+        and graph.
+        share_plan=True: a further frame in flight of THIS engine's plan -- shares its schedule constants (`update_options`
+        on the parent reaches it).  Call `prepare` on the parent first, then on the slot with the same arguments.  (The
+        reference keeps one frame in flight per Ray actor; frames are independent, so a second one fills the gaps the
+        first leaves between its small dependent kernels.)
+        share_plan=False: an independent plan (another frame size / step count / session) with constants of its own: it is
+        prepared and updated like a parent, while the other plans keep running (server.py:90-93: options are per session,
+        every session's frames go through the same actors)."""
         e = Engine.__new__(Engine)
         e.__dict__.update(self.__dict__)
         e.ops = self.ops.clone()
@@ -392,50 +470,69 @@ class Engine:
         e.graph = None
         e.plan = None
         e._stage = None  # own pinned staging buffers and events (a copy of the parent's would be SHARED with it)
-        e.is_slot = True
+        e.pblock = None
+        e._installed = None
+        e._want = None
+        e.is_slot = bool(share_plan)
+        if not share_plan:
+            e.shared = {}
         return e
 
     # ---------------------------------------------------------------- prompt-dependent constants
-    def set_text_embeds(self, embeds: torch.Tensor):
-        """embeds: [77, cross_dim] (or [1,77,cross_dim]) -> cross-attention K and V^T of every layer.
-        Replaces the to_k / to_v projections diffusers recomputes every step (attn2 of each block)."""
+    def _nets(self):
+        return [self.unet] + ([self.cn] if self.cn else [])
+
+    def build_prompt(self, embeds: torch.Tensor) -> PromptBlock:
+        """embeds: [77, cross_dim] (or [1,77,cross_dim]) -> a fresh PromptBlock: cross-attention K and V^T of every layer (the
+        to_k / to_v projections diffusers recomputes every step, attn2 of each block) and, for the wide blocks, the query /
+        output weights with K / V folded in (vsd_xattn_fold) -- all on the GPU (~1 ms), touching nothing a running launch
+        reads: a prompt cache is filled while frames of other prompts are in flight."""
         ops = self.ops
         e = embeds.reshape(-1, embeds.shape[-1]).to(torch.float16).contiguous()
-        self.text = ops.to_device(e)
-        tl = self.text.shape[0]
-        ldt = _ru(tl, 64)
-        for net in [self.unet] + ([self.cn] if self.cn else []):
-            first = not hasattr(net, "kv_cache")
-            if first:
-                net.kv_cache = []
-            for i, t in enumerate(net.transformers):
+        text = ops.to_device(e)
+        tl = text.shape[0]
+        lay = self.family.get("layout")
+        if lay is None or lay.tl != tl:
+            lay = self.family["layout"] = PromptLayout(self._nets(), tl)
+        blk = PromptBlock(ops, lay)
+        blk.text = text
+        for ni, net in enumerate(self._nets()):
+            for bi, t in enumerate(net.transformers):
                 c = t.kv2.n // 2
-                if first:
-                    net.kv_cache.append((ops.zeros(tl, c), ops.zeros(c, ldt)))
-                k, vt = net.kv_cache[i]
-                ops.conv(self.text, None, Geom.linear(tl), t.kv2, k, ldo=c, out_t=vt, ldt=ldt, t_col0=c)
+                k, vt = blk.kv(ni, bi)
+                ops.conv(text, None, Geom.linear(tl), t.kv2, k, ldo=c, out_t=vt, ldt=lay.ldt, t_col0=c)
+                if (ni, bi) in lay.absorbed:
+                    wq, ga, be = t.xa_raw
+                    heads = net.cfg.heads_for(c)
+                    ops.xattn_fold(k, vt, tl, wq, t.out2.weight, ga, be, c, heads, (c // heads) ** -0.5, blk.view(ni, bi, "xa1_w"),
+                                   blk.view(ni, bi, "xa1_s"), blk.view(ni, bi, "xa1_t"), blk.view(ni, bi, "xa2_w"))
+                    ops.copy_(blk.view(ni, bi, "xa2_b"), t.out2.bias)
         ops.synchronize()
-        if tl > 128 or not self.absorb_cross_attention:
-            return
-        # absorbed cross-attention: fold this prompt's K / V into the query / output weights of the wide blocks.  The
-        # device buffers keep their addresses (captured graphs read them): a new prompt rewrites them in place.
-        for net in [self.unet] + ([self.cn] if self.cn else []):
-            for i, t in enumerate(net.transformers):
-                if t.xa_raw is None:
-                    continue
-                k, vt = net.kv_cache[i]
-                kh = ops.download(k).float()
-                vh = ops.download(vt)[:, :tl].float().t().contiguous()
-                wq, ga, be, wo, bo = t.xa_raw
-                x1, x2 = pack_cross_attention(kh, vh, wq, wo, bo, ga, be, net.cfg.heads_for(k.shape[1]))
-                if t.xa1 is None:
-                    t.xa1, t.xa2 = net._to_dev(x1), net._to_dev(x2)
-                else:
-                    for dst, src in ((t.xa1, x1), (t.xa2, x2)):
-                        for f in ("weight", "bias", "ln_s", "ln_t"):
-                            if getattr(src, f) is not None:
-                                ops.upload(getattr(dst, f), getattr(src, f).contiguous())
-        ops.synchronize()
+        return blk
+
+    def set_text_embeds(self, embeds: torch.Tensor):
+        """The prompt of this engine AND of every engine made from it that was not given one of its own (`use_prompt`).
+        Prepared plans stay valid: an engine copies the new constants over its own block before its next launch."""
+        blk = self.build_prompt(embeds)
+        self.family["prompt"] = blk
+        self._want = None
+        self.text = blk.text
+
+    def use_prompt(self, blk: Optional[PromptBlock]):
+        """This engine's launches use `blk` (from `build_prompt`, e.g. a prompt cache entry) from the next launch on, whatever
+        the other engines of the family run; None: follow the family default again.  Call it with no launch of THIS engine
+        in flight (the other lanes are not affected: every engine reads its own copy)."""
+        self._want = blk
+
+    def _sync_prompt(self):
+        src = self._want if self._want is not None else self.family.get("prompt")
+        if src is None:
+            raise RuntimeError("set_text_embeds (or use_prompt) must be called before a launch")
+        if src is not self._installed:
+            if self.pblock is None or src.layout is not self.pblock.layout:
+                raise RuntimeError("the prompt's text length differs from the one this plan was prepared for: prepare again")
+            self.ops.copy_(self.pblock.buf, src.buf)  # one device-to-device copy on this engine's own stream
+            self._installed = src
 
     def set_added_cond(self, pooled: torch.Tensor, time_ids):
         """SDXL micro-conditioning: pooled text embedding [add_pooled_dim] and the 6 time ids
@@ -476,6 +573,10 @@ class Engine:
         ops.conv(h2, None, Geom.linear(n), net.temb_proj, out[:n])
         ops.synchronize()
 
+    def _temb(self, net):
+        """this plan's per-step time-embedding projections of `net` (device constants shared by the plan's engines)"""
+        return self.shared["temb"]["cn" if net is self.cn else "unet"]
+
     # ---------------------------------------------------------------- network builders (record ops)
     def _resnet(self, r, rw: ResnetW, net, step, x, x2, c0, c1, hw, geom, out=None, out2=None, add2=None, residual2=None,
                 temb=None, stat_out=None, side=False):
@@ -488,7 +589,7 @@ class Engine:
         t1 = a.alloc(rows, cin)
         self._gn(r, x, x2, c0, c1, hw, cfg.groups, 1e-5, rw.n1[0], rw.n1[1], True, t1)
         h = a.alloc(rows, rw.cout)
-        tv = (net.temb_all if temb is None else temb)[step, rw.temb_off:rw.temb_off + rw.cout]
+        tv = (self._temb(net) if temb is None else temb)[step, rw.temb_off:rw.temb_off + rw.cout]
         r.conv(t1, None, geom, rw.conv1, h, rowvec=tv, chanstat_out=self._stat_buf(h, rw.cout))
         t2 = a.alloc(rows, rw.cout)
         self._gn(r, h, None, rw.cout, 0, hw, cfg.groups, 1e-5, rw.n2[0], rw.n2[1], True, t2)
@@ -562,7 +663,9 @@ class Engine:
                     r.attention(qk, 2 * c, qk[:, c:], 2 * c, vt_full[:, off:], ld2, att, c, hw, hw, heads, d, d ** -0.5)
                 else:
                     r.attention(qk, 2 * c, qk_full[:, c:], 2 * c, vt_full, ld2, att, c, hw, 2 * hw, heads, d, d ** -0.5)
-            kt, vtt = net.kv_cache[bw.kv_index]
+            ni = 1 if net is self.cn else 0
+            kt, vtt = self.pblock.kv(ni, bw.kv_index)
+            xa = self.pblock.xa(ni, bw.kv_index) if self.absorb_cross_attention else None
             fused = (self.use_fused_tail and c == getattr(self.ops, "TAIL_C", 0) and len(tw.blocks) == 1 and ref is None and
                      stat_out is None and out2 is None and not self.fuse_gn_stats and hasattr(self.ops, "tail_a"))
             if fused:
@@ -595,12 +698,12 @@ class Engine:
             # cross-attention over the cached text K / V^T (shared by all images)
             h2 = a.alloc(rows, c)
             rs2 = stat()
-            if bw.xa1 is not None and self.absorb_cross_attention:
+            if xa is not None:
                 # wide blocks: probabilities = softmax per head of LN(h1) G^T (one 128-column tile per head, softmax in the
                 # GEMM epilogue), then h2 = P Z^T + bias + h1 -- two launches instead of three, fewer FLOPs for C >= 1024
-                pr = a.alloc(rows, bw.xa1.n)
-                r.conv(h1, None, lin, bw.xa1, pr, ln_part=rs1, act=L.ACT_SOFTMAX, softmax_cols=kt.shape[0])
-                r.conv(pr, None, lin, bw.xa2, h2, residual=h1, rowstat_out=rs2)
+                pr = a.alloc(rows, xa[0].n)
+                r.conv(h1, None, lin, xa[0], pr, ln_part=rs1, act=L.ACT_SOFTMAX, softmax_cols=kt.shape[0])
+                r.conv(pr, None, lin, xa[1], h2, residual=h1, rowstat_out=rs2)
             else:
                 q = a.alloc(rows, c)
                 r.conv(h1, None, lin, bw.q2, q, ln_part=rs1)
@@ -895,8 +998,12 @@ class Engine:
         self.batch = batch
         if H % 8 or W % 8:
             raise ValueError("height and width must be multiples of 8 (TAESD / latent stride)")
-        if self.text is None:
+        src = self._want if self._want is not None else self.family.get("prompt")
+        if src is None:
             raise RuntimeError("set_text_embeds must be called before prepare")
+        if self.pblock is None or self.pblock.layout is not src.layout:
+            self.pblock = PromptBlock(self.ops, src.layout)
+            self._installed = None
         if use_controlnet and self.cn is None:
             raise RuntimeError("no ControlNet weights loaded")
         if ref_mode and (batch != 1 or use_controlnet or (H // 8) * (W // 8) % 8):
@@ -939,12 +1046,11 @@ class Engine:
             if c is None or self.shared.get("n") != n:
                 self.shared["consts"] = c = ops.zeros(2 + 6 * n + ncn, dtype=torch.float32)
                 self.shared["n"] = n
-            for net in [self.unet] + ([self.cn] if use_controlnet else []):
-                if getattr(net, "temb_all", None) is None or net.temb_all.shape[0] != n:
-                    net.temb_all = ops.zeros(n, net.temb_proj.n)
+            temb = self.shared.setdefault("temb", {})
+            for name, net in [("unet", self.unet)] + ([("cn", self.cn)] if use_controlnet else []) + ([("ref", self.unet)] if ref_mode else []):
+                if name not in temb or temb[name].shape[0] != n:
+                    temb[name] = ops.zeros(n, net.temb_proj.n)
             self.shared["ref_mode"] = bool(ref_mode)
-            if ref_mode and (getattr(self.unet, "temb_ref", None) is None or self.unet.temb_ref.shape[0] != n):
-                self.unet.temb_ref = ops.zeros(n, self.unet.temb_proj.n)
             self._write_constants(sched, controlnet_scale, use_controlnet)
         self._cn_scale_consts = c[2 + 6 * n:]
         # noise draws: the reference resets the global CPU generator to a fresh-Generator state on every
@@ -1015,8 +1121,8 @@ class Engine:
                 # ref_xt = add_noise(ref latents, fresh draw, t_i) (lcm_reference_pipeline.py:861-871); the coefficients of
                 # timestep t_i are the first two of the step's scheduler coefficients
                 r.add_noise_dev(ref_x0, self.noise_ref[i], c[2 + 6 * i:4 + 6 * i], hw0, 1, ref_xt)
-                w_mid, w_skips = self._unet_encoder(r, i, ref_xt, sizes, ref=rc, temb=self.unet.temb_ref)
-                self._unet_decoder(r, i, w_mid, w_skips, sizes, ref_eps, ref=rc, temb=self.unet.temb_ref)
+                w_mid, w_skips = self._unet_encoder(r, i, ref_xt, sizes, ref=rc, temb=self.shared["temb"]["ref"])
+                self._unet_decoder(r, i, w_mid, w_skips, sizes, ref_eps, ref=rc, temb=self.shared["temb"]["ref"])
                 rc.mode = "read"
                 u_mid, u_skips = self._unet_encoder(r, i, cur, sizes, ref=rc)
             else:
@@ -1033,6 +1139,7 @@ class Engine:
                          sizes=sizes, timesteps=sched.timesteps, n_ops=len(r.calls), arena_bytes=a.peak)
         # per-shape kernel configuration (timed once per shape, cached in ops.tile_override), warm-up, capture
         torch.cuda.synchronize() if torch.cuda.is_available() else None  # allocation fills vs. kernel streams
+        self._sync_prompt()
         if autotune:  # (only shapes missing from the shared table are timed: a slot with the parent's batch size finds all)
             self.autotune()
         r.run()
@@ -1056,10 +1163,10 @@ class Engine:
         host = torch.zeros(c.numel(), dtype=torch.float32)
         host[:len(vals)] = torch.tensor(vals, dtype=torch.float32)
         self.ops.upload(c, host)
-        for net in [self.unet] + ([self.cn] if (use_controlnet and self.cn is not None) else []):
-            self._time_embeddings(net, sched, net.temb_all)
+        for name, net in [("unet", self.unet)] + ([("cn", self.cn)] if (use_controlnet and self.cn is not None) else []):
+            self._time_embeddings(net, sched, self.shared["temb"][name])
         if self.shared.get("ref_mode"):  # the reference-only WRITE pass: same timesteps, no guidance embedding
-            self._time_embeddings(self.unet, sched, self.unet.temb_ref, use_cond=False)
+            self._time_embeddings(self.unet, sched, self.shared["temb"]["ref"], use_cond=False)
         self.ops.synchronize()
 
     def update_options(self, strength: float, controlnet_scale: float) -> bool:
@@ -1108,6 +1215,7 @@ class Engine:
     # ---------------------------------------------------------------- per frame
     def launch(self):
         """Enqueue one frame's work (frame_u8 -> out_u8) on the ops stream."""
+        self._sync_prompt()
         if self.graph is not None:
             self.ops.graph_launch(self.graph)
         else:

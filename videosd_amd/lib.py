@@ -4,8 +4,10 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvsd.so")
+# VSD_LIB: another build of the same sources (development: the instrumented libvsd_tl.so of build.build_timeline)
+LIB_PATH = os.environ.get("VSD_LIB") or os.path.join(HERE, "libvsd.so")
 
+VERSION = 3  # include/vsd.h VSD_VERSION
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_QUICKGELU, ACT_SOFTMAX = range(6)
 ACT_POST = 256
 SPLITK_MAX_TILES = 16384
@@ -49,6 +51,9 @@ class ConvDesc(C.Structure):
 # name -> (restype, argtypes); every symbol declared in include/vsd.h
 SIGNATURES = {
     "vsd_version": (C.c_int, []),
+    "vsd_conv_desc_size": (C.c_int, []),
+    "vsd_xattn_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsd_create": (C.c_void_p, [C.c_int]),
     "vsd_destroy": (None, [C.c_void_p]),
     "vsd_last_error": (C.c_char_p, [C.c_void_p]),
@@ -111,10 +116,19 @@ def load():
     import torch  # noqa: F401
 
     lib = C.CDLL(LIB_PATH)
+    rebuild = f"{LIB_PATH} is stale: rebuild it with `python -m videosd_amd.build --force`"
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        try:
+            fn = getattr(lib, name)  # a declared symbol that is not exported = a library built from older sources
+        except AttributeError:
+            raise RuntimeError(f"{rebuild} (symbol {name} is missing)") from None
         fn.restype = res
         fn.argtypes = args
+    # same interface version and the same vsd_conv_desc layout on both sides of the boundary (the struct grew
+    # three fields while vsd_version stayed 1; a stale library was only caught through missing symbols)
+    if lib.vsd_version() != VERSION or lib.vsd_conv_desc_size() != C.sizeof(ConvDesc):
+        raise RuntimeError(f"{rebuild} (library: interface version {lib.vsd_version()}, vsd_conv_desc {lib.vsd_conv_desc_size()} bytes; "
+                           f"this binding: version {VERSION}, {C.sizeof(ConvDesc)} bytes)")
     _lib = lib
     return lib
 

@@ -225,6 +225,13 @@ class HipOps:
         if tile is None:
             if key in self.tile_override:
                 tile, split_k, inkernel, pipeline = self.tile_override[key]
+                if w.tile128 or w.geglu:
+                    # these epilogues need whole 128-column tiles.  The shape key does not say which epilogue a layer has, so a
+                    # table entry found for a plain layer of the same (M, N, K) may name a 64-column tile or a form without
+                    # them: widen it instead of failing at `prepare`
+                    tile = {L.TILE_128x64: L.TILE_128x128, L.TILE_64x64: L.TILE_64x128, L.TILE_256x64: L.TILE_256x128}.get(tile, tile)
+                    if pipeline in (7, 9, 10):
+                        pipeline = 3
             else:
                 tile, sk = choose_tile(m, w.n, w.kp, w.geglu or w.tile128, t_col0 if out_t is not None else 0)
                 split_k = sk if split_k is None else split_k
@@ -512,6 +519,11 @@ class HipOps:
     def adain(self, x, stats, stats_ref, rows, c, out, eps=1e-6):
         """reference-only AdaIN: per-channel re-normalisation of x to the banked statistics (fp32 [c][2] sum / sumsq)"""
         self.ctx.call("vsd_adain", self._p(x), self._p(stats), self._p(stats_ref), rows, c, eps, self._p(out), self.s)
+
+    def xattn_fold(self, k, vt, tl, wq, wo, gamma, beta, c, heads, scale, xa1_w, xa1_s, xa1_t, xa2_w):
+        """per-prompt constants of one absorbed cross-attention block (include/vsd.h vsd_xattn_fold)"""
+        self.ctx.call("vsd_xattn_fold", self._p(k), k.stride(0), self._p(vt), vt.stride(0), tl, self._p(wq), self._p(wo), self._p(gamma),
+                      self._p(beta), c, heads, float(scale), self._p(xa1_w), self._p(xa1_s), self._p(xa1_t), self._p(xa2_w), self.s)
 
     def embed_tokens(self, ids_i64, tok_emb, pos_emb, out):
         n, c = out.shape

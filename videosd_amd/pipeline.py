@@ -55,6 +55,7 @@ class VideoSDPipeline:
 
     def __init__(self, *args, **kwargs):
         self.device = kwargs.get("device", 0)
+        self._kwargs = dict(kwargs)
         self.honor_controlnet_flag = bool(kwargs.get("honor_controlnet_flag", False))  # extension, off by default
         # extension, off by default: `ref=True` runs the reference-only mode (lcm_reference_pipeline.py, dead code at the
         # reference's v2 where `ref` / `style_fidelity` are accepted and ignored, videopipeline.py:84-85)
@@ -66,13 +67,22 @@ class VideoSDPipeline:
         except KeyError:
             print("Model name and controlnet model must be specified")  # videopipeline.py:24-26
             raise
-        self._prompt_key = None
-        self._plan_key = None
-        self._opt_key = None
-        self._engines = {}  # (plan_key, batch, lane) -> prepared engine (the first one is self.model, the others are its slots)
-        self.max_plans = int(kwargs.get("max_plans", 8))
+        # Per-session state without stalls (server.py:90-93: options live on each VideoSDTrack; :132-137: every session's
+        # frames go through the same actors).  Two LRU caches:
+        #   prompts: prompt key -> PromptBlock (cross-attention K / V^T + absorbed weights of every layer, ~40 MB, built on the
+        #            GPU in ~1 ms); an engine takes a cached prompt with one device-to-device copy on its own stream;
+        #   plans:   (size, steps, timestep count, ControlNet, ref) -> {engines by (frames per launch, lane), constants}: each
+        #            plan has its own schedule constants, so sessions with different sizes / steps alternate frame by frame
+        #            with their graphs intact.  `max_plans` counts PROGRAMS; a plan's engines are never evicted one by one.
+        from collections import OrderedDict
+
+        self._prompts = OrderedDict()
+        self.max_prompts = int(kwargs.get("max_prompts", 8))
+        self._plans = OrderedDict()
+        self.max_plans = int(kwargs.get("max_plans", 3))
         self._outstanding = []  # engines with a submitted, not yet collected launch
-        self._host_ms = {"crop_resize": [], "upload_enqueue": [], "wait_download": [], "to_pil": [], "gpu": [], "prepare": [], "update_options": []}
+        self._host_ms = {"crop_resize": [], "upload_enqueue": [], "wait_download": [], "to_pil": [], "gpu": [], "prepare": [], "update_options": [],
+                         "prompt": []}
 
     # ------------------------------------------------------------------ model loading
     def load_model(self, model_name, controlnet_model="lllyasviel/control_v11p_sd15_canny"):
@@ -88,6 +98,11 @@ class VideoSDPipeline:
         tuning = os.environ.get("VSD_TUNING") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                               "profiles", "tuning_mi355x.json")
         ops.load_tuning(tuning)
+        # "auto": shapes missing from the table are timed on this GPU at `prepare`; "table": never -- missing shapes take the
+        # deterministic heuristic (ops.choose_tile), so that every rank of a group builds the SAME kernels and a frame's bits
+        # do not depend on the rank it lands on (dispatch.spawn_workers sets this for groups; `sync_tuning` spreads rank 0's
+        # measured choices)
+        self.tuning_mode = str(getattr(self, "_kwargs", {}).get("tuning_mode", "auto"))
         # Extension (BASELINE.json configs[3]; the reference only knows SD1.5): a model name containing "xl" selects the
         # SDXL-base UNet topology (LCM-SDXL weights as `unet_sdxl.safetensors`, TAESD-XL as `taesdxl.safetensors`),
         # without a ControlNet tower; prompts then need 2048-wide embeddings + a 1280-wide pooled vector.
@@ -139,14 +154,21 @@ class VideoSDPipeline:
         return (77, self.unet_cfg.cross_dim)
 
     def set_prompt_embeds(self, embeds: torch.Tensor, key=None):
-        """Install embeddings produced elsewhere (rank 0 broadcasts them over RCCL, dispatch.py)."""
-        self._require_idle("install new prompt embeddings")
-        self.model.set_text_embeds(embeds)
-        self._prompt_key = key
-        if self.is_xl:  # the added conditioning (pooled embedding) is baked into the time embeddings at `prepare`
-            self._pooled = self.encode_pooled(key if isinstance(key, str) else list(key or ()))
-            self._engines.clear()
-            self._plan_key = None
+        """Install embeddings produced elsewhere (rank 0 broadcasts them over RCCL, dispatch.py) as prompt `key`: they join
+        the prompt cache; nothing in flight is disturbed."""
+        return self._cache_prompt(key, embeds)
+
+    def _cache_prompt(self, key, embeds=None, prompt=None):
+        blk = self._prompts.get(key)
+        if blk is None or embeds is not None:
+            t0 = time.perf_counter()
+            blk = self.model.build_prompt(embeds if embeds is not None else self.encode_prompt(prompt))
+            self._prompts[key] = blk
+            self._note("prompt", t0)
+            while len(self._prompts) > max(1, self.max_prompts):  # least recently used first; an engine that still holds an
+                self._prompts.popitem(last=False)                 # evicted block keeps it alive until it switches
+        self._prompts.move_to_end(key)
+        return blk
 
     def set_reference(self, img):
         """The reference image of the reference-only mode (`honor_ref_flag=True`, `infer(..., ref=True)`).  Without one the
@@ -178,15 +200,17 @@ class VideoSDPipeline:
 
         out = {k: (round(statistics.median(v), 3) if v else None) for k, v in self._host_ms.items()}
         out["plans_cached"] = len(self._engines)
+        out["programs_cached"] = len(self._plans)
+        out["prompts_cached"] = len(self._prompts)
         return {"stage_ms_p50": out}
 
     def stage_profile(self, batch: int = 1):
         """Per-kernel-family device ms of ONE eager pass of the current plan (vsd_stage_times; the captured graph cannot be
         bracketed per launch).  On demand only: it re-runs the program un-captured."""
         self._require_idle("profile")
-        eng = self.model
-        if eng.plan is None:
+        if not self._plans:
             raise RuntimeError("no plan prepared yet: call infer first")
+        eng = next(reversed(self._plans.values()))["root"]  # the most recently used program
         ops = eng.ops
         eng.program.run()
         ops.synchronize()
@@ -253,16 +277,7 @@ class VideoSDPipeline:
         imgs = [center_crop_resize(im, width, height) for im in imgs]
         self._note("crop_resize", t0)
         pkey = prompt if isinstance(prompt, str) else tuple(prompt)
-        if pkey != self._prompt_key:
-            self._require_idle("change the prompt")
-            self.model.set_text_embeds(self.encode_prompt(prompt))
-            self._prompt_key = pkey  # (the cross-attention K / V^T caches are rewritten in place: captured graphs stay valid)
-            if self.is_xl:
-                self._pooled = self.encode_pooled(prompt)
-                self._engines.clear()  # the added conditioning is baked into the time embeddings at `prepare`
-                self._plan_key = None
-        if self.is_xl:  # micro-conditioning: original size = target size = the frame size, no crop
-            self.model.set_added_cond(self._pooled, (height, width, 0, 0, height, width))
+        pblock = self._cache_prompt(pkey, prompt=prompt)  # cached: nothing to do; new: ~1 ms on the GPU, nobody waits
         use_cn = False if self.is_xl else (bool(controlnet) if self.honor_controlnet_flag else True)
         use_ref = bool(ref) and self.honor_ref_flag and not self.is_xl
         if use_ref:
@@ -278,9 +293,11 @@ class VideoSDPipeline:
         from .lcm import lcm_timesteps
 
         n_eff = len(lcm_timesteps(float(strength), int(steps)))  # ValueError for an empty schedule: the caller's problem
-        plan_key = (height, width, int(steps), n_eff, use_cn, use_ref)
+        # (SDXL: the pooled text embedding is baked into the time embeddings at `prepare`, so the prompt is part of the program)
+        plan_key = (height, width, int(steps), n_eff, use_cn, use_ref) + ((pkey,) if self.is_xl else ())
         opts = (float(strength), float(controlnet_scale))
-        eng = self._engine_for(plan_key, opts, len(imgs), lane)
+        eng = self._engine_for(plan_key, opts, len(imgs), lane, prompt=pblock, prompt_text=prompt)
+        eng.use_prompt(pblock)  # this lane's launch reads ITS copy of the constants: the other lanes may run other prompts
         if use_ref and getattr(eng, "_ref_epoch", None) != self._ref_epoch:
             rf = np.asarray(center_crop_resize(self._ref_img.convert("RGB"), width, height), dtype=np.uint8)
             eng.ops.upload(eng.ref_u8, torch.from_numpy(np.array(rf, copy=True)))  # (PIL's buffer is read-only)
@@ -310,45 +327,100 @@ class VideoSDPipeline:
         self._note("to_pil", t0)
         return res
 
-    def _engine_for(self, plan_key, opts, batch: int, lane: int = 0):
-        """A prepared engine per (program, batch size, lane): the parent engine serves the first one, slots (shared
-        weights and constants, own arena / graph) serve the others, so switching between batch sizes costs nothing per
-        frame.  `opts` = (strength, controlnet_scale): a change rewrites the shared device constants, nothing else."""
-        height, width, steps, _n, use_cn, use_ref = plan_key
+    @property
+    def _engines(self):
+        """(plan_key, frames per launch, lane) -> prepared engine, over all cached plans"""
+        return {(pk, b, l): e for pk, pl in self._plans.items() for (b, l), e in pl["engines"].items()}
+
+    def _plan_busy(self, plan) -> bool:
+        return any(e in self._outstanding for e in plan["engines"].values())
+
+    def needs_idle(self, **options) -> bool:
+        """Would a frame with these `infer` options have to wait for launches in flight?  Only a change of `strength` /
+        `controlnet_scale` of a plan that is running does (its graphs read those constants); other prompts, sizes, step
+        counts and batch sizes go beside what is running.  (dispatch.py's worker drains before such a frame.)"""
+        try:
+            from .lcm import lcm_timesteps
+
+            o = dict(height=360, width=640, strength=0.4, steps=20, controlnet=False, ref=False, controlnet_scale=1, prompt=["pixar, cg"])
+            o.update(options)
+            n_eff = len(lcm_timesteps(float(o["strength"]), int(o["steps"])))
+            use_cn = False if self.is_xl else (bool(o["controlnet"]) if self.honor_controlnet_flag else True)
+            use_ref = bool(o["ref"]) and self.honor_ref_flag and not self.is_xl
+            if use_ref:
+                return bool(self._outstanding)  # (reference image upload + one frame per launch: keep it simple)
+            pk = (o["height"], o["width"], int(o["steps"]), n_eff, use_cn and not use_ref, use_ref)
+            if self.is_xl:
+                pk += (o["prompt"] if isinstance(o["prompt"], str) else tuple(o["prompt"]),)
+            plan = self._plans.get(pk)
+            if plan is None:
+                return False
+            return plan["opts"] != (float(o["strength"]), float(o["controlnet_scale"])) and self._plan_busy(plan)
+        except Exception:
+            return bool(self._outstanding)
+
+    def _engine_for(self, plan_key, opts, batch: int, lane: int = 0, prompt=None, prompt_text=None):
+        """A prepared engine per (program, frames per launch, lane).  A program's first engine owns its schedule constants;
+        the others are slots of it (shared weights and constants, own arena / prompt constants / graph), so that switching
+        between batch sizes, lanes, prompts and PROGRAMS costs nothing per frame.  `opts` = (strength, controlnet_scale): a
+        change rewrites that program's device constants, nothing else."""
+        height, width, steps, _n, use_cn, use_ref = plan_key[:6]
         strength, cn_scale = opts
-        if plan_key == self._plan_key and opts != self._opt_key:
-            self._require_idle("change strength / controlnet_scale")
-            t0 = time.perf_counter()
-            if not self.model.update_options(strength, cn_scale):  # (cannot happen: the timestep count is in the key)
-                self._plan_key = None
-            self._opt_key = opts
-            self._note("update_options", t0)
-        key = (plan_key, batch, lane)
-        eng = self._engines.get(key) if plan_key == self._plan_key else None
-        if eng is not None:
-            if eng in self._outstanding:
-                raise RuntimeError("this lane's previous launch has not been collected")
-            return eng
+        plan = self._plans.get(plan_key)
+        if plan is not None:
+            self._plans.move_to_end(plan_key)
+            if opts != plan["opts"]:
+                if self._plan_busy(plan):
+                    raise RuntimeError("cannot change strength / controlnet_scale of a plan with launches in flight: collect them first")
+                t0 = time.perf_counter()
+                if not plan["root"].update_options(strength, cn_scale):  # (cannot happen: the timestep count is in the key)
+                    raise RuntimeError("update_options refused a schedule with the same number of timesteps")
+                plan["opts"] = opts
+                self._note("update_options", t0)
+            eng = plan["engines"].get((batch, lane))
+            if eng is not None:
+                if eng in self._outstanding:
+                    raise RuntimeError("this lane's previous launch has not been collected")
+                return eng
         t0 = time.perf_counter()
-        # a new program re-prepares the parent engine (and drops its slots); so does a full cache -- but never under a
-        # launch that is still running: the cache just grows until the lanes are idle
-        evict = len(self._engines) >= self.max_plans and not self._outstanding
-        if plan_key != self._plan_key or evict:
-            self._require_idle("prepare another plan")
-            self._engines.clear()
-            self.model.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch,
-                               ref_mode=use_ref)
-            self._plan_key, self._opt_key = plan_key, opts
-            eng = self.model
-            eng._ref_epoch = None
-        else:  # same program and constants as the parent's current plan: a slot suffices
-            eng = self.model.make_slot()
-            eng.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch,
-                        ref_mode=use_ref)
-            eng._ref_epoch = None
-        self._engines[key] = eng
+        if plan is None:
+            # least recently used PROGRAMS go first, but never one with a launch still running (the cache then grows)
+            for pk in list(self._plans):
+                if len(self._plans) < max(1, self.max_plans):
+                    break
+                if not self._plan_busy(self._plans[pk]):
+                    for e in self._plans.pop(pk)["engines"].values():
+                        if e.graph is not None:
+                            e.ops.graph_destroy(e.graph)
+                            e.graph = None
+            eng = self.model.make_slot(share_plan=False)  # its own schedule constants: the other programs keep running
+            plan = self._plans[plan_key] = {"root": eng, "opts": opts, "engines": {}}
+        else:
+            eng = plan["root"].make_slot()
+        if prompt is not None:
+            eng.use_prompt(prompt)
+        if self.is_xl:  # micro-conditioning: original size = target size = the frame size, no crop
+            eng.set_added_cond(self.encode_pooled(prompt_text if prompt_text is not None else ""), (height, width, 0, 0, height, width))
+        eng.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch, ref_mode=use_ref,
+                    autotune=self.tuning_mode != "table")
+        eng._ref_epoch = None
+        plan["engines"][(batch, lane)] = eng
         self._note("prepare", t0)
         return eng
+
+    def export_tuning(self):
+        """The per-shape kernel choices of this process (table + what `prepare` measured), for `import_tuning` elsewhere."""
+        return {k: tuple(v) for k, v in self.model.ops.tile_override.items()}
+
+    def import_tuning(self, table):
+        """Take another process's choices for shapes this one has none for yet (rank 0's after its warm-up: every rank then
+        builds the same kernels for the same shapes -- same bits whichever rank a frame lands on)."""
+        n = 0
+        for k, v in table.items():
+            if k not in self.model.ops.tile_override:
+                self.model.ops.tile_override[k] = tuple(v)
+                n += 1
+        return n
 
     # `VideoSDPipeline.remote(**config)` -> awaitable handle (replaces the Ray actor API, server.py:320-321)
     @classmethod
