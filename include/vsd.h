@@ -105,20 +105,13 @@ typedef struct vsd_conv_desc {
                              DMA issues interleaved between the MFMAs (single-basic-block iterations); 7 = halo patch:
                              3x3 stride-1 convs only (Cin % 64 == 0 per source, tile 128x128, 128x64, 256x128 or
                              256x64, plain epilogue): the (8+2)x(16+2) input patch of a 64-channel block is
-                             staged in LDS once and serves all nine taps; 8 = 8-stage direct-to-LDS ring (64x64 tile, Cin %
-                             64 == 0, no resize): 112 KB in flight per workgroup for the weight-streaming layers;
-                             9 = weight-streaming form for the small-image levels (csrc/conv_skinny.hip): M <= 192 rows,
-                             ksize 1 or 3 with stride 1 and pad ksize/2, no resize, Cin % 128 == 0 per source and >= 256,
-                             n % 64 == 0, needs weight_frag, `tile` ignored, split_k must be Cin / 128 (the slabs are
-                             reduced by the second kernel, so no rowstat_out / chanstat_out / GEGLU / softmax / out_t);
-                             10 = weights-resident persistent form (csrc/conv_resident.hip): 3x3 stride-1 conv with exactly 64 input
-                             (one source) and 64 output channels (the TAESD blocks), plain epilogue as for 7, split_k 1, `tile`
-                             ignored: every wave keeps the nine taps' weights of its 32 output channels in registers, persistent workgroups
-                             walk the 8x16-pixel patches, results bit-identical to 7 */
+                             staged in LDS once and serves all nine taps.  (Round 2's forms 8 / 9 / 10 -- an 8-stage ring, a weight-streaming form
+                             for M <= 192 and a weights-resident persistent conv -- measured at parity or behind these and were removed
+                             in round 3; DESIGN.md keeps the findings.) */
   void* rowstat_out;      /* optional fp32 [M][n/64][2]: per output row, (sum, sum of squares) of the fp16 outputs over
                              each 64-column group -- the LayerNorm statistics of the NEXT layer, for free */
   void* chanstat_out;     /* optional fp32 [n][2]: per output CHANNEL, (sum, sum of squares) of the fp16 outputs over all M
-                             rows -- the GroupNorm statistics of the next layer (vsd_groupnorm's chan_stats).  Needs
+                             rows (the reference-only mode's AdaIN statistics, vsd_adain).  Needs
                              chanstat_part (fp32 scratch, ceil(M/BM) * n * 2 floats, BM >= 64) and chan_counters
                              (ceil(n/64) int32, all zero; left at zero).  The last workgroup of each column block folds
                              the per-tile partials in tile order: deterministic. */
@@ -150,9 +143,6 @@ typedef struct vsd_conv_desc {
                              (scores_h = LN(x) (scale K_h Wq_h)^T, one 128-column group per head), the GEMM tile IS the score
                              block of one head and this epilogue turns it into probabilities: cross-attention over the 77
                              text tokens (Attention.forward of attn2 under lcm_controlnet.py:568) as two plain GEMMs. */
-  const void* weight_frag; /* pipeline 9 only: the same [n][k] weights fragment-major -- blocks [n/16][k/32] of 1 KB, each
-                             [k/8 mod 4][n mod 16][8 halfs] -- so that one wave load instruction fetches one contiguous KB
-                             straight into the B operand registers of v_mfma_f32_16x16x32_f16 (k % 32 == 0, kp == k) */
 } vsd_conv_desc;
 #define VSD_SPLITK_MAX_TILES 16384
 
@@ -184,12 +174,6 @@ int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int 
 int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int batch, int groups,
                           float eps, const void* gamma, const void* beta, int silu, void* out, void* workspace,
                           void* stream);
-/* Same as vsd_groupnorm, with the statistics pass skipped: chan0 / chan1 are the per-channel (sum, sumsq) fp32 [c][2] arrays the
- * producing vsd_conv_gemm launches left behind (chanstat_out) for src0 / src1.  One kernel instead of two. */
-int vsd_groupnorm_prestat(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int groups, float eps,
-                          const void* gamma, const void* beta, int silu, void* out, const void* chan0, const void* chan1,
-                          void* stream);
-
 /* ---- LayerNorm over the last dimension (BasicTransformerBlock.norm1/2/3, CLIP layer norms) -------- */
 int vsd_layernorm(vsd_ctx* ctx, const void* x, int rows, int c, const void* gamma, const void* beta, float eps,
                   void* out, void* stream);

@@ -36,7 +36,22 @@ for name, H, Wd, steps, cn, scale in [("config1 256x256 1-step +CN", 256, 256, 1
     for e in slots: e.ops.synchronize()
     fps3 = n / (time.perf_counter() - t)
     row = {"config": name, "p50_latency_ms_1_in_flight": round(sorted(lat)[6], 2), "fps_3_in_flight": round(fps3, 1)}
+    out.append(row)
     print(json.dumps(row), flush=True)
+
+# ---- the reference-only mode (lcm_reference_pipeline.py:855-890: a WRITE pass and a READ pass of the UNet per step,
+#      no ControlNet, one frame per launch): what `ref=True` costs next to the plain UNet-only frame above
+eng.overlap_controlnet = True
+eng.prepare(512, 512, 4, 0.6, use_controlnet=False, ref_mode=True)
+f = np.random.default_rng(0).integers(0, 256, (512, 512, 3), dtype=np.uint8)
+eng.ops.upload(eng.ref_u8, torch.from_numpy(np.random.default_rng(1).integers(0, 256, (512, 512, 3), dtype=np.uint8)))
+lat = []
+for i in range(12):
+    t = time.perf_counter(); eng.infer_u8(f); lat.append((time.perf_counter() - t) * 1e3)
+row = {"config": "reference-only (ref=True) 512x512 4-step, no CN, 1 frame per launch", "p50_latency_ms_1_in_flight": round(sorted(lat)[6], 2),
+       "fps_1_in_flight": round(1e3 / sorted(lat)[6], 1)}
+out.append(row)
+print(json.dumps(row), flush=True)
 
 # ---- BASELINE configs[3]: SDXL 1024x1024 LCM 4-step (UNet only path: no ControlNet), 1 frame per launch
 del slots, eng, wu, wc
@@ -60,6 +75,9 @@ t = time.perf_counter()
 for i in range(12): (xl, s2)[i % 2].launch()
 for e in (xl, s2): e.ops.synchronize()
 fps2 = 12 / (time.perf_counter() - t)
-ops.save_tuning(os.path.join("gpurun_out", "tuning_with_sdxl.json"))
-print(json.dumps({"config": "config4 SDXL 1024x1024 4-step (27.0 TFLOP/frame)", "p50_latency_ms_1_in_flight": round(sorted(lat)[4], 2),
-                  "fps_2_in_flight": round(fps2, 2), "mfma_frac_at_that_fps": round(27.04 * fps2 / 2500.0, 4)}), flush=True)
+row = {"config": "config4 SDXL 1024x1024 4-step (27.0 TFLOP/frame)", "p50_latency_ms_1_in_flight": round(sorted(lat)[4], 2),
+       "fps_2_in_flight": round(fps2, 2), "mfma_frac_at_that_fps": round(27.04 * fps2 / 2500.0, 4)}
+out.append(row)
+print(json.dumps(row), flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open(os.path.join("gpurun_out", "bench_configs.json"), "w"), indent=1)

@@ -6,5 +6,5 @@ rm -rf /tmp/pmc_a /tmp/pmc_b
 timeout 500 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d /tmp/pmc_a -- python3 scripts/profile_frame.py --batch=${NB:-5} sq_a > /tmp/pmc_a.log 2>&1; tail -2 /tmp/pmc_a.log | cut -c1-200
 timeout 500 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/pmc_b -- python3 scripts/profile_frame.py --batch=${NB:-5} sq_b > /tmp/pmc_b.log 2>&1; tail -2 /tmp/pmc_b.log | cut -c1-200
 ls /tmp/pmc_a/*/ /tmp/pmc_b/*/ | head
-N=$(python3 -c "import json; print(len(json.load(open('gpurun_out/ops_sq_a.json'))))" 2>/dev/null || echo 2157)
-python3 scripts/pmc_sq_summary.py "gpurun_out/${TAG:-round2}_pmc_sq.json" "$N" /tmp/pmc_a/*/*_counter_collection.csv /tmp/pmc_b/*/*_counter_collection.csv | cut -c1-1500
+N=0  # the last eager frame (from its preprocess_rgb dispatch on)
+python3 scripts/pmc_sq_summary.py "gpurun_out/${TAG:-round3}_pmc_sq.json" "$N" /tmp/pmc_a /tmp/pmc_b | cut -c1-2500

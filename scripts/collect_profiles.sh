@@ -24,4 +24,4 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_$C -- python3 scripts/profile_frame.py --batch=$NB ${TAG}_pmc > /tmp/pmc_$C.log 2>&1
 done
-python3 scripts/pmc_summary.py /tmp/pmc_FETCH_SIZE/*/*_counter_collection.csv /tmp/pmc_WRITE_SIZE/*/*_counter_collection.csv gpurun_out/ops_${TAG}_pmc.json gpurun_out/${TAG}_pmc_conv_gemm.json
+python3 scripts/pmc_summary.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE gpurun_out/ops_${TAG}_pmc.json gpurun_out/${TAG}_pmc_conv_gemm.json

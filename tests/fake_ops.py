@@ -163,29 +163,16 @@ class FakeOps:
         if out2 is not None:
             out2[:, :nout] = (y + add2[:, :nout].float()).half()
 
-    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=None, batch=1):
+    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, batch=1):
         if batch > 1:
-            assert chan_stats is None
             for b in range(batch):
                 sl = slice(b * hw, (b + 1) * hw)
-                self.groupnorm(src0[sl], None if src1 is None else src1[sl], c0, c1, hw, groups, eps, gamma, beta, silu,
-                               out[sl])
+                self.groupnorm(src0[sl], None if src1 is None else src1[sl], c0, c1, hw, groups, eps, gamma, beta, silu, out[sl])
             return
         x = src0[:, :c0].float()
         if src1 is not None and c1:
             x = torch.cat([x, src1[:, :c1].float()], dim=1)
-        if chan_stats is not None:  # normalise with the statistics the producers handed over (checks the wiring)
-            cs = chan_stats[0].float() if chan_stats[1] is None else torch.cat([chan_stats[0].float(), chan_stats[1].float()])
-            c = c0 + c1
-            g = cs.reshape(groups, c // groups, 2).sum(dim=1)
-            n = hw * (c // groups)
-            mean = g[:, 0] / n
-            rstd = torch.rsqrt((g[:, 1] / n - mean * mean).clamp_min(0) + eps)
-            mean_c = mean.repeat_interleave(c // groups)
-            rstd_c = rstd.repeat_interleave(c // groups)
-            y = (x - mean_c[None]) * rstd_c[None] * gamma.float()[None] + beta.float()[None]
-        else:
-            y = F.group_norm(x.t()[None], groups, gamma.float(), beta.float(), eps)[0].t()
+        y = F.group_norm(x.t()[None], groups, gamma.float(), beta.float(), eps)[0].t()
         if silu:
             y = F.silu(y)
         out[:, : c0 + c1] = y.half()

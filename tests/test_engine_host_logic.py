@@ -106,23 +106,6 @@ def test_batched_frames_equal_single_frames(mini, H, Wd, cn):
         eng.infer_u8(frames[0])
 
 
-def test_fused_groupnorm_statistics_wiring(mini):
-    """The optional producer-side GroupNorm statistics (chanstat_out -> groupnorm(chan_stats=...)) reach every
-    GroupNorm with the right tensors: same image as the default path, through the emulator."""
-    wu, wc, wv, text = mini
-    outs = []
-    for fuse in (False, True):
-        eng = Engine(FakeOps(), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
-        eng.fuse_gn_stats = fuse
-        eng.set_text_embeds(text)
-        eng.prepare(64, 64, 2, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
-        n_pre = sum(1 for fn, a, k in eng.program.calls if fn.__name__ == "groupnorm" and k.get("chan_stats") is not None)
-        n_gn = sum(1 for fn, a, k in eng.program.calls if fn.__name__ == "groupnorm")
-        assert (n_pre == n_gn) if fuse else (n_pre == 0)
-        outs.append(eng.infer_u8(_frame(64, 64)))
-    assert np.abs(outs[0].astype(int) - outs[1].astype(int)).mean() < 0.5
-
-
 def test_prepare_rejects_bad_sizes_and_missing_text(mini):
     wu, wc, wv, text = mini
     eng = Engine(FakeOps(), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)

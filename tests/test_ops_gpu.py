@@ -359,8 +359,8 @@ def test_groupnorm(ops, c0, c1, hw, silu, eps):
 
 @pytest.mark.parametrize("h,w,c0,c1,cout,tile,split", [(16, 16, 128, 64, 192, 2, 1), (18, 14, 64, 0, 320, 1, 3),
                                                         (64, 64, 64, 0, 64, 0, 1), (8, 8, 640, 640, 1280, 2, 4)])
-def test_fused_groupnorm_statistics(ops, h, w, c0, c1, cout, tile, split):
-    """conv epilogue leaves per-channel (sum, sumsq); GroupNorm over [conv out | other tensor] uses them."""
+def test_conv_channel_statistics_output(ops, h, w, c0, c1, cout, tile, split):
+    """conv epilogue leaves per-channel (sum, sumsq) of its output (chanstat_out: the reference-only mode's AdaIN statistics)."""
     from videosd_amd.ops import Geom
     from videosd_amd.packing import pack_conv
 
@@ -381,20 +381,6 @@ def test_fused_groupnorm_statistics(ops, h, w, c0, c1, cout, tile, split):
         assert torch.allclose(cs[:, 0].cpu(), o.sum(dim=0), rtol=1e-4, atol=2e-2), rep
         assert torch.allclose(cs[:, 1].cpu(), (o * o).sum(dim=0), rtol=1e-4, atol=2e-2), rep
     assert int(ops._chan_counters[0].abs().sum()) == 0
-    # GroupNorm over the concat [out | other] with pre-computed statistics == the two-kernel GroupNorm
-    other = rnd(hw, 64, seed=7).cuda()
-    ocs = torch.stack([other.float().sum(dim=0), (other.float() ** 2).sum(dim=0)], dim=1).contiguous()
-    c = cout + 64
-    gamma, beta = (1 + 0.1 * rnd(c, seed=5).float()).half().cuda(), rnd(c, seed=6, scale=0.1).cuda()
-    y1 = torch.zeros(hw, c, dtype=torch.float16, device="cuda")
-    y2 = torch.zeros(hw, c, dtype=torch.float16, device="cuda")
-    ops.groupnorm(out, other, cout, 64, hw, 32, 1e-5, gamma, beta, True, y1)
-    ops.groupnorm(out, other, cout, 64, hw, 32, 1e-5, gamma, beta, True, y2, chan_stats=(cs, ocs))
-    ops.synchronize()
-    x = torch.cat([o, other.float().cpu()], dim=1)
-    ref = F.silu(F.group_norm(x.t()[None], 32, gamma.float().cpu(), beta.float().cpu(), 1e-5)[0].t())
-    check(y1, ref, "gn two-kernel")
-    check(y2, ref, "gn prestat")
 
 
 @pytest.mark.parametrize("rows,c", [(4096, 320), (77, 768), (5, 1280), (1000, 64), (64, 1536)])
@@ -906,171 +892,3 @@ def test_conv3x3_halo_patch_batched(ops):
     ops.synchronize()
     ref = F.silu(F.conv2d(xs.float(), wt.float(), bias.float(), padding=1)).permute(0, 2, 3, 1).reshape(g.m, cout)
     check(out, ref, "batched halo conv")
-
-
-@pytest.mark.parametrize("split_k,inkernel", [(1, True), (3, True), (3, False)])
-def test_conv_deep_ring_pipeline8(ops, split_k, inkernel):
-    """pipeline 8: 8-stage direct-to-LDS ring (64x64 tile) for the tiny-M / deep-K weight-streaming layers."""
-    h, w, cin, cout = 8, 8, 1280, 200  # K = 11520 (180 tiles), M = 64
-    x = rnd(1, cin, h, w, seed=1)
-    wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
-    res = rnd(h * w, cout, seed=5)
-    ops.inkernel_splitk = inkernel
-    got, ref = run_conv(ops, [x], h, w, wt, rnd(cout, seed=3, scale=0.1), ksize=3, tile=2, split_k=split_k, pipeline=8, residual=res, act=2)
-    base, _ = run_conv(ops, [x], h, w, wt, rnd(cout, seed=3, scale=0.1), ksize=3, tile=2, split_k=split_k, pipeline=3, residual=res, act=2)
-    ops.inkernel_splitk = True
-    check(got, ref, f"deep ring split={split_k}")
-    assert torch.equal(got, base)  # same tile order, same summation order as the 3-stage ring
-    # short K (fewer tiles than stages)
-    x2 = rnd(1, 128, 5, 7, seed=7)
-    w2 = rnd(72, 128, 3, 3, seed=8, scale=(128 * 9) ** -0.5)
-    got, ref = run_conv(ops, [x2], 5, 7, w2, None, ksize=3, tile=2, split_k=1, pipeline=8)
-    check(got, ref, "deep ring short K")
-
-
-@pytest.mark.parametrize("B,h,w,cins,cout,ksize", [
-    (3, 8, 8, (1280,), 1280, 3),      # the 8x8 level at three frames per launch (M = 192, 12 row fragments)
-    (3, 8, 8, (1280, 1280), 640, 3),  # decoder: concat sources
-    (1, 8, 8, (256,), 64, 3),         # one frame (4 row fragments), the smallest K split
-    (2, 8, 8, (384,), 128, 3),        # two frames (8 row fragments), 3 slices
-    (1, 12, 12, (512,), 192, 3),      # 768 x 768 deepest level: 144 pixels, 14 x 14 padded patch
-    (3, 5, 7, (256,), 64, 3),         # ragged image, M = 105 (rows past M inside the last fragment)
-    (3, 8, 8, (1280,), 1280, 1),      # linear layer at the same level
-    (1, 4, 4, (640, 128), 320, 1),    # 16 rows, unequal concat sources
-])
-def test_conv_weight_streaming_pipeline9(ops, B, h, w, cins, cout, ksize):
-    """pipeline 9 (csrc/conv_skinny.hip): the small-image weight-streaming form -- every weight byte loaded once,
-    fragment-major, against all M rows; 128-channel slices reduced by the split-K reducer with the layer's epilogue --
-    against F.conv2d in fp32, and bit-identical to itself across launches."""
-    from videosd_amd.ops import Geom
-    from videosd_amd.packing import pack_conv
-
-    cin = sum(cins)
-    xs = [rnd(B, c, h, w, seed=1 + i) for i, c in enumerate(cins)]
-    wt = rnd(cout, cin, ksize, ksize, seed=5, scale=(cin * ksize * ksize) ** -0.5)
-    bias, rv = rnd(cout, seed=6, scale=0.1), rnd(cout, seed=7, scale=0.1)
-    pw = ops.to_device_pack(pack_conv(wt, bias))
-    g = Geom.conv(h, w, ksize=ksize, batch=B)
-    res = rnd(g.m, cout, seed=8)
-    srcs = [x.permute(0, 2, 3, 1).reshape(B * h * w, -1).contiguous().cuda() for x in xs]
-    out = torch.zeros(g.m, cout, dtype=torch.float16, device="cuda")
-    kw = dict(c0=cins[0], c1=cins[1] if len(cins) > 1 else 0, act=2, rowvec=rv.cuda(), residual=res.cuda(), pipeline=9)
-    ops.conv(srcs[0], srcs[1] if len(srcs) > 1 else None, g, pw, out, **kw)
-    ops.synchronize()
-    assert pw.weight_frag is not None
-    ref = F.conv2d(torch.cat([x.float() for x in xs], dim=1), wt.float(), bias.float(), padding=ksize // 2) + rv.float()[None, :, None, None]
-    ref = F.silu(ref).permute(0, 2, 3, 1).reshape(g.m, cout) + res.float()
-    check(out, ref, f"weight-streaming conv B={B} {h}x{w} {cins}->{cout} k={ksize}")
-    again = torch.zeros_like(out)
-    ops.conv(srcs[0], srcs[1] if len(srcs) > 1 else None, g, pw, again, **kw)
-    ops.synchronize()
-    assert torch.equal(out, again)
-    # same sums as the general kernel's split-K over the same number of slices would give up to fp32 association: compare
-    # with the tiled kernel at tolerance, not bitwise
-    base = torch.zeros_like(out)
-    ops.conv(srcs[0], srcs[1] if len(srcs) > 1 else None, g, pw, base, **dict(kw, pipeline=3, tile=2, split_k=1))
-    ops.synchronize()
-    assert float((out.float() - base.float()).abs().max()) <= 4e-3 * max(1.0, float(base.float().abs().max()))
-
-
-def test_conv_weight_streaming_rejects_what_it_cannot_do(ops):
-    from videosd_amd.ops import Geom
-    from videosd_amd.packing import pack_conv
-
-    # 16 x 16 x 3 frames: M = 768 > 192 -- a tuning-table entry for pipeline 9 must not be applied to such a call
-    x = rnd(3, 256, 16, 16, seed=1)
-    wt = rnd(64, 256, 3, 3, seed=2, scale=(256 * 9) ** -0.5)
-    pw = ops.to_device_pack(pack_conv(wt, None))
-    g = Geom.conv(16, 16, batch=3)
-    out = torch.zeros(g.m, 64, dtype=torch.float16, device="cuda")
-    ops.conv(x.permute(0, 2, 3, 1).reshape(-1, 256).contiguous().cuda(), None, g, pw, out, pipeline=9)  # falls back to the tiled form
-    ops.synchronize()
-    ref = F.conv2d(x.float(), wt.float(), None, padding=1).permute(0, 2, 3, 1).reshape(g.m, 64)
-    check(out, ref, "pipeline 9 fallback")
-    # asked for directly through the C-ABI with the wrong split: an error, not a wrong answer
-    import ctypes as C
-
-    from videosd_amd import lib as L
-
-    x2 = rnd(1, 256, 8, 8, seed=3).permute(0, 2, 3, 1).reshape(64, 256).contiguous().cuda()
-    out2 = torch.zeros(64, 64, dtype=torch.float16, device="cuda")
-    ops.conv(x2, None, Geom.conv(8, 8), pw, out2, pipeline=9)
-    ops.synchronize()
-    d = L.ConvDesc()
-    d.src0, d.c0, d.hs, d.ws, d.hi, d.wi, d.ho, d.wo = x2.data_ptr(), 256, 8, 8, 8, 8, 8, 8
-    d.ksize, d.stride, d.pad, d.weight, d.n, d.k, d.kp = 3, 1, 1, pw.weight.data_ptr(), 64, 2304, 2304
-    d.out, d.ldo, d.ldr, d.out_scale, d.tile, d.split_k, d.pipeline = out2.data_ptr(), 64, 64, 1.0, 2, 3, 9
-    d.weight_frag = pw.weight_frag.data_ptr()
-    d.workspace = torch.zeros(3 * 64 * 64, device="cuda").data_ptr()
-    assert ops.ctx.lib.vsd_conv_gemm(ops.ctx.h, C.byref(d), ops.s) != 0
-    assert b"split_k must be Cin / 128" in ops.ctx.lib.vsd_last_error(ops.ctx.h)
-
-
-@pytest.mark.parametrize("B,hs,ws,up,act,with_res", [
-    (1, 16, 16, None, 1, False),          # two patches, bias + ReLU
-    (3, 24, 40, None, 1 | 256, True),     # patches hanging over the right edge, residual then ReLU (the TAESD block's last conv)
-    (2, 27, 19, None, 2, True),           # ragged both ways, SiLU + residual
-    (5, 64, 128, None, 1, True),          # 320 patches > 256 workgroups: the persistent loop, double-buffered halo prefetch
-    (2, 16, 24, (32, 48), 0, False),      # the decoder's Upsample(2x) folded into the conv
-    (1, 8, 8, None, 0, False),            # a single patch
-])
-def test_conv_weights_resident_pipeline10(ops, B, hs, ws, up, act, with_res):
-    """pipeline 10 (csrc/conv_resident.hip): the 64 -> 64 channel 3x3 convs of TAESD with all nine weight tiles resident in
-    LDS and one persistent workgroup per CU -- against F.conv2d in fp32, and bit-identical to the halo-patch kernel (same
-    fragments, same summation order)."""
-    from videosd_amd.ops import Geom
-    from videosd_amd.packing import pack_conv
-
-    cin = cout = 64
-    x = rnd(B, cin, hs, ws, seed=1)
-    wt = rnd(cout, cin, 3, 3, seed=2, scale=(cin * 9) ** -0.5)
-    bias, rv = rnd(cout, seed=3, scale=0.1), rnd(cout, seed=4, scale=0.1)
-    pw = ops.to_device_pack(pack_conv(wt, bias))
-    g = Geom.conv(hs, ws, up_to=up, batch=B)
-    res = rnd(g.m, cout, seed=5) if with_res else None
-    xs = x.permute(0, 2, 3, 1).reshape(B * hs * ws, cin).contiguous().cuda()
-    kw = dict(act=act, rowvec=rv.cuda())
-    if with_res:
-        kw["residual"] = res.cuda()
-    out = torch.zeros(g.m, cout, dtype=torch.float16, device="cuda")
-    ops.conv(xs, None, g, pw, out, pipeline=10, tile=1, **kw)
-    halo = torch.zeros_like(out)
-    ops.conv(xs, None, g, pw, halo, pipeline=7, tile=1, split_k=1, **kw)
-    ops.synchronize()
-    xin = x.float() if up is None else F.interpolate(x.float(), size=up, mode="nearest")
-    ref = F.conv2d(xin, wt.float(), bias.float(), padding=1) + rv.float()[None, :, None, None]
-    a = act & 0xff
-    post = bool(act & 256)
-    if a == 1 and not post:
-        ref = F.relu(ref)
-    elif a == 2:
-        ref = F.silu(ref)
-    ref = ref.permute(0, 2, 3, 1).reshape(g.m, cout)
-    if with_res:
-        ref = ref + res.float()
-    if post:
-        ref = F.relu(ref)
-    check(out, ref, f"weights-resident conv B={B} {hs}x{ws} up={up} act={act}")
-    if a == 2:  # (the SiLU epilogue is compiled in another context: the exp / rcp sequence may round differently by an fp16 ulp)
-        assert float((out.float() - halo.float()).abs().max()) <= 2e-3 * max(1.0, float(halo.float().abs().max()))
-    else:
-        assert torch.equal(out, halo)
-    again = torch.full_like(out, 3.0)
-    ops.conv(xs, None, g, pw, again, pipeline=10, tile=1, **kw)
-    ops.synchronize()
-    assert torch.equal(out, again)
-
-
-def test_conv_weights_resident_falls_back_for_other_shapes(ops):
-    """A tuning-table entry for pipeline 10 must never be applied to a call it cannot serve (other channel counts)."""
-    from videosd_amd.ops import Geom
-    from videosd_amd.packing import pack_conv
-
-    x = rnd(1, 128, 16, 16, seed=1)
-    wt = rnd(64, 128, 3, 3, seed=2, scale=(128 * 9) ** -0.5)
-    pw = ops.to_device_pack(pack_conv(wt, None))
-    g = Geom.conv(16, 16)
-    out = torch.zeros(g.m, 64, dtype=torch.float16, device="cuda")
-    ops.conv(x.permute(0, 2, 3, 1).reshape(-1, 128).contiguous().cuda(), None, g, pw, out, pipeline=10, tile=1)
-    ops.synchronize()
-    check(out, F.conv2d(x.float(), wt.float(), None, padding=1).permute(0, 2, 3, 1).reshape(g.m, 64), "pipeline 10 fallback")

@@ -293,6 +293,37 @@ def test_baseline_config5_768_eight_step_scale2_matches_oracle(sd15_setup):
     assert r0 <= 5e-3 and r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (r0, r1, mad, psnr)
 
 
+@pytest.mark.slow
+def test_reference_only_mode_512_four_step_matches_oracle(sd15_setup):
+    """SURVEY 8f-4 at FULL size (tested at 128x192 and 64x64 only): the reference-only program
+    (lcm_reference_pipeline.py:498-794, 855-890: per step a WRITE pass over the noised reference latents banks self-attention
+    K / V and block statistics, the READ pass attends over [x ; bank] -- 8192 keys at the 64x64 level -- and applies AdaIN) at
+    512x512, 4 steps, against the oracle restatement; and what it costs (the mode doubles the UNet work)."""
+    import time
+
+    eng, orc, text = sd15_setup
+    H = W = 512
+    eng.prepare(H, W, 4, 0.6, use_controlnet=False, ref_mode=True)
+    frame, refimg = _frame(H, W, seed=51), _frame(H, W, seed=52)
+    eng.ops.upload(eng.ref_u8, torch.from_numpy(refimg))
+    got = eng.infer_u8(frame)
+    want = np.asarray(orc.infer(Image.fromarray(frame, "RGB"), text[None].float(), height=H, width=W, strength=0.6, steps=4, seed=23,
+                                ref_image=Image.fromarray(refimg, "RGB"), keep_trace=True))
+    den = eng.buffers["denoised"][:, :4].float().cpu().reshape(H // 8, W // 8, 4).permute(2, 0, 1)
+    ref_den = orc.trace["denoised"][-1][0]
+    r1 = float((den - ref_den).norm() / ref_den.norm())
+    mad = float(np.abs(got.astype(int) - want.astype(int)).mean())
+    assert r1 <= 2e-2 and mad <= 1.5 and _psnr(got, want) >= 38.0, (r1, mad, _psnr(got, want))
+    assert np.array_equal(got, eng.infer_u8(frame))  # deterministic replay
+    lat = []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        eng.infer_u8(frame)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    print(f"reference-only 512x512 4-step: {sorted(lat)[3]:.1f} ms/frame (host u8 in -> host u8 out, one frame per launch)")
+    eng.prepare(H, W, 4, 0.6, controlnet_scale=1.0, use_controlnet=True)  # (leave the shared engine in its usual state)
+
+
 @pytest.mark.parametrize("cfg_name", ["MINI_CLIP", "CLIP_L"])
 def test_clip_text_encoder_matches_oracle(cfg_name):
     """CLIP text encoder on the HIP kernels vs the oracle restatement (itself pinned against transformers)."""

@@ -95,3 +95,13 @@ def test_sdxl_1024_properties(full_xl):
     assert torch.isfinite(eng.buffers["denoised"].float()).all() and a.std() > 1.0
     eng.prepare(H, W, 4, 0.6, use_controlnet=False, use_graph=False)
     assert np.array_equal(a, eng.infer_u8(f))
+
+
+@pytest.mark.slow
+def test_sdxl_1024_four_step_matches_oracle(full_xl):
+    """BASELINE.json configs[3] at FULL size against the oracle (properties only until now): 1024x1024, 4 LCM steps,
+    the 10-deep transformer stacks at 32x32 and the two-block stacks at 64x64 with the tiles / split-K full size selects.
+    (Several minutes of CPU oracle: 27 TFLOP in fp32.)"""
+    eng, orc, text, pooled = full_xl
+    r1, mad, psnr = _compare(eng, orc, text, pooled, 1024, 1024, 4)
+    assert r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (r1, mad, psnr)

@@ -95,6 +95,22 @@ __device__ __forceinline__ float quick_gelu_f(float x) { return x * __builtin_am
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Division by a launch constant without the ~40-instruction runtime integer division (five to eight of them sat in the
+// prologue of every conv workgroup: block -> tile, row -> (image, y, x)).  q = (umulhi(x, mul) + x) >> shr, exact for
+// 0 <= x < 2^31 and 1 <= d < 2^31 (the round-up multiplier of Granlund / Montgomery; d = 1 gives mul = 1, shr = 0).
+struct FastDiv {
+  unsigned mul, shr;
+};
+static inline FastDiv fast_div(unsigned d) {
+  FastDiv f;
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shr = s;
+  f.mul = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+  return f;
+}
+__device__ __forceinline__ int fdiv(int x, FastDiv f) { return (int)((__umulhi((unsigned)x, f.mul) + (unsigned)x) >> f.shr); }
+
 // Workgroup timeline (development builds only: -DVSD_WG_TIMELINE, videosd_amd.build.build_timeline): every workgroup of the
 // instrumented kernels leaves its start / main-loop-done / end time (s_memrealtime, 100 MHz) and where it ran (HW_ID,
 // XCC_ID) in a log buffer, one region per launch [grid, kind, 8 words per workgroup ...], so that a launch's duration can

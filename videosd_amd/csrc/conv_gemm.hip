@@ -82,9 +82,8 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.ln_s = (const float*)d->ln_s;
   p.ln_t = (const float*)d->ln_t;
   const int stages = d->pipeline;
-  if (stages != 0 && (stages < 3 || stages > 10)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..10)", stages);
+  if (stages != 0 && (stages < 3 || stages > 7)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..7)", stages);
   const bool halo = stages == 7;
-  const bool skinny = stages == 9;
 
   if (!p.src0 || !p.w || !p.out) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: null src/weight/out");
   if (p.M <= 0 || p.N <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: empty problem M=%d N=%d", p.M, p.N);
@@ -107,51 +106,6 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   if (p.ln_part && (p.ksize != 1 || !p.ln_s || !p.ln_t || p.ln_groups <= 0 || p.bias))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: fused LayerNorm needs a 1x1 layer, ln_s/ln_t and no separate bias");
   if (p.split_k > 1 && !p.ws_partial) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: split_k needs a workspace");
-  if (stages == 10) {
-    // weights-resident persistent form (conv_resident.hip): 3x3 stride-1 conv, 64 -> 64 channels, the halo kernel's plain epilogue
-    const int act = p.act & 0xff;
-    const bool simple_epi = !p.out2 && !p.residual2 && !p.out_t && !p.rowstat_out && !p.chanstat_out && !p.ln_part && p.out_scale == 1.0f &&
-                            !p.out_scale_dev && (act == VSD_ACT_NONE || act == VSD_ACT_RELU || act == VSD_ACT_SILU) &&
-                            !((p.act & VSD_ACT_POST) && act != VSD_ACT_RELU);
-    if (!p.halo_ok || p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.c0 != 64 || p.c1 != 0 || p.N != 64 || p.Kp != 576 || !simple_epi ||
-        p.split_k != 1 || p.ldo % 8)
-      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the weights-resident form (pipeline 10) is a 3x3 stride-1 conv with 64 input and 64 output "
-                      "channels, the plain epilogue and no split-K");
-    p.counters = nullptr;
-    p.tiles_m = p.batch * cdiv(p.ho, 8) * cdiv(p.wo, 16);
-    p.tiles_n = 1;
-    LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
-    vsd_launch_conv_resident(p, p.tiles_m, s);
-    return ls.finish();
-  }
-  if (skinny) {
-    // weight-streaming form (conv_skinny.hip): one workgroup = 64 output channels x all M rows x 128 input channels
-    const int padded = p.batch * (p.hs + 2 * (p.ksize / 2)) * (p.ws + 2 * (p.ksize / 2));
-    const int act = p.act & 0xff;
-    if (!d->weight_frag || p.M > 192 || padded > vsd_conv_skinny_max_pixels() || p.stride != 1 || p.pad != p.ksize / 2 || p.resize ||
-        p.ho != p.hs || p.wo != p.ws || p.c0 % 128 || p.c1 % 128 || p.cin < 256 || p.N % 64 || p.Kp != p.K || p.rowstat_out || p.chanstat_out ||
-        p.out_t || act == VSD_ACT_GEGLU || act == VSD_ACT_SOFTMAX || (size_t)p.N * p.K * 2 >= 0x7fffffffull)
-      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the weight-streaming form (pipeline 9) needs weight_frag, M <= 192, a stride-1 same-size "
-                      "1x1 / 3x3 layer, Cin %% 128 == 0 per source (>= 256), N %% 64 == 0 and an epilogue the split-K reducer can apply");
-    if (p.split_k != p.cin / 128 || !p.ws_partial)
-      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline 9 splits over 128-channel slices: split_k must be Cin / 128 = %d (with a workspace)", p.cin / 128);
-    p.counters = nullptr;
-    p.tiles_m = 1;
-    p.tiles_n = p.N / 64;
-    p.kt_per_split = 0;
-    p.order = 0;
-    {
-      LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
-      vsd_launch_conv_skinny(p, (const half_t*)d->weight_frag, p.tiles_n * p.split_k, s);
-      int rc = ls.finish();
-      if (rc) return rc;
-    }
-    LaunchScope ls(ctx, s, VSD_FAM_SPLITK_REDUCE, 0.0);
-    size_t total = (size_t)p.M * ((p.N + 7) / 8);
-    int g = (int)((total + 255) / 256);
-    vsd_launch_splitk_reduce(p, g > 2048 ? 2048 : g, s);
-    return ls.finish();
-  }
   int BM, BN;
   switch (d->tile) {
     case VSD_TILE_128x128: BM = 128; BN = 128; break;
@@ -170,8 +124,6 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the halo-patch form (pipeline 7) needs a 3x3 stride-1 conv, Cin %% 64 == 0 per "
                       "source, a 128- or 256-row tile and the plain epilogue");
   }
-  if (stages == 8 && (d->tile != VSD_TILE_64x64 || !p.fast))
-    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 8-stage ring (pipeline 8) exists for the 64x64 tile on the buffer-load path only");
   if (!halo && BM == 256 && (BN != 128 || !p.fast || (stages != 3 && stages != 5)))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 256x128 tile exists for the buffer-load path (Cin %% 64 == 0, no resize) "
                     "with the 3-stage ring (pipeline 3 or 5) only");
@@ -207,6 +159,15 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     const double by_a = a_bytes + w_bytes * (p.tiles_m < 8 ? p.tiles_m : 8);
     static const char* force = getenv("VSD_CONV_ORDER");
     p.order = force ? atoi(force) : (by_a < by_w ? 1 : 0);
+    const int S = p.order ? G : p.tiles_m;  // (block_to_tile)
+    p.fd_span = fast_div(8u * (unsigned)S);
+    p.fd_s = fast_div((unsigned)S);
+    p.fd_tiles_n = fast_div((unsigned)p.tiles_n);
+    p.fd_hw_out = fast_div((unsigned)p.hw_out);
+    p.fd_wo = fast_div((unsigned)p.wo);
+    const int ppr = cdiv(p.wo, 16), tpi = cdiv(p.ho, BM / 16) * ppr;  // halo: patches per row / per image (8x16 or 16x16 pixels)
+    p.fd_ppr = fast_div((unsigned)ppr);
+    p.fd_tpi = fast_div((unsigned)tpi);
   }
 #ifdef VSD_WG_TIMELINE
   p.wgtl = wgtl_claim(grid);

@@ -84,13 +84,14 @@ __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p
 
   int tile_m, grp;
   block_to_tile(p, blockIdx.x, tile_m, grp);  // XCD-aware order, as in conv_gemm_kernel
-  const int tile_n = grp % p.tiles_n;
-  const int split = grp / p.tiles_n;
+  const int split = fdiv(grp, p.fd_tiles_n);
+  const int tile_n = grp - split * p.tiles_n;
   const int n0 = tile_n * BN;
   // tile -> (image, patch origin)
   const int ppr = (p.wo + PW - 1) / PW, tpi = ((p.ho + PH - 1) / PH) * ppr;  // patches may hang over the right / bottom edge
-  const int img = tile_m / tpi, trem = tile_m - img * tpi;
-  const int y0 = (trem / ppr) * PH, x0 = (trem % ppr) * PW;
+  const int img = fdiv(tile_m, p.fd_tpi), trem = tile_m - img * tpi;  // (fd_tpi / fd_ppr: the host's multipliers for tpi / ppr)
+  const int prow = fdiv(trem, p.fd_ppr);
+  const int y0 = prow * PH, x0 = (trem - prow * ppr) * PW;
   const int pix0 = img * p.img_in;   // first SOURCE pixel of the image (hs x ws; nearest-resized to hi x wi = ho x wo on the fly)
   const int opix0 = img * p.hw_out;  // first output row of the image
   auto row_ok = [&](int r) { return y0 + (r >> 4) < p.ho && x0 + (r & 15) < p.wo; };

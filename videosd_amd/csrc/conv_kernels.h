@@ -80,6 +80,9 @@ struct ConvParams {
   int hw_out;   // ho * wo
   int img_in;   // hs * ws
   int t_img;    // transposed output: columns per image (image b's rows m land at b * t_img + (m - b * hw_out))
+  // launch constants as multipliers (common.h fdiv): block -> tile (span = 8 S, S, tiles_n: see block_to_tile), output row ->
+  // (image, y, x) (hw_out, wo), halo patch -> (image, patch row / column) (tiles per image, patches per row)
+  FastDiv fd_span, fd_s, fd_tiles_n, fd_hw_out, fd_wo, fd_tpi, fd_ppr;
 };
 
 #ifdef VSD_CONV_PROBE
@@ -105,14 +108,11 @@ inline long long* g_conv_probe = nullptr;
 // launchers of the tile families (one translation unit each; conv_gemm.hip dispatches)
 void vsd_launch_conv_128x128(const ConvParams& p, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_128x64(const ConvParams& p, int grid, int stages, hipStream_t s);
-void vsd_launch_conv_64x64(const ConvParams& p, int grid, int stages, hipStream_t s);   // stages 8: the 8-stage ring
+void vsd_launch_conv_64x64(const ConvParams& p, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_64x128(const ConvParams& p, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_256x128(const ConvParams& p, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_halo(const ConvParams& p, int bm, int bn, int grid, hipStream_t s);
 void vsd_launch_splitk_reduce(const ConvParams& p, int grid, hipStream_t s);
-void vsd_launch_conv_skinny(const ConvParams& p, const half_t* wfrag, int grid, hipStream_t s);  // conv_skinny.hip (pipeline 9)
-int vsd_conv_skinny_max_pixels();
-void vsd_launch_conv_resident(const ConvParams& p, int patches, hipStream_t s);  // conv_resident.hip (pipeline 10)
 
 namespace {
 
@@ -364,13 +364,14 @@ __device__ __forceinline__ void block_to_tile(const ConvParams& p, int bid, int&
   int prim, sec;
   if (bid < full * S) {
     const int span = 8 * S;
-    const int chunk = bid / span, r = bid - chunk * span;
+    const int chunk = fdiv(bid, p.fd_span), r = bid - chunk * span;
     prim = chunk * 8 + (r & 7);
     sec = r >> 3;
   } else {
     const int rem = bid - full * S;
-    prim = full + rem / S;
-    sec = rem - (rem / S) * S;
+    const int q = fdiv(rem, p.fd_s);
+    prim = full + q;
+    sec = rem - q * S;
   }
   tile_m = p.order ? prim : sec;
   grp = p.order ? sec : prim;
@@ -417,8 +418,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   // then fetched into one XCD's L2 once instead of once per XCD.  Pure speed: any placement gives the same result.
   int tile_m, grp;
   block_to_tile(p, blockIdx.x, tile_m, grp);
-  const int tile_n = grp % p.tiles_n;
-  const int split = grp / p.tiles_n;
+  const int split = fdiv(grp, p.fd_tiles_n);
+  const int tile_n = grp - split * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int KT = p.Kp / BK;
   const int kt_begin = split * p.kt_per_split;
@@ -441,11 +442,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       int mm = mvalid[i] ? m : 0;
       int b = 0;
       if (p.batch > 1) {
-        b = mm / p.hw_out;
+        b = fdiv(mm, p.fd_hw_out);
         mm -= b * p.hw_out;
       }
       ib[i] = b * p.img_in;
-      int oy = mm / p.wo, ox = mm - oy * p.wo;
+      int oy = fdiv(mm, p.fd_wo), ox = mm - oy * p.wo;
       iy0[i] = oy * p.stride - p.pad;
       ix0[i] = ox * p.stride - p.pad;
     }
@@ -617,11 +618,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         const int n = n0 + lr + 32 * i;
         bvoff[i] = n < p.N ? n * p.Kp * 2 + lc * 16 : OOB;
       }
-      const int k0 = kt_begin * BK;
-      cur_tap = k0 / p.cin;
-      cur_c = k0 - cur_tap * p.cin;
-      cur_ky = cur_tap / p.ksize;
-      cur_kx = cur_tap - cur_ky * p.ksize;
+      if (kt_begin > 0) {  // (only a later K split starts inside the tap / channel sequence)
+        const int k0 = kt_begin * BK;
+        cur_tap = k0 / p.cin;
+        cur_c = k0 - cur_tap * p.cin;
+        cur_ky = cur_tap / p.ksize;
+        cur_kx = cur_tap - cur_ky * p.ksize;
+      }
     }
 // fetch the cursor's tile into ring slot SLOT_, then (ADV_) move the cursor one K tile on
 #define VSD_ISSUE_FAST(SLOT_, ADV_)                                                                    \
@@ -708,9 +711,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       for (int t = 0; t < nt; ++t) {
         // tile t has landed once all but the younger tiles' loads are done; then everyone's has (barrier)
         const int rem = min(STAGES - 2, nt - 1 - t);
-        if (STAGES > 4 && rem >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
-        else if (STAGES > 4 && rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");  // (tail: over-waits a little)
-        else if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CPROBE(1)
@@ -1146,7 +1147,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
       half_t* row = p.out_t + (size_t)(n - p.t_col0) * p.ldt;
       int b = 0, mm = m;
       if (p.batch > 1) {
-        b = m / p.hw_out;
+        b = fdiv(m, p.fd_hw_out);
         mm = m - b * p.hw_out;
       }
       if (vec_ok && m + 8 <= p.M) {  // the 8 rows lie in one image (hw_out % 8 == 0) and the piece is 16-byte aligned
@@ -1158,7 +1159,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
           if (mi < p.M) {
             int col = mi;
             if (p.batch > 1) {
-              const int bi = mi / p.hw_out;
+              const int bi = fdiv(mi, p.fd_hw_out);
               col = bi * p.t_img + (mi - bi * p.hw_out);
             }
             row[col] = o[i];

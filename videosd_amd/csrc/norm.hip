@@ -26,8 +26,6 @@ struct GnParams {
   int silu;
   half_t* out;
   float* part;  // [nblk][groups][2]
-  const float* chan0;  // pre-computed per-channel (sum, sumsq) of src0 / src1 (fused into the producer), or null
-  const float* chan1;
   int nblk;     // stats workgroups (per image)
   int rpp;      // rows per pass = blockDim / c8
   int batch;    // images stacked along the rows (blockIdx.y): each normalised with its own statistics
@@ -119,17 +117,7 @@ __global__ void gn_apply_kernel(const GnParams p) {
   half8 xf2 = gn_load(p, okf2 ? rf + 2 * p.rpp : rsafe, ch8), xf3 = gn_load(p, okf3 ? rf + 3 * p.rpp : rsafe, ch8);
   const half8 ga = *reinterpret_cast<const half8*>(p.gamma + ch8 * 8);
   const half8 be = *reinterpret_cast<const half8*>(p.beta + ch8 * 8);
-  if (p.chan0) {
-    for (int i = t; i < npairs; i += blockDim.x) {
-      const int g = i >> 1, which = i & 1;
-      float acc = 0.f;
-      for (int j = 0; j < p.cpg; ++j) {
-        int c = g * p.cpg + j;
-        acc += (c < p.c0) ? p.chan0[c * 2 + which] : p.chan1[(c - p.c0) * 2 + which];
-      }
-      sm[i] = acc;
-    }
-  } else {
+  {
     // fold the statistics partials: (pair, chunk) per thread, chunk ch sums blocks ch, ch+nch, ... (16 loads at a time,
     // all independent), then the chunks are added in order: deterministic
     int nch = (int)blockDim.x / npairs;
@@ -301,21 +289,18 @@ __global__ void gn_fused_kernel(const GnParams p) {
 
 // launches the one-kernel form when the shape fits it (dry: only says whether it would); returns false otherwise
 static bool gn_try_fused(const GnParams& p, int batch, hipStream_t s, bool dry) {
-  if (p.chan0 || getenv("VSD_GN_NO_FUSED")) return false;
+  if (getenv("VSD_GN_NO_FUSED")) return false;
   // measured on MI355X (us, one launch vs two): 8x8x1280 5.5 vs 14.5; 16x16x1280 6.3 vs 14.2; 32x32x640 11.5 vs 13.6;
   // it loses with more registers per thread (32x32x1920: 133 vs 14) and with 20-byte row pieces at 64x64 (31 vs 15)
   if (!((p.hw <= 256 && p.cpg <= 40) || (p.hw <= 1024 && p.cpg <= 20))) return false;
   const int threads = p.hw <= 64 ? 64 : (p.hw <= 128 ? 128 : (p.hw <= 256 ? 256 : 1024));
-  const int rows = (p.hw + threads - 1) / threads;  // <= 4
   dim3 grid(p.groups, batch), block(threads);
   const bool a8 = p.cpg % 8 == 0 && p.c0 % 8 == 0 && p.c1 % 8 == 0;
   const bool a4 = p.cpg % 4 == 0 && p.c0 % 4 == 0 && p.c1 % 4 == 0;
 #define GN_GO(VW_, NV_)                                                                           \
   {                                                                                               \
     if (dry) return true;                                                                         \
-    if (rows <= 1) hipLaunchKernelGGL((gn_fused_kernel<VW_, NV_, 1>), grid, block, 0, s, p);      \
-    else if (rows <= 2) hipLaunchKernelGGL((gn_fused_kernel<VW_, NV_, 2>), grid, block, 0, s, p); \
-    else hipLaunchKernelGGL((gn_fused_kernel<VW_, NV_, 4>), grid, block, 0, s, p);                \
+    hipLaunchKernelGGL((gn_fused_kernel<VW_, NV_, 1>), grid, block, 0, s, p); /* threads >= hw: one row per thread */ \
     return true;                                                                                  \
   }
   if (a8 && p.cpg == 40) GN_GO(8, 5)
@@ -419,7 +404,6 @@ extern "C" int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void*
   p.hw = hw; p.groups = groups; p.cpg = p.c / groups; p.eps = eps;
   p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.silu = silu;
   p.out = (half_t*)out; p.part = (float*)workspace;
-  p.chan0 = nullptr; p.chan1 = nullptr;
   p.rpp = p.c8 >= 512 ? 1 : 512 / p.c8;
   if (p.rpp > hw) p.rpp = hw;
   const int threads = p.c8 * p.rpp;
@@ -448,36 +432,6 @@ extern "C" int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void*
     hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk, batch), dim3(threads), smem, s, p);
     return ls.finish();
   }
-}
-
-extern "C" int vsd_groupnorm_prestat(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int groups,
-                                     float eps, const void* gamma, const void* beta, int silu, void* out, const void* chan0,
-                                     const void* chan1, void* stream) {
-  if (!ctx) return VSD_ERR_ARG;
-  GnParams p;
-  p.src0 = (const half_t*)src0;
-  p.src1 = (const half_t*)src1;
-  p.c0 = c0;
-  p.c1 = src1 ? c1 : 0;
-  p.c = p.c0 + p.c1;
-  if (!src0 || !out || !gamma || !beta || !chan0 || (src1 && !chan1)) return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm_prestat: null pointer");
-  if (p.c0 % 8 || p.c1 % 8 || hw <= 0 || groups <= 0 || p.c % groups || groups > 256)
-    return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm_prestat: bad shape c0=%d c1=%d hw=%d groups=%d", c0, c1, hw, groups);
-  p.c8 = p.c / 8;
-  if (p.c8 > 1024) return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm_prestat: C=%d too large", p.c);
-  p.hw = hw; p.groups = groups; p.cpg = p.c / groups; p.eps = eps;
-  p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.silu = silu;
-  p.out = (half_t*)out; p.part = nullptr; p.nblk = 0; p.batch = 1;
-  p.chan0 = (const float*)chan0; p.chan1 = (const float*)chan1;
-  p.rpp = p.c8 >= 512 ? 1 : 512 / p.c8;
-  if (p.rpp > hw) p.rpp = hw;
-  const int threads = p.c8 * p.rpp;
-  hipStream_t s = (hipStream_t)stream;
-  int ablk = cdiv(hw, 2 * p.rpp);
-  if (ablk > 256) ablk = 256;
-  LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk), dim3(threads), (size_t)groups * 2 * sizeof(float), s, p);
-  return ls.finish();
 }
 
 extern "C" int vsd_layernorm(vsd_ctx* ctx, const void* x, int rows, int c, const void* gamma, const void* beta,

@@ -420,25 +420,16 @@ class Engine:
         self.use_graph = True
         self.is_slot = False
         self.batch = 1
-        # GroupNorm statistics can be produced by the convs' epilogues (chanstat_out); measured on MI355X this costs
-        # the short-lived conv workgroups more (LDS fold + arrival ticket at their tail) than the separate, overlappable
-        # statistics kernels it removes, so it is off by default.
-        self.fuse_gn_stats = False
-        self._stats = {}
         self.overlap_controlnet = True  # run the ControlNet encoder on a second stream, parallel to the UNet encoder
         # ... and, optionally, while that stream is otherwise idle: the ControlNet skip merges beside the mid block / decoder
-        # start and Sobel + conditioning embedding beside the TAESD encoder (`use_side_stream`), the 1x1 shortcut convs of
-        # the decoder's ResnetBlocks beside their main path (`side_shortcuts`).  Measured on MI355X (512x512, 4 steps): one
-        # frame alone 23.8 -> 23.2 ms (23.6 with the shortcuts too), but with two launches in flight 97 -> 81 frames/s --
-        # four busy hardware queues instead of two cost more than the filled gaps give.  So: off by default, switched on
-        # where a single frame is in flight (bench.py's latency leg).
+        # start and Sobel + conditioning embedding beside the TAESD encoder (`use_side_stream`).  Measured on MI355X (512x512,
+        # 4 steps): one frame alone 23.8 -> 23.2 ms, but with two launches in flight 97 -> 81 frames/s -- four busy hardware
+        # queues instead of two cost more than the filled gaps give.  So: off by default, switched on where a single frame is
+        # in flight (bench.py's latency leg).  (Round 2 also moved the decoder's 1x1 shortcut convs there: 23.6 ms, removed.)
         self.use_side_stream = False
-        self.side_shortcuts = False
         import os as _os
-        _v = _os.environ.get("VSD_SIDE")  # A/B switch: 0 off, 1 merges + conditioning, 2 also the shortcuts
-        if _v is not None:
-            self.use_side_stream = _v in ("1", "2")
-            self.side_shortcuts = _v == "2"
+        if _os.environ.get("VSD_SIDE") is not None:  # A/B switch
+            self.use_side_stream = _os.environ.get("VSD_SIDE") == "1"
         self._ev_count = 0
         # what a slot shares with its parent besides the weights: the per-plan constant block (schedule coefficients,
         # ControlNet scales) that the captured graphs READ, so that `update_options` reaches every graph at once
@@ -579,10 +570,10 @@ class Engine:
 
     # ---------------------------------------------------------------- network builders (record ops)
     def _resnet(self, r, rw: ResnetW, net, step, x, x2, c0, c1, hw, geom, out=None, out2=None, add2=None, residual2=None,
-                temb=None, stat_out=None, side=False):
+                temb=None, stat_out=None):
         """x (and optional concat partner x2) -> ResnetBlock2D output [batch*hw][cout]  (hw = pixels per image).
-        temb: another time-projection table than net.temb_all; stat_out: fp32 [cout][2] to receive the output's
-        per-channel (sum, sumsq) (reference-only AdaIN); side: stream 1 is free (UNet decoder): the shortcut conv goes there."""
+        temb: another time-projection table than the plan's; stat_out: fp32 [cout][2] to receive the output's per-channel
+        (sum, sumsq) (reference-only AdaIN)."""
         a, cfg = self.arena, net.cfg
         cin = c0 + c1
         rows = self.batch * hw
@@ -590,30 +581,17 @@ class Engine:
         self._gn(r, x, x2, c0, c1, hw, cfg.groups, 1e-5, rw.n1[0], rw.n1[1], True, t1)
         h = a.alloc(rows, rw.cout)
         tv = (self._temb(net) if temb is None else temb)[step, rw.temb_off:rw.temb_off + rw.cout]
-        r.conv(t1, None, geom, rw.conv1, h, rowvec=tv, chanstat_out=self._stat_buf(h, rw.cout))
+        r.conv(t1, None, geom, rw.conv1, h, rowvec=tv)
         t2 = a.alloc(rows, rw.cout)
         self._gn(r, h, None, rw.cout, 0, hw, cfg.groups, 1e-5, rw.n2[0], rw.n2[1], True, t2)
         if rw.shortcut is not None:
             sc = a.alloc(rows, rw.cout)
-            if side:  # the 1x1 shortcut only depends on the block's input: run it beside GroupNorm / conv1 / GroupNorm
-                ev = f"sc{self._ev_count}"
-                self._ev_count += 1
-                r.signal(ev + "a")
-                r.use_stream(1)
-                r.wait(ev + "a")
-                r.conv(x, x2, Geom.linear(rows), rw.shortcut, sc, c0=c0, c1=c1)
-                r.signal(ev + "b")
-                r.use_stream(0)
-            else:
-                r.conv(x, x2, Geom.linear(rows), rw.shortcut, sc, c0=c0, c1=c1)
+            r.conv(x, x2, Geom.linear(rows), rw.shortcut, sc, c0=c0, c1=c1)
         else:
             sc = x
-            side = False
         out = out if out is not None else a.alloc(rows, rw.cout)
-        if side:
-            r.wait(ev + "b")
         r.conv(t2, None, geom, rw.conv2, out, residual=sc, residual2=residual2, out2=out2, add2=add2,
-               chanstat_out=stat_out if stat_out is not None else self._stat_buf(out, rw.cout))
+               chanstat_out=stat_out)
         return out
 
     def _transformer(self, r, tw: TransformerW, net, x, hw, out2=None, add2=None, ref: Optional[RefCtx] = None, stat_out=None):
@@ -667,7 +645,7 @@ class Engine:
             kt, vtt = self.pblock.kv(ni, bw.kv_index)
             xa = self.pblock.xa(ni, bw.kv_index) if self.absorb_cross_attention else None
             fused = (self.use_fused_tail and c == getattr(self.ops, "TAIL_C", 0) and len(tw.blocks) == 1 and ref is None and
-                     stat_out is None and out2 is None and not self.fuse_gn_stats and hasattr(self.ops, "tail_a"))
+                     stat_out is None and out2 is None and hasattr(self.ops, "tail_a"))
             if fused:
                 # the block's per-token chains as fused launches around the cross-attention (csrc/fused_tail.hip): the token
                 # tile's owner streams only the weights; h1 / q (and in tail_b h2, the GEGLU hidden state, h3) stay on chip.
@@ -719,29 +697,13 @@ class Engine:
             h = h3
         out = a.alloc(rows, c)
         r.conv(h, None, lin, tw.proj_out, out, residual=x, out2=out2, add2=add2,
-               chanstat_out=stat_out if stat_out is not None else self._stat_buf(out, c))
+               chanstat_out=stat_out)
         return out
 
-    # ---- fused GroupNorm statistics: a conv that writes a tensor a GroupNorm will read also leaves the tensor's
-    #      per-channel (sum, sumsq); the GroupNorm then needs no statistics pass of its own
-    def _stat_buf(self, tensor, c):
-        if not self.fuse_gn_stats or self.batch > 1:  # producer-side statistics are per tensor, not per image
-            return None
-        sb = self.arena.alloc(c, 2, dtype=torch.float32)
-        self._stats[tensor.data_ptr()] = sb
-        return sb
-
     def _gn(self, r, x, x2, c0, c1, hw, groups, eps, gamma, beta, silu, out):
-        cs = None
-        if self.fuse_gn_stats:
-            s0 = self._stats.get(x.data_ptr())
-            s1 = self._stats.get(x2.data_ptr()) if x2 is not None else None
-            if s0 is not None and (x2 is None or s1 is not None):
-                cs = (s0, s1)
-        if self.batch > 1:
-            r.groupnorm(x, x2, c0, c1, hw, groups, eps, gamma, beta, silu, out, batch=self.batch)
-        else:
-            r.groupnorm(x, x2, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=cs)
+        # (round 1-2 could also take the statistics from the producing conv's epilogue (chanstat_out): slower than the separate,
+        #  overlappable statistics kernel on MI355X, removed in round 3 -- chanstat_out remains for the reference-only AdaIN)
+        r.groupnorm(x, x2, c0, c1, hw, groups, eps, gamma, beta, silu, out, batch=self.batch)
 
     def _vt_buffer(self, c, ldvt):
         # V^T buffers live outside the rewound arena: their key-padding columns must stay zero forever
@@ -790,7 +752,7 @@ class Engine:
             if ds is not None:
                 h2, w2 = sizes[i + 1]
                 o = a.alloc(self.batch * h2 * w2, c)
-                r.conv(h, None, Geom.conv(hh, ww, stride=2, batch=self.batch), ds, o, chanstat_out=self._stat_buf(o, c))
+                r.conv(h, None, Geom.conv(hh, ww, stride=2, batch=self.batch), ds, o)
                 h = o
                 skips.append((o, c, i + 1))
         hh, ww = sizes[-1]
@@ -809,7 +771,7 @@ class Engine:
         ch = net.cfg.block_out_channels
         h0, w0 = sizes[0]
         x = a.alloc(self.batch * h0 * w0, ch[0])
-        r.conv(lat, None, Geom.conv(h0, w0, batch=self.batch), net.conv_in, x, chanstat_out=self._stat_buf(x, ch[0]))
+        r.conv(lat, None, Geom.conv(h0, w0, batch=self.batch), net.conv_in, x)
         h, skips = self._down_mid(r, net, step, x, sizes, ref=ref, temb=temb)
         return h, [(x, ch[0], 0)] + skips
 
@@ -832,8 +794,7 @@ class Engine:
                 if ev and ev[0]:
                     r.wait(ev[0])  # this skip's ControlNet merge ran on the second stream
                 st = self._ref_site(r, ref, "up", i, j, rw.cout)
-                h = self._resnet(r, rw, net, step, h, s, cprev, sc, hw, g3, temb=temb, stat_out=st if tw is None else None,
-                                 side=self.overlap_controlnet and self.use_side_stream and self.side_shortcuts)
+                h = self._resnet(r, rw, net, step, h, s, cprev, sc, hw, g3, temb=temb, stat_out=st if tw is None else None)
                 cprev = rw.cout
                 if tw is not None:
                     h = self._transformer(r, tw, net, h, hw, ref=ref, stat_out=st)
@@ -843,8 +804,7 @@ class Engine:
                 h2, w2 = sizes[lvl - 1]
                 o = a.alloc(self.batch * h2 * w2, cprev)
                 # nearest resize to the next skip's size folded into the conv's gather (Upsample2D)
-                r.conv(h, None, Geom.conv(hh, ww, up_to=(h2, w2), batch=self.batch), up, o,
-                       chanstat_out=self._stat_buf(o, cprev))
+                r.conv(h, None, Geom.conv(hh, ww, up_to=(h2, w2), batch=self.batch), up, o)
                 h = o
         t = a.alloc(self.batch * hw0, ch[0])
         self._gn(r, h, None, ch[0], 0, hw0, net.cfg.groups, 1e-5, net.norm_out[0], net.norm_out[1], True, t)
@@ -855,8 +815,7 @@ class Engine:
         ch = net.cfg.block_out_channels
         h0, w0 = sizes[0]
         x = a.alloc(self.batch * h0 * w0, ch[0])
-        r.conv(lat, None, Geom.conv(h0, w0, batch=self.batch), net.conv_in, x, residual=cond_emb,
-               chanstat_out=self._stat_buf(x, ch[0]))
+        r.conv(lat, None, Geom.conv(h0, w0, batch=self.batch), net.conv_in, x, residual=cond_emb)
         h, skips = self._down_mid(r, net, step, x, sizes)
         return h, [(x, ch[0], 0)] + skips
 
@@ -883,8 +842,7 @@ class Engine:
             hh, ww = sizes[lvl]
             rows = self.batch * hh * ww
             o = a.alloc(rows, c)
-            r.conv(s, None, Geom.linear(rows), net.zero_convs[i], o, out_scale_dev=sc[i:i + 1], residual=us,
-                   chanstat_out=self._stat_buf(o, c))
+            r.conv(s, None, Geom.linear(rows), net.zero_convs[i], o, out_scale_dev=sc[i:i + 1], residual=us)
             ev = None
             if side:
                 ev = f"skip{i}"
@@ -896,8 +854,7 @@ class Engine:
         rows = self.batch * hh * ww
         c = net.cfg.block_out_channels[-1]
         mid = a.alloc(rows, c)
-        r.conv(cn_mid, None, Geom.linear(rows), net.zero_mid, mid, out_scale_dev=sc[nres - 1:nres], residual=u_mid,
-               chanstat_out=self._stat_buf(mid, c))
+        r.conv(cn_mid, None, Geom.linear(rows), net.zero_mid, mid, out_scale_dev=sc[nres - 1:nres], residual=u_mid)
         return mid, merged
 
     def _cond_embedding(self, r, ctrl, H, W):
@@ -1024,7 +981,6 @@ class Engine:
             ops.graph_destroy(self.graph)
             self.graph = None
         self.arena = Arena(ops, chunk_bytes=max(256 << 20, _ru(batch * H * W * 64 * 2, 1 << 20)))  # >= one TAESD tensor
-        self._stats = {}
         self._vt_pool, self._vt_count = getattr(self, "_vt_pool", {}), 0
         # persistent per-frame I/O and constants
         B = batch
@@ -1101,7 +1057,6 @@ class Engine:
         mark = a.mark()
         for i in range(n):
             a.rewind(mark)
-            self._stats = {}
             self._vt_count = 0
             cur, nxt = lat[i & 1], lat[(i + 1) & 1]
             if use_controlnet:

@@ -44,7 +44,6 @@ class ConvDesc(C.Structure):
         ("batch", C.c_int32), ("t_img", C.c_int32),
         ("out_scale_dev", C.c_void_p),
         ("softmax_cols", C.c_int32),
-        ("weight_frag", C.c_void_p),
     ]
 
 
@@ -63,8 +62,6 @@ SIGNATURES = {
     "vsd_groupnorm_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "vsd_groupnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "vsd_groupnorm_prestat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
-                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsd_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                 C.c_void_p, C.c_void_p]),
     "vsd_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -230,7 +230,7 @@ class HipOps:
                     # table entry found for a plain layer of the same (M, N, K) may name a 64-column tile or a form without
                     # them: widen it instead of failing at `prepare`
                     tile = {L.TILE_128x64: L.TILE_128x128, L.TILE_64x64: L.TILE_64x128, L.TILE_256x64: L.TILE_256x128}.get(tile, tile)
-                    if pipeline in (7, 9, 10):
+                    if pipeline == 7:
                         pipeline = 3
             else:
                 tile, sk = choose_tile(m, w.n, w.kp, w.geglu or w.tile128, t_col0 if out_t is not None else 0)
@@ -238,21 +238,6 @@ class HipOps:
         split_k = split_k or 1
         if w.tile128:
             inkernel = True  # (the tile softmax runs in the reducing workgroup's epilogue)
-        if pipeline == 10 and (out_scale_dev is not None or w.cin != 64 or w.n != 64 or (c1 or 0) != 0 or
-                               not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part)):
-            pipeline, tile, split_k, inkernel = 3, L.TILE_128x64, 1, True  # (a table entry found for another call of the shape)
-        if pipeline == 10:
-            split_k, inkernel = 1, False
-        if pipeline == 9 and not self._skinny_call_ok(g, w, c0, c1, act, out_t, rowstat_out, chanstat_out):
-            # a tuning-table entry found for another call of the same shape key
-            pipeline, tile, split_k, inkernel = 3, L.TILE_64x64, min(8, max(1, w.kp // 128)), True
-        if pipeline == 9:
-            split_k, inkernel = w.cin // 128, False
-            if w.weight_frag is None:  # (first use: a second, fragment-major copy of this layer's weights)
-                from .packing import pack_mfma_frag
-
-                with torch.cuda.stream(self.stream):
-                    w.weight_frag = pack_mfma_frag(w.weight[:, :w.k])
         if pipeline == 7 and (self.no_halo or out_scale_dev is not None or
                               not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out,
                                                      chanstat_out, ln_part)):
@@ -266,7 +251,6 @@ class HipOps:
         d.hs, d.ws, d.hi, d.wi, d.ho, d.wo = g.hs, g.ws, g.hi, g.wi, g.ho, g.wo
         d.ksize, d.stride, d.pad = g.ksize, g.stride, g.pad
         d.weight = self._p(w.weight)
-        d.weight_frag = self._p(w.weight_frag) if pipeline == 9 else None
         d.n, d.k, d.kp = w.n, w.k, w.kp
         d.bias = self._p(w.bias)
         if ln_part is not None:
@@ -301,17 +285,6 @@ class HipOps:
         elif workspace is not None:  # (development probes pass a buffer through)
             d.workspace = self._p(workspace)
         self.ctx.call("vsd_conv_gemm", C.byref(d), self.s)
-
-    SKINNY_MAX_PIXELS = 320  # csrc/conv_skinny.hip SK_MAX_PIX: padded pixels of all images its LDS panel holds
-
-    @classmethod
-    def _skinny_call_ok(cls, g, w, c0, c1, act, out_t, rowstat_out, chanstat_out) -> bool:
-        """What vsd_conv_gemm's weight-streaming form (pipeline 9) accepts."""
-        padded = g.batch * (g.hs + 2 * (g.ksize // 2)) * (g.ws + 2 * (g.ksize // 2))
-        return (g.m <= 192 and padded <= cls.SKINNY_MAX_PIXELS and g.ksize in (1, 3) and g.stride == 1 and g.pad == g.ksize // 2 and
-                (g.hi, g.wi) == (g.hs, g.ws) and (g.ho, g.wo) == (g.hs, g.ws) and c0 % 128 == 0 and (c1 or 0) % 128 == 0 and
-                w.cin >= 256 and w.n % 64 == 0 and w.kp == w.k and not w.geglu and not w.tile128 and out_t is None and
-                rowstat_out is None and chanstat_out is None and (act & 0xff) not in (L.ACT_GEGLU, L.ACT_SOFTMAX))
 
     @staticmethod
     def _halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part) -> bool:
@@ -352,8 +325,6 @@ class HipOps:
             blocks = -(-g.m // bm) * -(-w.n // bn)
             for pl in ((3, 5) if t == L.TILE_256x128 else (0, 3, 4, 5, 6)):
                 cands.append((t, 1, False, pl))
-            # (pipeline 8, the 8-stage ring, is not a candidate: measured 25.1 vs 23.9 us on 64 x 1280 x 11520 -- more
-            #  tiles in flight do not help, the per-wave LDS-DMA issue rate is what limits these layers)
             if halo_ok and bm == 128:  # LDS halo patch (pipeline 7); split-K (over channel blocks) = the two-kernel form
                 hblocks = g.batch * -(-g.ho // 8) * -(-g.wo // 16) * -(-w.n // bn)
                 for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20):
@@ -377,17 +348,6 @@ class HipOps:
                     if sp > w.cin // 64 or (sp > 1 and hblocks * sp > 1536):
                         break
                     cands.append((t, sp, False, 7))
-        c1_ = kwargs.get("c1", 0) or 0
-        c0_ = kwargs.get("c0") if kwargs.get("c0") is not None else w.cin - c1_
-        if _os.environ.get("VSD_TUNE_STREAMING") and self._skinny_call_ok(g, w, c0_, c1_, act, kwargs.get("out_t"), kwargs.get("rowstat_out"),
-                                                                          kwargs.get("chanstat_out")):
-            # weight-streaming form (tile ignored, split = Cin / 128).  Opt-in: measured at parity with the tiled forms on
-            # the 3x3 layers and slower on the linear ones, and it cannot share a CU with another launch (conv_skinny.hip)
-            cands.append((L.TILE_64x64, w.cin // 128, False, 9))
-        if _os.environ.get("VSD_TUNE_RESIDENT") and halo_ok and w.cin == 64 and w.n == 64 and c1_ == 0 and kwargs.get("out_scale_dev") is None:
-            # weights resident in registers, persistent workgroups (conv_resident.hip).  Opt-in: measured 7 % ahead of the halo
-            # kernel at 5 x 512 x 512 only, behind it at every smaller size
-            cands.append((L.TILE_128x64, 1, False, 10))
         kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline")}
         table = []
         saved = self.tile_override.pop(key, None)
@@ -462,19 +422,12 @@ class HipOps:
                       self._p(ff1.weight_frag), self._p(ff1.ln_s), self._p(ff1.ln_t), ln_eps, self._p(ff2.weight_frag),
                       self._p(ff2.bias), self._p(proj.weight_frag), self._p(proj.bias), self._p(out), self.s)
 
-    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, chan_stats=None, batch=1):
+    def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, batch=1):
+        ws = self.workspace("gn", max(1, batch) * int(self.ctx.lib.vsd_groupnorm_workspace_bytes(hw, c0 + c1, groups)))
         if batch > 1:
-            if chan_stats is not None:
-                raise RuntimeError("groupnorm: producer-side statistics are per tensor (batch must be 1)")
-            ws = self.workspace("gn", batch * int(self.ctx.lib.vsd_groupnorm_workspace_bytes(hw, c0 + c1, groups)))
             self.ctx.call("vsd_groupnorm_batched", self._p(src0), self._p(src1), c0, c1, hw, batch, groups, eps,
                           self._p(gamma), self._p(beta), int(silu), self._p(out), self._p(ws), self.s)
             return
-        if chan_stats is not None:  # statistics were produced by the convs that wrote src0 / src1: one kernel
-            self.ctx.call("vsd_groupnorm_prestat", self._p(src0), self._p(src1), c0, c1, hw, groups, eps, self._p(gamma),
-                          self._p(beta), int(silu), self._p(out), self._p(chan_stats[0]), self._p(chan_stats[1]), self.s)
-            return
-        ws = self.workspace("gn", int(self.ctx.lib.vsd_groupnorm_workspace_bytes(hw, c0 + c1, groups)))
         self.ctx.call("vsd_groupnorm", self._p(src0), self._p(src1), c0, c1, hw, groups, eps, self._p(gamma),
                       self._p(beta), int(silu), self._p(out), self._p(ws), self.s)
 
