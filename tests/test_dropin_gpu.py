@@ -240,3 +240,26 @@ def test_sdxl_model_name_selects_the_sdxl_engine():
                     use_controlnet=False, pooled=p.encode_pooled(opts["prompt"]))
     a, b = np.asarray(got), np.asarray(ref)
     assert np.abs(a.astype(int) - b.astype(int)).mean() <= 1.5 and _psnr(a, b) >= 38.0
+
+
+def test_two_ranks_return_the_same_bits_for_a_size_the_table_lacks():
+    """with round-robin sharding consecutive frames of one stream come from different ranks, so every rank
+    must build the same kernel for the same shape.  Two worker processes in one group (both on cuda:0, gloo carries the
+    collectives as in test_bench_launcher), a frame size that is not in profiles/tuning_mi355x.json: rank 0 warms up first and
+    measures its own choices, `__sync_tuning__` hands them to rank 1 (which never times anything: tuning_mode="table"), and
+    the same frame through either rank is bit-identical."""
+    from videosd_amd.dispatch import spawn_workers
+
+    opts = dict(prompt="a watercolor painting", height=208, width=336, strength=0.6, steps=2, seed=7, controlnet_scale=1.5)
+    ws = spawn_workers(2, backend="gloo", devices=[0, 0], warm_options=opts, **CFG)
+    try:
+        img = _photo(400, 300, 61)
+        a = np.asarray(ws[0].infer(img, **opts))
+        b = np.asarray(ws[1].infer(img, **opts))
+        assert a.shape == (208, 336, 3) and np.array_equal(a, b)
+        # and a size neither rank has seen (nothing was warmed or synchronised): both fall back to the same deterministic choice
+        opts2 = dict(opts, height=176, width=304)
+        assert np.array_equal(np.asarray(ws[0].infer(img, **opts2)), np.asarray(ws[1].infer(img, **opts2)))
+    finally:
+        for w in ws:
+            w.close()

@@ -741,7 +741,17 @@ def warm_group(ws: List["RemotePipeline"], warm_options: Dict[str, Any]):
     b = int(getattr(ws[0], "max_batch", 1) or 1)
     kw = dict(batches=tuple(range(1, b + 1)), lanes=getattr(ws[0], "lanes", 2) if b > 1 else 1, **warm_options)
     if len(ws) > 1 and all(getattr(w, "group", None) for w in ws):
+        # rank 0 alone may time kernel candidates, and only now: afterwards every rank (rank 0 too) takes the deterministic
+        # choice for a shape nobody has measured, so that frames of sizes that turn up later still get the same kernels everywhere
+        try:
+            ws[0].method("set_tuning_mode")("auto")
+        except RemoteCallError:
+            pass
         ws[0].method("warm_up")(**kw)
+        try:
+            ws[0].method("set_tuning_mode")("table")
+        except RemoteCallError:
+            pass
         for f in [w.sync_tuning.remote() for w in ws]:
             f.result(timeout=600)
         futs = [w.method("warm_up").remote(**kw) for w in ws[1:]]

@@ -408,6 +408,13 @@ class VideoSDPipeline:
         self._note("prepare", t0)
         return eng
 
+    def set_tuning_mode(self, mode: str):
+        """ "auto" (time the candidates of shapes the table lacks at `prepare`) or "table" (never: deterministic heuristic)."""
+        if mode not in ("auto", "table"):
+            raise ValueError("tuning_mode must be 'auto' or 'table'")
+        self.tuning_mode = mode
+        return mode
+
     def export_tuning(self):
         """The per-shape kernel choices of this process (table + what `prepare` measured), for `import_tuning` elsewhere."""
         return {k: tuple(v) for k, v in self.model.ops.tile_override.items()}
