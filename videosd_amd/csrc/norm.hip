@@ -408,6 +408,8 @@ extern "C" int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void*
   if (p.rpp > hw) p.rpp = hw;
   const int threads = p.c8 * p.rpp;
   int nblk = cdiv(hw, 4 * p.rpp);
+  static const int nblk_cap = getenv("VSD_GN_NBLK") ? atoi(getenv("VSD_GN_NBLK")) : GN_MAX_PART;  // (benchmarking: statistics workgroups per image)
+  if (nblk > nblk_cap) nblk = nblk_cap;
   if (nblk > GN_MAX_PART) nblk = GN_MAX_PART;
   if (nblk < 1) nblk = 1;
   p.nblk = nblk;
@@ -427,7 +429,8 @@ extern "C" int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void*
   }
   {
     int ablk = cdiv(hw, 2 * p.rpp);
-    if (ablk > 256) ablk = 256;
+    static const int ablk_cap = getenv("VSD_GN_ABLK") ? atoi(getenv("VSD_GN_ABLK")) : 256;  // (benchmarking: apply workgroups per image)
+    if (ablk > ablk_cap) ablk = ablk_cap;
     LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk, batch), dim3(threads), smem, s, p);
     return ls.finish();
