@@ -15,6 +15,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 for sq, sk, heads, d, B in shapes:
     c = heads * d
     t_img = (sk + 63) // 64 * 64
+    torch.manual_seed(sq + d)
     q = torch.randn(B * sq, c, device="cuda").half(); k = torch.randn(B * sk, c, device="cuda").half()
     vt = torch.zeros(c, B * t_img, device="cuda").half()
     for b in range(B):
@@ -38,4 +39,4 @@ for sq, sk, heads, d, B in shapes:
         err = float((o.float() - ref.float()).abs().max())
         row.append(f"{v}: {us:6.1f}us" + ("" if err < 2e-3 else f" (maxdiff {err:.3g}!)"))
     os.environ.pop("VSD_ATTN_SHAPE", None)
-    print(f"attn sq={sq} sk={sk} h={heads} d={d} B={B} [{4.0*sq*sk*heads*d*B/1e9:6.1f} GF] " + " | ".join(row), flush=True)
+    print(f"attn sq={sq} sk={sk} h={heads} d={d} B={B} [{4.0*sq*sk*heads*d*B/1e9:6.1f} GF] " + " | ".join(row) + f"  sum16={int(ref.view(torch.int16).long().sum())}", flush=True)

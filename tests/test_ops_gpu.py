@@ -866,6 +866,15 @@ def test_conv3x3_halo_patch(ops, h, w, c0, c1, cout, tile, split, act):
     got, ref = run_conv(ops, xs, h, w, wt, rnd(cout, seed=4, scale=0.1), ksize=3, tile=tile, split_k=split, pipeline=7, residual=res,
                         rowvec=rv, act=act)
     check(got, ref, f"halo conv {h}x{w} {cin}->{cout} tile={tile} split={split}")
+    if split > 1:  # the in-launch reduction (default) and the reducer kernel sum the slabs in the same order: same bits
+        ops.inkernel_splitk = False
+        try:
+            two, _ = run_conv(ops, xs, h, w, wt, rnd(cout, seed=4, scale=0.1), ksize=3, tile=tile, split_k=split, pipeline=7,
+                              residual=res, rowvec=rv, act=act)
+        finally:
+            ops.inkernel_splitk = True
+        assert torch.equal(got, two)
+        assert int(ops._counters[0].abs().sum()) == 0
 
 
 @pytest.mark.parametrize("hs,ws,up,tile,split", [(8, 8, (16, 16), 1, 1), (14, 24, (27, 48), 5, 2), (16, 16, (32, 32), 0, 1)])

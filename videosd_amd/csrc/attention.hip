@@ -65,7 +65,7 @@ __device__ __forceinline__ float xhalf_max(float x) {  // max over the two half-
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <int NQK, int NPV, int NW, int QB, int KSP>
+template <int NQK, int NPV, int NW, int QB, int KSP, bool PIPE>
 __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnParams pp) {
   constexpr int NTG = 64 * NW;       // threads of one key-split group (they stage that group's tiles)
   constexpr int KS = NQK * 16 + 8;   // K tile row pitch (halfs): 4 * odd dwords -> conflict-free ds_read_b128
@@ -145,10 +145,9 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
 // no per-tile address arithmetic.  Rows past the last key (ragged last tile only) re-read row 0 (a valid address), NOT
 // zeroed by a select: a select on the loaded value makes the wave wait for the load on the spot (a whole memory latency
 // per tile); those keys are masked to -inf in the score tile anyway.
-#define ATT_LOAD(SET_, KEY0_)                                                                       \
+#define ATT_LOAD_K(SET_, KEY0_)                                                                     \
   {                                                                                                 \
     const half_t* kb_ = p.k + (size_t)(KEY0_) * p.ldk;                                              \
-    const half_t* vb_ = p.vt + (KEY0_);                                                             \
     if ((KEY0_) + 64 <= p.sk) {                                                                     \
       _Pragma("unroll") for (int i = 0; i < KCH; ++i) kreg[SET_][i] = *reinterpret_cast<const u32x4*>(kb_ + kg[i]); \
     } else {                                                                                        \
@@ -157,12 +156,19 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
         kreg[SET_][i] = *reinterpret_cast<const u32x4*>(ok ? kb_ + kg[i] : p.k);                    \
       }                                                                                             \
     }                                                                                               \
+  }
+#define ATT_LOAD_V(SET_, KEY0_)                                                                     \
+  {                                                                                                 \
+    const half_t* vb_ = p.vt + (KEY0_);                                                             \
     _Pragma("unroll") for (int i = 0; i < VCH; ++i) vreg[SET_][i] = *reinterpret_cast<const u32x4*>(vb_ + vg[i]); \
   }
-#define ATT_STORE(SET_, BUF_)                                                                       \
+#define ATT_STORE_K(SET_, BUF_)                                                                     \
   {                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < KCH; ++i)                                                 \
       if (krow[i] < 64) *reinterpret_cast<u32x4*>(Ks + (BUF_) * KTILE + kl[i]) = kreg[SET_][i];     \
+  }
+#define ATT_STORE_V(SET_, BUF_)                                                                     \
+  {                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < VCH; ++i)                                                 \
       if (vok[i]) {                                                                                 \
         half_t* dst = Vs + (BUF_) * VTILE + vl[i];                                                  \
@@ -170,6 +176,8 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
         *reinterpret_cast<u32x2*>(dst + 8) = (u32x2){vreg[SET_][i][2], vreg[SET_][i][3]};           \
       }                                                                                             \
   }
+#define ATT_LOAD(SET_, KEY0_) { ATT_LOAD_K(SET_, KEY0_) ATT_LOAD_V(SET_, KEY0_) }
+#define ATT_STORE(SET_, BUF_) { ATT_STORE_K(SET_, BUF_) ATT_STORE_V(SET_, BUF_) }
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q0 + 32 qb + lr][ks*16 + lh*8 .. +8], pre-scaled
   half8 qf[QB][NQK];
@@ -212,23 +220,14 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
   // this group's tiles are grp, grp + KSP, ...; "slot j" = its j-th tile, living in register set j & 1 / LDS buffer j & 1
   auto slot_key0 = [&](int j) { return (j * KSP + grp) * 64; };
   auto slot_ok = [&](int j) { return j * KSP + grp < ntiles; };
-  if (slot_ok(0)) ATT_LOAD(0, slot_key0(0))
-  if (slot_ok(1)) ATT_LOAD(1, slot_key0(1))
-  __syncthreads();  // zero fill complete before the first tile lands on top of it
-  if (ones_row && gtid < 2 * 64) Vs[(gtid >> 6) * VTILE + (DV - 1) * VS + (gtid & 63)] = (half_t)1.0f;
-  if (slot_ok(0)) ATT_STORE(0, 0)
-  __syncthreads();
-
 #ifdef VSD_ATTN_PROBE
   long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long plast = __builtin_readcyclecounter();
 #endif
-  auto tile = [&](const int buf, const int key0, auto masked) __attribute__((always_inline)) {
+  // ---- S^T = K Q^T of the tile in LDS buffer `buf`: two independent 32-key accumulation chains, interleaved (each K
+  // fragment feeds all QB blocks)
+  auto qk_tile = [&](const int buf, f32x16 (&s)[QB][2]) __attribute__((always_inline)) {
       const half_t* Kb = Ks + buf * KTILE;
-      const half_t* Vb = Vs + buf * VTILE;
-
-      // ---- S^T = K Q^T: two independent 32-key accumulation chains, interleaved (each K fragment feeds all QB blocks)
-      f32x16 s[QB][2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -245,6 +244,10 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
         }
       }
       PROBE(1)
+  };
+  // ---- masking, online softmax of the score tile `s` (keys key0..key0+63), O^T += V^T P^T with V^T in LDS buffer `buf`
+  auto softmax_pv = [&](const int buf, const int key0, auto masked, f32x16 (&s)[QB][2]) __attribute__((always_inline)) {
+      const half_t* Vb = Vs + buf * VTILE;
       // ---- masking (tail keys / causal)
       if constexpr (decltype(masked)::value) {
 #pragma unroll
@@ -323,33 +326,89 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
       }
       PROBE(3)
   };
-
-  auto run_tile = [&](int j) __attribute__((always_inline)) {
+  // two copies of the softmax body: the masked one only runs for a ragged last tile (or causal attention) -- as ONE
+  // body the compiler if-converts the mask into ~300 selects that every tile would execute
+  auto run_softmax_pv = [&](int j, const int buf, f32x16 (&s)[QB][2]) __attribute__((always_inline)) {
     const int key0 = slot_key0(j);
-    // two copies of the tile body: the masked one only runs for a ragged last tile (or causal attention) -- as ONE
-    // body the compiler if-converts the mask into ~300 selects that every tile would execute
-    if ((key0 + 64 > p.sk) || p.causal) tile(j & 1, key0, std::true_type{});
-    else tile(j & 1, key0, std::false_type{});
+    if ((key0 + 64 > p.sk) || p.causal) softmax_pv(buf, key0, std::true_type{}, s);
+    else softmax_pv(buf, key0, std::false_type{}, s);
   };
-  for (int it = 0; it < niter; it += 2) {
-    // even slot `it` (LDS buffer 0, its registers -- set 0 -- are free again): fetch slot it + 2, compute, park slot it + 1
-    if (slot_ok(it + 2)) ATT_LOAD(0, slot_key0(it + 2))
-    PROBE(0)
-    if (slot_ok(it)) run_tile(it);
-    if (slot_ok(it + 1)) ATT_STORE(1, 1)
-    PROBE(4)
+
+  if constexpr (!PIPE) {
+    if (slot_ok(0)) ATT_LOAD(0, slot_key0(0))
+    if (slot_ok(1)) ATT_LOAD(1, slot_key0(1))
+    __syncthreads();  // zero fill complete before the first tile lands on top of it
+    if (ones_row && gtid < 2 * 64) Vs[(gtid >> 6) * VTILE + (DV - 1) * VS + (gtid & 63)] = (half_t)1.0f;
+    if (slot_ok(0)) ATT_STORE(0, 0)
     __syncthreads();
-    PROBE(5)
-    // odd slot it + 1 (LDS buffer 1, register set 1)
-    if (it + 1 < niter) {
-      if (slot_ok(it + 3)) ATT_LOAD(1, slot_key0(it + 3))
+    auto run_tile = [&](int j) __attribute__((always_inline)) {
+      f32x16 s[QB][2];
+      qk_tile(j & 1, s);
+      run_softmax_pv(j, j & 1, s);
+    };
+    for (int it = 0; it < niter; it += 2) {
+      // even slot `it` (LDS buffer 0, its registers -- set 0 -- are free again): fetch slot it + 2, compute, park slot it + 1
+      if (slot_ok(it + 2)) ATT_LOAD(0, slot_key0(it + 2))
       PROBE(0)
-      if (slot_ok(it + 1)) run_tile(it + 1);
-      if (slot_ok(it + 2)) ATT_STORE(0, 0)
+      if (slot_ok(it)) run_tile(it);
+      if (slot_ok(it + 1)) ATT_STORE(1, 1)
       PROBE(4)
+      __syncthreads();
+      PROBE(5)
+      // odd slot it + 1 (LDS buffer 1, register set 1)
+      if (it + 1 < niter) {
+        if (slot_ok(it + 3)) ATT_LOAD(1, slot_key0(it + 3))
+        PROBE(0)
+        if (slot_ok(it + 1)) run_tile(it + 1);
+        if (slot_ok(it + 2)) ATT_STORE(0, 0)
+        PROBE(4)
+      }
+      __syncthreads();
+      PROBE(5)
     }
+  } else {
+    // Software-pipelined form: the score MFMAs of slot j + 1 are issued BEFORE the softmax of slot j, so the matrix pipe
+    // works under the ~800 VALU cycles of the softmax (exp2 alone is 33 quarter-rate instructions) instead of before
+    // them.  K therefore runs one slot ahead of V^T in LDS: entering iteration j, K buffer (j+1)&1 holds slot j + 1, V^T
+    // buffer j&1 holds slot j, and the score tile of slot j is in registers; the iteration parks K of slot j + 2 (buffer
+    // j&1: its scores were taken an iteration ago) and V^T of slot j + 1 (buffer (j+1)&1: multiplied an iteration ago).
+    // K slot j + 2 waits in register set j&1 (fetched at the top of iteration j - 1), V^T slot j + 1 in set (j+1)&1.
+    // Same arithmetic in the same order as the plain form: same bits.
+    f32x16 sa[QB][2], sb[QB][2];
+    if (slot_ok(0)) { ATT_LOAD_K(0, slot_key0(0)) ATT_LOAD_V(0, slot_key0(0)) }
+    if (slot_ok(1)) ATT_LOAD_K(1, slot_key0(1))
+    __syncthreads();  // zero fill complete before the first tile lands on top of it
+    if (ones_row && gtid < 2 * 64) Vs[(gtid >> 6) * VTILE + (DV - 1) * VS + (gtid & 63)] = (half_t)1.0f;
+    if (slot_ok(0)) { ATT_STORE_K(0, 0) ATT_STORE_V(0, 0) }
+    if (slot_ok(1)) ATT_STORE_K(1, 1)
+    if (slot_ok(2)) ATT_LOAD_K(0, slot_key0(2))
+    if (slot_ok(1)) ATT_LOAD_V(1, slot_key0(1))
     __syncthreads();
-    PROBE(5)
+    if (slot_ok(0)) qk_tile(0, sa);
+    for (int it = 0; it < niter; it += 2) {
+      if (slot_ok(it + 3)) ATT_LOAD_K(1, slot_key0(it + 3))
+      if (slot_ok(it + 2)) ATT_LOAD_V(0, slot_key0(it + 2))
+      PROBE(0)
+      if (slot_ok(it + 1)) qk_tile(1, sb);
+      if (slot_ok(it)) run_softmax_pv(it, 0, sa);
+      if (slot_ok(it + 2)) ATT_STORE_K(0, 0)
+      if (slot_ok(it + 1)) ATT_STORE_V(1, 1)
+      PROBE(4)
+      __syncthreads();
+      PROBE(5)
+      if (it + 1 < niter) {
+        if (slot_ok(it + 4)) ATT_LOAD_K(0, slot_key0(it + 4))
+        if (slot_ok(it + 3)) ATT_LOAD_V(1, slot_key0(it + 3))
+        PROBE(0)
+        if (slot_ok(it + 2)) qk_tile(0, sa);
+        if (slot_ok(it + 1)) run_softmax_pv(it + 1, 1, sb);
+        if (slot_ok(it + 3)) ATT_STORE_K(1, 1)
+        if (slot_ok(it + 2)) ATT_STORE_V(0, 0)
+        PROBE(4)
+      }
+      __syncthreads();
+      PROBE(5)
+    }
   }
 #ifdef VSD_ATTN_PROBE
   if (p.probe && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
@@ -357,6 +416,10 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
 #endif
 #undef ATT_LOAD
 #undef ATT_STORE
+#undef ATT_LOAD_K
+#undef ATT_LOAD_V
+#undef ATT_STORE_K
+#undef ATT_STORE_V
 
   // ---- merge the key-split groups: group 1 hands (max, sum, O) of its keys to group 0 through LDS
   if constexpr (KSP > 1) {
@@ -428,7 +491,9 @@ struct AttnShape {
 template <int NQK, int NPV, int NW, int QB, int KSP>
 void launch_one(const AttnParams& p, int batch, hipStream_t s) {
   dim3 grid(p.heads, (p.sq + 32 * NW * QB - 1) / (32 * NW * QB), batch);
-  hipLaunchKernelGGL((attention_kernel<NQK, NPV, NW, QB, KSP>), grid, dim3(64 * NW * KSP), 0, s, p);
+  static const bool pipe = getenv("VSD_ATTN_PIPE") ? atoi(getenv("VSD_ATTN_PIPE")) != 0 : false;
+  if (pipe) hipLaunchKernelGGL((attention_kernel<NQK, NPV, NW, QB, KSP, true>), grid, dim3(64 * NW * KSP), 0, s, p);
+  else hipLaunchKernelGGL((attention_kernel<NQK, NPV, NW, QB, KSP, false>), grid, dim3(64 * NW * KSP), 0, s, p);
 }
 
 template <int NQK, int NPV>

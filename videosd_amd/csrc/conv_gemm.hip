@@ -144,7 +144,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   if (p.split_k > KT) p.split_k = KT;
   p.kt_per_split = cdiv(KT, p.split_k);
   p.split_k = cdiv(KT, p.kt_per_split);
-  if (p.split_k == 1 || halo) p.counters = nullptr;  // (halo: always the reducer kernel)
+  if (p.split_k == 1) p.counters = nullptr;
   if (p.counters && p.tiles_m * p.tiles_n > VSD_SPLITK_MAX_TILES)
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: %d tiles exceed the split-K counter buffer", p.tiles_m * p.tiles_n);
   const int grid = p.tiles_m * p.tiles_n * p.split_k;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
 // for the input / 6 (6 per wave per channel block instead of 4 per wave per tap).  Only the weight tiles stream per tap
 // (3-slot ring, counted vmcnt).  Zero padding = out-of-range buffer offsets, as in the FAST path.
 // K order inside a workgroup: channel block outer, tap inner (weights stay [N][(ky,kx,c)]).  Split-K over channel
-// blocks writes fp32 slabs for splitk_reduce_kernel.  Epilogue: bias + time vector, activation, one residual.
+// blocks writes fp32 slabs for splitk_reduce_kernel, or (p.counters) for the last workgroup to arrive at the tile.  Epilogue: bias + time vector, activation, one residual.
 // Eligible: ksize 3, stride 1, pad 1, Cin % 64 == 0 (each concat source), with or without the folded nearest resize
 // (Upsample2D + conv: the patch fetch reads each source pixel into the halo rows that show it); patches hanging over the
 // right / bottom edge compute but do not store their outside pixels.
@@ -265,11 +265,11 @@ __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p
   constexpr int CH = BN / 8;
   constexpr int NIT = BM * CH / NT;
   half8 rpre[NIT];
-  float brv[8];
-  const int pre_n = n0 + (tid % CH) * 8;
+  float brv[8], brv2[8];  // x = (acc + brv) + brv2: bias + time vector summed first (one launch) | bias, then the time vector
+  const int pre_n = n0 + (tid % CH) * 8;  // (the in-launch split-K reduction: the reducer kernel's order of additions, same bits)
   const bool ncol_ok = pre_n + 8 <= p.N;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) brv[i] = 0.f;
+  for (int i = 0; i < 8; ++i) brv[i] = brv2[i] = 0.f;
   if (p.split_k == 1) {
     if (ncol_ok && p.bias) {
       half8 v = *reinterpret_cast<const half8*>(p.bias + pre_n);
@@ -302,21 +302,70 @@ __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p
     }
   __syncthreads();
   CPROBE(5)
-  if (p.split_k > 1) {  // fp32 slab of this split; splitk_reduce_kernel applies the epilogue
+  bool from_slabs = false;
+  if (p.split_k > 1) {  // fp32 slab of this split
     float* slab = p.ws_partial + (size_t)split * p.M * p.N;
+    // in-launch reduction (p.counters): write-through stores, so that the reducing workgroup sees them from any XCD
+    // without an L2 write-back on the producers (as in conv_gemm_kernel)
+    const bool wt = p.counters != nullptr;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        slab, 0, (int)min((size_t)p.M * p.N * sizeof(float), (size_t)0x7fffffff), 0x00020000);
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
       const int q = tid + j * NT;
       const int r = q / CH, c8 = (q - r * CH) * 8;
       const int n = n0 + c8;
       if (n + 8 <= p.N && row_ok(r)) {
-        float* d = slab + (size_t)row_m(r) * p.N + n;
-        *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8);
-        *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8 + 4);
+        const float* sp = Cs + r * BNP + c8;
+        if (wt) {
+          const int off = (int)(((size_t)row_m(r) * p.N + n) * sizeof(float));
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sp), rsrc, off, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sp + 4), rsrc, off + 16, 0, 16);
+        } else {
+          float* d = slab + (size_t)row_m(r) * p.N + n;
+          *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(sp);
+          *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+        }
       }
     }
-    WGTL_END(1)
-    return;
+    if (!p.counters) { WGTL_END(1) return; }  // two-kernel form: splitk_reduce_kernel applies the epilogue
+    // The LAST workgroup to arrive at this (patch, column tile) sums the slabs in the order 0..split_k-1 (the reducer
+    // kernel's order: same bits) and runs the epilogue.  Ticket protocol as in conv_gemm_kernel.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* lastflag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      int* cnt = p.counters + tile_n * p.tiles_m + tile_m;
+      const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == p.split_k - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *lastflag = last;
+    }
+    __syncthreads();
+    if (!*lastflag) { WGTL_END(1) return; }
+    from_slabs = true;
+    if (ncol_ok && p.bias) {
+      half8 v = *reinterpret_cast<const half8*>(p.bias + pre_n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) brv[i] += (float)v[i];
+    }
+    if (ncol_ok && p.rowvec) {
+      half8 v = *reinterpret_cast<const half8*>(p.rowvec + pre_n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) brv2[i] = (float)v[i];
+    }
+    if (p.residual) {
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const int q = tid + j * NT;
+        const int r = q / CH;
+        rpre[j] = *reinterpret_cast<const half8*>(p.residual + (ncol_ok && row_ok(r) ? (size_t)row_m(r) * p.ldr + pre_n : 0));
+      }
+    }
   }
   const int act = p.act & 0xff;
   const bool post = (p.act & VSD_ACT_POST) != 0;
@@ -328,13 +377,29 @@ __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p
       const int r = q / CH, c8 = (q - r * CH) * 8;
       const int n = n0 + c8;
       if (n + 8 <= p.N && row_ok(r)) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8 + 4);
+        f32x4 lo, hi;
+        if (from_slabs) {
+          lo = hi = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const float* sp = p.ws_partial + (size_t)row_m(r) * p.N + n;
+          const size_t slab_sz = (size_t)p.M * p.N;
+          for (int k = 0; k < p.split_k; ++k) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sp + k * slab_sz);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(sp + k * slab_sz + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              lo[i] += a[i];
+              hi[i] += b[i];
+            }
+          }
+        } else {
+          lo = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8);
+          hi = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8 + 4);
+        }
         const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         half8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          float x = v[i] + brv[i];
+          float x = (v[i] + brv[i]) + brv2[i];
           if (ACT == 1) x = fmaxf(x, 0.f);
           if (ACT == 2) x = silu_f(x);
           if (p.residual) x += (float)rpre[j][i];

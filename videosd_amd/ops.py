@@ -99,6 +99,7 @@ class HipOps:
         self._ws = {}
         self.tile_override = {} if tile_override is None else tile_override
         self.inkernel_splitk = True
+        self.one_launch_bias_us = float(_os.environ.get("VSD_ONE_LAUNCH_BIAS_US", "0.5"))  # tune_conv: see there
         self.no_halo = bool(__import__("os").environ.get("VSD_NO_HALO"))  # debugging: run halo-tuned shapes on the generic ring
         self.default_pipeline = 3
         with torch.cuda.stream(self.stream):
@@ -331,6 +332,8 @@ class HipOps:
                     if sp > w.cin // 64 or (sp > 1 and hblocks * sp > 1536):
                         break
                     cands.append((t, sp, False, 7))
+                    if sp > 1 and hblocks <= L.SPLITK_MAX_TILES:
+                        cands.append((t, sp, True, 7))
             if w.geglu or blocks >= 384:
                 continue
             for sp in (2, 3, 4, 6, 8, 12, 16, 24):
@@ -348,6 +351,8 @@ class HipOps:
                     if sp > w.cin // 64 or (sp > 1 and hblocks * sp > 1536):
                         break
                     cands.append((t, sp, False, 7))
+                    if sp > 1 and hblocks <= L.SPLITK_MAX_TILES:
+                        cands.append((t, sp, True, 7))
         kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline")}
         table = []
         saved = self.tile_override.pop(key, None)
@@ -371,6 +376,15 @@ class HipOps:
         self.inkernel_splitk = True
         table.sort()
         best = table[0]
+        if best[2] > 1 and not best[3] and self.one_launch_bias_us > 0:
+            # a two-launch form won: take a one-launch form that is within the bias instead (one graph node less; back-to-back
+            # timing on an otherwise idle GPU flatters the second launch, which in a frame also delays the NEXT layer's start)
+            for cand in table[1:]:
+                if cand[0] > best[0] + self.one_launch_bias_us:
+                    break
+                if cand[2] == 1 or cand[3]:
+                    best = cand
+                    break
         self.tile_override[key] = (best[1], best[2], best[3], best[4])
         return best, table
 
