@@ -1,3 +1,4 @@
+// (without -DVSD_ATTN_PROBE: launch time only -- the form the -DVSD_ATTN_EXP=n ablation builds use, see attention.hip)
 // Standalone timing probe of csrc/attention.hip (not part of libvsd): builds the kernel with -DVSD_ATTN_PROBE, runs one
 // self-attention problem and prints (a) the launch time and (b) where wave 0 of workgroup 0 spent its shader clocks.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -DVSD_ATTN_PROBE scripts/attn_probe.cpp \
@@ -7,7 +8,9 @@
 #include <stdlib.h>
 #include <vector>
 #include "../include/vsd.h"
+#ifdef VSD_ATTN_PROBE
 extern "C" void vsd_attn_set_probe(void* buf);
+#endif
 int main(int argc, char** argv) {
   int sq = argc > 1 ? atoi(argv[1]) : 4096, heads = argc > 2 ? atoi(argv[2]) : 8, d = argc > 3 ? atoi(argv[3]) : 40;
   int batch = argc > 4 ? atoi(argv[4]) : 1;
@@ -22,7 +25,9 @@ int main(int argc, char** argv) {
   hipMalloc(&q, nq * 2); hipMalloc(&k, nq * 2); hipMalloc(&vt, nv * 2); hipMalloc(&o, nq * 2); hipMalloc(&probe, 64);
   hipMemcpy(q, h.data(), nq * 2, hipMemcpyHostToDevice); hipMemcpy(k, h.data(), nq * 2, hipMemcpyHostToDevice);
   hipMemcpy(vt, h.data(), nv * 2, hipMemcpyHostToDevice); hipMemset(probe, 0, 64);
+#ifdef VSD_ATTN_PROBE
   vsd_attn_set_probe(probe);
+#endif
   hipStream_t s; hipStreamCreate(&s);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto run = [&]() { return vsd_attention_batched(ctx, q, c, k, c, vt, batch * timg, o, c, sq, sq, heads, d, 0.158f, 0, batch, sq, timg, s); };

@@ -148,7 +148,54 @@ void run(const char* name, int threads, int per_iter_lo, int per_iter_hi) {
   hipFree(d); hipFree(sink);
 }
 
+// The shader clock under load: s_memtime (shader cycles) against s_memrealtime (constant 100 MHz) around a long loop of
+// MFMAs (+ the softmax VALU mix) on `grid` workgroups of 512 threads.
+template <int WHAT>
+__global__ void clk_kernel(long long* out, float* sink, int iters) {
+  float v[8];
+  for (int i = 0; i < 8; ++i) v[i] = -0.001f * (threadIdx.x + i + 1);
+  f32x16 acc[2];
+  for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+  half8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)0.01f; b[i] = (_Float16)0.02f; }
+  long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+  body<WHAT>(v, acc, a, b, iters);
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i) s += v[i];
+  for (int i = 0; i < 16; ++i) s += acc[0][i] + acc[1][i];
+  asm volatile("s_nop 0" ::"v"(s));
+  long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+  if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+  if (s == 123.f) sink[threadIdx.x] = s;
+}
+
+template <int WHAT>
+void clk(const char* name, int grid, int iters) {
+  long long* d; float* sink;
+  hipMalloc(&d, 16 * sizeof(long long));
+  hipMalloc(&sink, 1024 * sizeof(float));
+  long long h[2] = {0, 0};
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((clk_kernel<WHAT>), dim3(grid), dim3(512), 0, 0, d, sink, iters);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+  }
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  printf("%-44s grid %5d: %.2f ms; workgroup 0: %lld shader cycles in %lld ticks of 100 MHz = %.0f MHz\n", name, grid, ms, h[0], h[1],
+         h[1] ? (double)h[0] / ((double)h[1] / 100.0) : 0.0);
+  hipFree(d); hipFree(sink);
+}
+
 int main() {
+  clk<T_MFMA>("clock: mfma only", 1, 20000);
+  clk<T_MFMA>("clock: mfma only", 256, 20000);
+  clk<T_MFMA>("clock: mfma only", 2048, 20000);
+  clk<T_MIX>("clock: mfma + softmax VALU mix", 256, 20000);
+  clk<T_MIX>("clock: mfma + softmax VALU mix", 2048, 20000);
+  clk<T_MIXVALU>("clock: VALU mix only", 2048, 20000);
   run<T_EXP, T_EXP>("v_exp_f32, one wave per SIMD", 256, 16, 16);
   run<T_SUB, T_SUB>("v_sub_f32, one wave per SIMD", 256, 16, 16);
   run<T_FMA, T_FMA>("v_fma_f32, one wave per SIMD", 256, 16, 16);

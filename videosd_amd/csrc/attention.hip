@@ -65,7 +65,7 @@ __device__ __forceinline__ float xhalf_max(float x) {  // max over the two half-
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <int NQK, int NPV, int NW, int QB, int KSP, bool PIPE>
+template <int NQK, int NPV, int NW, int QB, int KSP>
 __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnParams pp) {
   constexpr int NTG = 64 * NW;       // threads of one key-split group (they stage that group's tiles)
   constexpr int KS = NQK * 16 + 8;   // K tile row pitch (halfs): 4 * odd dwords -> conflict-free ds_read_b128
@@ -334,81 +334,36 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
     else softmax_pv(buf, key0, std::false_type{}, s);
   };
 
-  if constexpr (!PIPE) {
-    if (slot_ok(0)) ATT_LOAD(0, slot_key0(0))
-    if (slot_ok(1)) ATT_LOAD(1, slot_key0(1))
-    __syncthreads();  // zero fill complete before the first tile lands on top of it
-    if (ones_row && gtid < 2 * 64) Vs[(gtid >> 6) * VTILE + (DV - 1) * VS + (gtid & 63)] = (half_t)1.0f;
-    if (slot_ok(0)) ATT_STORE(0, 0)
+  if (slot_ok(0)) ATT_LOAD(0, slot_key0(0))
+  if (slot_ok(1)) ATT_LOAD(1, slot_key0(1))
+  __syncthreads();  // zero fill complete before the first tile lands on top of it
+  if (ones_row && gtid < 2 * 64) Vs[(gtid >> 6) * VTILE + (DV - 1) * VS + (gtid & 63)] = (half_t)1.0f;
+  if (slot_ok(0)) ATT_STORE(0, 0)
+  __syncthreads();
+  auto run_tile = [&](int j) __attribute__((always_inline)) {
+    f32x16 s[QB][2];
+    qk_tile(j & 1, s);
+    run_softmax_pv(j, j & 1, s);
+  };
+  for (int it = 0; it < niter; it += 2) {
+    // even slot `it` (LDS buffer 0, its registers -- set 0 -- are free again): fetch slot it + 2, compute, park slot it + 1
+    if (slot_ok(it + 2)) ATT_LOAD(0, slot_key0(it + 2))
+    PROBE(0)
+    if (slot_ok(it)) run_tile(it);
+    if (slot_ok(it + 1)) ATT_STORE(1, 1)
+    PROBE(4)
     __syncthreads();
-    auto run_tile = [&](int j) __attribute__((always_inline)) {
-      f32x16 s[QB][2];
-      qk_tile(j & 1, s);
-      run_softmax_pv(j, j & 1, s);
-    };
-    for (int it = 0; it < niter; it += 2) {
-      // even slot `it` (LDS buffer 0, its registers -- set 0 -- are free again): fetch slot it + 2, compute, park slot it + 1
-      if (slot_ok(it + 2)) ATT_LOAD(0, slot_key0(it + 2))
+    PROBE(5)
+    // odd slot it + 1 (LDS buffer 1, register set 1)
+    if (it + 1 < niter) {
+      if (slot_ok(it + 3)) ATT_LOAD(1, slot_key0(it + 3))
       PROBE(0)
-      if (slot_ok(it)) run_tile(it);
-      if (slot_ok(it + 1)) ATT_STORE(1, 1)
+      if (slot_ok(it + 1)) run_tile(it + 1);
+      if (slot_ok(it + 2)) ATT_STORE(0, 0)
       PROBE(4)
-      __syncthreads();
-      PROBE(5)
-      // odd slot it + 1 (LDS buffer 1, register set 1)
-      if (it + 1 < niter) {
-        if (slot_ok(it + 3)) ATT_LOAD(1, slot_key0(it + 3))
-        PROBE(0)
-        if (slot_ok(it + 1)) run_tile(it + 1);
-        if (slot_ok(it + 2)) ATT_STORE(0, 0)
-        PROBE(4)
-      }
-      __syncthreads();
-      PROBE(5)
     }
-  } else {
-    // Software-pipelined form: the score MFMAs of slot j + 1 are issued BEFORE the softmax of slot j, so the matrix pipe
-    // works under the ~800 VALU cycles of the softmax (exp2 alone is 33 quarter-rate instructions) instead of before
-    // them.  K therefore runs one slot ahead of V^T in LDS: entering iteration j, K buffer (j+1)&1 holds slot j + 1, V^T
-    // buffer j&1 holds slot j, and the score tile of slot j is in registers; the iteration parks K of slot j + 2 (buffer
-    // j&1: its scores were taken an iteration ago) and V^T of slot j + 1 (buffer (j+1)&1: multiplied an iteration ago).
-    // K slot j + 2 waits in register set j&1 (fetched at the top of iteration j - 1), V^T slot j + 1 in set (j+1)&1.
-    // Same arithmetic in the same order as the plain form: same bits.
-    f32x16 sa[QB][2], sb[QB][2];
-    if (slot_ok(0)) { ATT_LOAD_K(0, slot_key0(0)) ATT_LOAD_V(0, slot_key0(0)) }
-    if (slot_ok(1)) ATT_LOAD_K(1, slot_key0(1))
-    __syncthreads();  // zero fill complete before the first tile lands on top of it
-    if (ones_row && gtid < 2 * 64) Vs[(gtid >> 6) * VTILE + (DV - 1) * VS + (gtid & 63)] = (half_t)1.0f;
-    if (slot_ok(0)) { ATT_STORE_K(0, 0) ATT_STORE_V(0, 0) }
-    if (slot_ok(1)) ATT_STORE_K(1, 1)
-    if (slot_ok(2)) ATT_LOAD_K(0, slot_key0(2))
-    if (slot_ok(1)) ATT_LOAD_V(1, slot_key0(1))
     __syncthreads();
-    if (slot_ok(0)) qk_tile(0, sa);
-    for (int it = 0; it < niter; it += 2) {
-      if (slot_ok(it + 3)) ATT_LOAD_K(1, slot_key0(it + 3))
-      if (slot_ok(it + 2)) ATT_LOAD_V(0, slot_key0(it + 2))
-      PROBE(0)
-      if (slot_ok(it + 1)) qk_tile(1, sb);
-      if (slot_ok(it)) run_softmax_pv(it, 0, sa);
-      if (slot_ok(it + 2)) ATT_STORE_K(0, 0)
-      if (slot_ok(it + 1)) ATT_STORE_V(1, 1)
-      PROBE(4)
-      __syncthreads();
-      PROBE(5)
-      if (it + 1 < niter) {
-        if (slot_ok(it + 4)) ATT_LOAD_K(0, slot_key0(it + 4))
-        if (slot_ok(it + 3)) ATT_LOAD_V(1, slot_key0(it + 3))
-        PROBE(0)
-        if (slot_ok(it + 2)) qk_tile(0, sa);
-        if (slot_ok(it + 1)) run_softmax_pv(it + 1, 1, sb);
-        if (slot_ok(it + 3)) ATT_STORE_K(1, 1)
-        if (slot_ok(it + 2)) ATT_STORE_V(0, 0)
-        PROBE(4)
-      }
-      __syncthreads();
-      PROBE(5)
-    }
+    PROBE(5)
   }
 #ifdef VSD_ATTN_PROBE
   if (p.probe && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
@@ -491,9 +446,7 @@ struct AttnShape {
 template <int NQK, int NPV, int NW, int QB, int KSP>
 void launch_one(const AttnParams& p, int batch, hipStream_t s) {
   dim3 grid(p.heads, (p.sq + 32 * NW * QB - 1) / (32 * NW * QB), batch);
-  static const bool pipe = getenv("VSD_ATTN_PIPE") ? atoi(getenv("VSD_ATTN_PIPE")) != 0 : false;
-  if (pipe) hipLaunchKernelGGL((attention_kernel<NQK, NPV, NW, QB, KSP, true>), grid, dim3(64 * NW * KSP), 0, s, p);
-  else hipLaunchKernelGGL((attention_kernel<NQK, NPV, NW, QB, KSP, false>), grid, dim3(64 * NW * KSP), 0, s, p);
+  hipLaunchKernelGGL((attention_kernel<NQK, NPV, NW, QB, KSP>), grid, dim3(64 * NW * KSP), 0, s, p);
 }
 
 template <int NQK, int NPV>

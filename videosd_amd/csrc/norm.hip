@@ -408,7 +408,13 @@ extern "C" int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void*
   if (p.rpp > hw) p.rpp = hw;
   const int threads = p.c8 * p.rpp;
   int nblk = cdiv(hw, 4 * p.rpp);
-  static const int nblk_cap = getenv("VSD_GN_NBLK") ? atoi(getenv("VSD_GN_NBLK")) : GN_MAX_PART;  // (benchmarking: statistics workgroups per image)
+  // statistics workgroups per image: with several images per launch fewer, longer workgroups win (fewer partials for
+  // the apply kernel to fold, the grid still covers the chip) -- MI355X, 5 images: 64x64x640 28.1 -> 23.7 us per pair,
+  // 64x64x960 31.3 -> 27.3, 32x32x1920 25.2 -> 21.0 at 32 instead of 128 (16: slower again)
+  static const int nblk_env = getenv("VSD_GN_NBLK") ? atoi(getenv("VSD_GN_NBLK")) : 0;  // (benchmarking)
+  int nblk_cap = 160 / batch;
+  nblk_cap = nblk_cap < 32 ? 32 : nblk_cap;
+  if (nblk_env > 0) nblk_cap = nblk_env;
   if (nblk > nblk_cap) nblk = nblk_cap;
   if (nblk > GN_MAX_PART) nblk = GN_MAX_PART;
   if (nblk < 1) nblk = 1;
