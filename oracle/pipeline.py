@@ -70,7 +70,10 @@ def postprocess(x: torch.Tensor) -> np.ndarray:
 class OraclePipeline:
     def __init__(self, unet_cfg, cn_cfg, w_unet, w_cn, w_vae, clip_cfg=None, w_clip=None, guidance_scale=7.5):
         self.unet_cfg, self.cn_cfg = unet_cfg, cn_cfg
-        self.w_unet, self.w_cn, self.w_vae, self.w_clip = w_unet, w_cn, w_vae, w_clip
+        # fp32 copies of the (fp16-rounded) parameters, made ONCE: nets.py up-casts every weight where it uses it, which for
+        # fp16 dictionaries was a third of a full-size frame's oracle time (3.4 GB of conversions per UNet pass)
+        f32 = lambda w: None if w is None else {k: (v.float() if v.is_floating_point() else v) for k, v in w.items()}  # noqa: E731
+        self.w_unet, self.w_cn, self.w_vae, self.w_clip = f32(w_unet), f32(w_cn), f32(w_vae), f32(w_clip)
         self.clip_cfg = clip_cfg
         self.sched = LCMSchedulerOracle()
         self.guidance_scale = guidance_scale  # never forwarded by videopipeline.py:114-124 -> always 7.5

@@ -9,12 +9,15 @@ import pytest
 import torch
 from PIL import Image
 
-import oracle_ahead
-
 pytestmark = pytest.mark.gpu
 
 
-_frame = oracle_ahead.frame
+def _frame(h, w, seed=1):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    grad = ((xx * 5 + yy * 3) % 256).astype(np.uint8)[..., None]
+    return (base // 2 + grad // 2).astype(np.uint8)
 
 
 def _psnr(a, b):
@@ -37,24 +40,18 @@ def _cpu(w):
     return {k: v.cpu() for k, v in w.items()}
 
 
-def _compare(eng, orc, frame, text, H, W, steps, cn, cn_scale=1.5, ahead=None):
-    """ahead: name of a tests/oracle_ahead.py job whose frame / options these are -- its result is used when a child
-    process computed it while the earlier tests ran (same function, same seeded inputs), else the oracle runs here."""
+def _compare(eng, orc, frame, text, H, W, steps, cn, cn_scale=1.5):
     got = eng.infer_u8(frame)
-    pre = oracle_ahead.result(ahead) if ahead else None
-    if pre is not None:
-        ref, ref_x0, ref_den = pre["want"], torch.from_numpy(pre["init_latents"]), torch.from_numpy(pre["denoised"])
-    else:
-        ref = np.asarray(orc.infer(Image.fromarray(frame, "RGB"), text[None].float(), height=H, width=W, strength=0.6,
-                                   steps=steps, seed=23, controlnet_scale=cn_scale, use_controlnet=cn, keep_trace=True))
-        ref_x0, ref_den = orc.trace["init_latents"][0], orc.trace["denoised"][-1][0]
+    ref = np.asarray(orc.infer(Image.fromarray(frame, "RGB"), text[None].float(), height=H, width=W, strength=0.6,
+                               steps=steps, seed=23, controlnet_scale=cn_scale, use_controlnet=cn, keep_trace=True))
     h0, w0 = H // 8, W // 8
     x0 = eng.buffers["x0"][:, :4].float().cpu().reshape(h0, w0, 4).permute(2, 0, 1)
+    ref_x0 = orc.trace["init_latents"][0]
     r0 = float((x0 - ref_x0).norm() / ref_x0.norm())
     den = eng.buffers["denoised"][:, :4].float().cpu().reshape(h0, w0, 4).permute(2, 0, 1)
+    ref_den = orc.trace["denoised"][-1][0]
     r1 = float((den - ref_den).norm() / ref_den.norm())
     diff = np.abs(got.astype(int) - ref.astype(int))
-    _compare.last_denoised = ref_den
     return r0, r1, float(diff.mean()), _psnr(got, ref), got
 
 
@@ -270,11 +267,10 @@ def test_baseline_config2_512_four_step_matches_oracle(sd15_setup):
     eng.prepare(H, W, 4, 0.6, controlnet_scale=1.0, use_controlnet=True)
     assert eng.plan["timesteps"] == [599, 459, 319, 179]
     frames = np.stack([_frame(H, W, seed=s) for s in (31, 32, 33, 34, 35)])
-    assert oracle_ahead.SD15_JOBS["sd15_config2"] == (H, W, 4, True, 1.0, 31)
-    r0, r1, mad, psnr, got = _compare(eng, orc, frames[0], text, H, W, 4, True, cn_scale=1.0, ahead="sd15_config2")
+    r0, r1, mad, psnr, got = _compare(eng, orc, frames[0], text, H, W, 4, True, cn_scale=1.0)
     assert r0 <= 5e-3 and r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (r0, r1, mad, psnr)
     single = [got] + [eng.infer_u8(f).copy() for f in frames[1:]]
-    ref_den = _compare.last_denoised
+    ref_den = orc.trace["denoised"][-1][0]
     for nb in (3, 5):
         eng.prepare(H, W, 4, 0.6, controlnet_scale=1.0, use_controlnet=True, batch=nb)
         out = eng.infer_u8(frames[:nb])
@@ -293,8 +289,7 @@ def test_baseline_config5_768_eight_step_scale2_matches_oracle(sd15_setup):
     H = W = 768
     eng.prepare(H, W, 8, 0.6, controlnet_scale=2.0, use_controlnet=True)
     assert eng.plan["timesteps"] == [599, 539, 479, 419, 359, 299, 239, 179]
-    assert oracle_ahead.SD15_JOBS["sd15_config5"] == (H, W, 8, True, 2.0, 41)
-    r0, r1, mad, psnr, _ = _compare(eng, orc, _frame(H, W, seed=41), text, H, W, 8, True, cn_scale=2.0, ahead="sd15_config5")
+    r0, r1, mad, psnr, _ = _compare(eng, orc, _frame(H, W, seed=41), text, H, W, 8, True, cn_scale=2.0)
     assert r0 <= 5e-3 and r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (r0, r1, mad, psnr)
 
 
@@ -312,10 +307,10 @@ def test_reference_only_mode_512_four_step_matches_oracle(sd15_setup):
     frame, refimg = _frame(H, W, seed=51), _frame(H, W, seed=52)
     eng.ops.upload(eng.ref_u8, torch.from_numpy(refimg))
     got = eng.infer_u8(frame)
-    assert oracle_ahead.SD15_JOBS["sd15_ref512"] == (H, W, 4, False, 1.0, 51, 52)
-    pre = oracle_ahead.result("sd15_ref512") or oracle_ahead.sd15_infer(orc, text, *oracle_ahead.SD15_JOBS["sd15_ref512"])
-    want, ref_den = pre["want"], torch.from_numpy(pre["denoised"])
+    want = np.asarray(orc.infer(Image.fromarray(frame, "RGB"), text[None].float(), height=H, width=W, strength=0.6, steps=4, seed=23,
+                                ref_image=Image.fromarray(refimg, "RGB"), keep_trace=True))
     den = eng.buffers["denoised"][:, :4].float().cpu().reshape(H // 8, W // 8, 4).permute(2, 0, 1)
+    ref_den = orc.trace["denoised"][-1][0]
     r1 = float((den - ref_den).norm() / ref_den.norm())
     mad = float(np.abs(got.astype(int) - want.astype(int)).mean())
     assert r1 <= 2e-2 and mad <= 1.5 and _psnr(got, want) >= 38.0, (r1, mad, _psnr(got, want))

@@ -11,7 +11,6 @@ import pytest
 import torch
 from PIL import Image
 
-import oracle_ahead
 from test_pipeline_gpu import _cpu, _frame, _psnr
 
 pytestmark = pytest.mark.gpu
@@ -35,16 +34,16 @@ def _setup(cfg, prefix):
     return eng, orc, text, pooled
 
 
-def _compare(eng, orc, text, pooled, H, W, steps, ahead=None):
-    """ahead: a tests/oracle_ahead.py job with these options (its result, when a child process already has it)."""
+def _compare(eng, orc, text, pooled, H, W, steps):
     frame = _frame(H, W, seed=2)
     eng.set_added_cond(pooled, (H, W, 0, 0, H, W))
     eng.prepare(H, W, steps, 0.6, use_controlnet=False)
     got = eng.infer_u8(frame)
-    pre = (oracle_ahead.result(ahead) if ahead else None) or oracle_ahead.sdxl_infer(orc, text, pooled, H, W, steps, frame_seed=2)
-    ref, ref_den = pre["want"], torch.from_numpy(pre["denoised"])
+    ref = np.asarray(orc.infer(Image.fromarray(frame, "RGB"), text[None].float(), height=H, width=W, strength=0.6,
+                               steps=steps, seed=23, use_controlnet=False, keep_trace=True, pooled=pooled))
     h0, w0 = H // 8, W // 8
     den = eng.buffers["denoised"][:, :4].float().cpu().reshape(h0, w0, 4).permute(2, 0, 1)
+    ref_den = orc.trace["denoised"][-1][0]
     r1 = float((den - ref_den).norm() / ref_den.norm())
     mad = float(np.abs(got.astype(int) - ref.astype(int)).mean())
     return r1, mad, _psnr(got, ref)
@@ -104,6 +103,5 @@ def test_sdxl_1024_four_step_matches_oracle(full_xl):
     the 10-deep transformer stacks at 32x32 and the two-block stacks at 64x64 with the tiles / split-K full size selects.
     (Several minutes of CPU oracle: 27 TFLOP in fp32.)"""
     eng, orc, text, pooled = full_xl
-    assert oracle_ahead.SDXL_JOBS["sdxl_1024"] == (1024, 1024, 4)
-    r1, mad, psnr = _compare(eng, orc, text, pooled, 1024, 1024, 4, ahead="sdxl_1024")
+    r1, mad, psnr = _compare(eng, orc, text, pooled, 1024, 1024, 4)
     assert r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (r1, mad, psnr)
