@@ -1,0 +1,58 @@
+"""tests/golden/fullsize_oracle.npz: the CPU oracle's output for the two slowest full-size parity cases (3 minutes of fp32
+oracle each on the GPU box's 128 cores), so that the GPU suite checks them in seconds.
+
+    gpurun -- 'python scripts/make_fullsize_golden.py gpurun_out/fullsize_oracle.npz'   then copy to tests/golden/
+
+Runs where the tests run (the seeded weights are synthesised with DEVICE generators: weights.synthesize(device="cuda")),
+with exactly the inputs of tests/test_sdxl_gpu.py::test_sdxl_1024_four_step_matches_oracle and
+tests/test_pipeline_gpu.py::test_baseline_config5_768_eight_step_scale2_matches_oracle.  Stored per case: the final denoised
+latents and the TAESD-encoded input latents (fp16) and every second row / column of the output image (uint8) -- the tests
+compute their latent rel-L2, mean |diff| and PSNR against these.  VSD_LIVE_ORACLE=1 makes the tests run the oracle instead."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle.pipeline import OraclePipeline  # noqa: E402
+from videosd_amd import config as C, weights as W  # noqa: E402
+from test_pipeline_gpu import _cpu, _frame  # noqa: E402
+
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "fullsize_oracle.npz")
+res = {}
+wv = _cpu(W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda"))
+
+t0 = time.time()
+wu = _cpu(W.synthesize(W.unet_spec(C.SD15_UNET), "unet.", device="cuda"))
+wc = _cpu(W.synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", device="cuda"))
+text = (torch.randn(77, C.SD15_UNET.cross_dim, generator=torch.Generator().manual_seed(7)) * 0.5).half()
+orc = OraclePipeline(C.SD15_UNET, C.SD15_CONTROLNET, wu, wc, wv)
+H = W_ = 768
+img = np.asarray(orc.infer(Image.fromarray(_frame(H, W_, seed=41), "RGB"), text[None].float(), height=H, width=W_, strength=0.6,
+                           steps=8, seed=23, controlnet_scale=2.0, use_controlnet=True, keep_trace=True))
+res["config5_image_half"] = img[::2, ::2].copy()
+res["config5_denoised"] = orc.trace["denoised"][-1][0].half().numpy()
+res["config5_init_latents"] = orc.trace["init_latents"][0].half().numpy()
+print(f"config5 768x768 8-step scale 2: {time.time() - t0:.0f} s", flush=True)
+del orc, wu, wc
+
+t0 = time.time()
+cfg = C.SDXL_UNET
+wx = _cpu(W.synthesize(W.unet_spec(cfg), "sdxl.", device="cuda"))
+g = torch.Generator().manual_seed(11)
+text = (torch.randn(77, cfg.cross_dim, generator=g) * 0.5).half()
+pooled = (torch.randn(cfg.add_pooled_dim, generator=g) * 0.5).half()
+orc = OraclePipeline(cfg, None, wx, None, wv)
+H = W_ = 1024
+img = np.asarray(orc.infer(Image.fromarray(_frame(H, W_, seed=2), "RGB"), text[None].float(), height=H, width=W_, strength=0.6,
+                           steps=4, seed=23, use_controlnet=False, keep_trace=True, pooled=pooled))
+res["sdxl1024_image_half"] = img[::2, ::2].copy()
+res["sdxl1024_denoised"] = orc.trace["denoised"][-1][0].half().numpy()
+print(f"SDXL 1024x1024 4-step: {time.time() - t0:.0f} s", flush=True)
+np.savez_compressed(out, **res)
+print(out, os.path.getsize(out), "bytes")

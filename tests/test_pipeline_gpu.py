@@ -4,6 +4,8 @@ seeded weights, frame, text embeddings and noise draws.
 Tolerances (fp16 storage + fp32 accumulation vs an fp32 oracle):
   TAESD-encoded latents rel-L2 <= 5e-3; final denoised latent rel-L2 <= 2e-2;
   output image mean |diff| <= 1.5 LSB and PSNR >= 38 dB."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -53,6 +55,29 @@ def _compare(eng, orc, frame, text, H, W, steps, cn, cn_scale=1.5):
     r1 = float((den - ref_den).norm() / ref_den.norm())
     diff = np.abs(got.astype(int) - ref.astype(int))
     return r0, r1, float(diff.mean()), _psnr(got, ref), got
+
+
+GOLDEN_FULLSIZE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_oracle.npz")
+
+
+def _compare_golden(eng, frame, H, W, case):
+    """The same numbers as `_compare`, against the oracle output stored by scripts/make_fullsize_golden.py (the two
+    slowest full-size cases: 3 minutes of CPU oracle each; VSD_LIVE_ORACLE=1 runs the oracle instead): latents in fp16,
+    every second row / column of the image."""
+    got = eng.infer_u8(frame)
+    with np.load(GOLDEN_FULLSIZE) as z:
+        ref_half, ref_den = z[case + "_image_half"], torch.from_numpy(z[case + "_denoised"]).float()
+        ref_x0 = torch.from_numpy(z[case + "_init_latents"]).float() if case + "_init_latents" in z.files else None
+    h0, w0 = H // 8, W // 8
+    r0 = 0.0
+    if ref_x0 is not None:
+        x0 = eng.buffers["x0"][:, :4].float().cpu().reshape(h0, w0, 4).permute(2, 0, 1)
+        r0 = float((x0 - ref_x0).norm() / ref_x0.norm())
+    den = eng.buffers["denoised"][:, :4].float().cpu().reshape(h0, w0, 4).permute(2, 0, 1)
+    r1 = float((den - ref_den).norm() / ref_den.norm())
+    half = got[::2, ::2]
+    diff = np.abs(half.astype(int) - ref_half.astype(int))
+    return r0, r1, float(diff.mean()), _psnr(half, ref_half), got
 
 
 @pytest.fixture(scope="module")
@@ -284,12 +309,17 @@ def test_baseline_config2_512_four_step_matches_oracle(sd15_setup):
 
 @pytest.mark.slow
 def test_baseline_config5_768_eight_step_scale2_matches_oracle(sd15_setup):
-    """BASELINE.json configs[4] at full size: 768x768, 8 steps, ControlNet scale 2 (about 3-4 minutes of oracle)."""
+    """BASELINE.json configs[4] at full size: 768x768, 8 steps, ControlNet scale 2, against the oracle's frame of exactly
+    these inputs (tests/golden/fullsize_oracle.npz, written on the GPU box by scripts/make_fullsize_golden.py; with
+    VSD_LIVE_ORACLE=1 the oracle runs here: about 3 minutes)."""
     eng, orc, text = sd15_setup
     H = W = 768
     eng.prepare(H, W, 8, 0.6, controlnet_scale=2.0, use_controlnet=True)
     assert eng.plan["timesteps"] == [599, 539, 479, 419, 359, 299, 239, 179]
-    r0, r1, mad, psnr, _ = _compare(eng, orc, _frame(H, W, seed=41), text, H, W, 8, True, cn_scale=2.0)
+    if os.environ.get("VSD_LIVE_ORACLE") == "1":
+        r0, r1, mad, psnr, _ = _compare(eng, orc, _frame(H, W, seed=41), text, H, W, 8, True, cn_scale=2.0)
+    else:
+        r0, r1, mad, psnr, _ = _compare_golden(eng, _frame(H, W, seed=41), H, W, "config5")
     assert r0 <= 5e-3 and r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (r0, r1, mad, psnr)
 
 
