@@ -16,7 +16,6 @@ g_ = torch.Generator().manual_seed(0)
 r = lambda *s: (torch.randn(*s, generator=g_) * 0.05).half()
 SHAPES = [(8, 8, 1280, 1280, 3), (8, 8, 2560, 1280, 3), (16, 16, 1280, 1280, 3), (16, 16, 2560, 1280, 3), (16, 16, 1280, 1280, 1),
           (16, 16, 1280, 10240, 1), (16, 16, 5120, 1280, 1), (32, 32, 640, 640, 3), (32, 32, 1280, 640, 3), (32, 32, 640, 640, 1)]
-side = torch.cuda.Stream()
 for (H, W, cin, cout, ks) in SHAPES:
     pw = ops.to_device_pack(pack_conv(r(cout, cin, ks, ks), r(cout)))
     wbytes = pw.weight.numel() * 2
@@ -44,14 +43,23 @@ for (H, W, cin, cout, ks) in SHAPES:
     warm = timeit(lambda i: run(pw), max(60, 2 * ncopy))
     cold = timeit(lambda i: run(copies[i % ncopy]), max(60, 2 * ncopy))
 
-    def with_touch(i):
-        # touch copy i+1 on the side stream while copy i's layer runs (the sum forces the read; result unused)
-        with torch.cuda.stream(side):
-            copies[(i + 1) % ncopy].weight.view(torch.int32).sum()
+    # (c) does touching one dword of every 128-byte line of the NEXT copy (on the same stream, before this layer) make
+    # the next layer run as on warm weights?  (d) = the same touch kernel on an unrelated buffer: what the touch itself costs.
+    other = [c.weight.clone() for c in copies[:max(2, ncopy // 2)]]
+
+    def touch_next(i):
+        copies[(i + 1) % ncopy].weight.view(torch.int32).view(-1)[::32].sum()
         run(copies[i % ncopy])
-    pre = timeit(with_touch, max(60, 2 * ncopy))
+
+    def touch_other(i):
+        other[i % len(other)].view(torch.int32).view(-1)[::32].sum()
+        run(copies[i % ncopy])
+    with torch.cuda.stream(ops.stream):
+        pre = timeit(touch_next, max(60, 2 * ncopy))
+        base = timeit(touch_other, max(60, 2 * ncopy))
     print(f"B={B} {H}x{W} {cin}->{cout} k={ks}: weights {wbytes/1e6:5.1f} MB x {ncopy}; form {best[1:]}; "
-          f"warm {warm:6.1f} us ({wbytes/warm/1e6:5.2f} TB/s)  cold {cold:6.1f} us ({wbytes/cold/1e6:5.2f} TB/s)  "
-          f"cold + touch-ahead {pre:6.1f} us", flush=True)
+          f"warm {warm:6.1f} us  cold {cold:6.1f} us | touch next + layer {pre:6.1f} us, touch other + layer {base:6.1f} us "
+          f"-> prefetched layer ~ {cold - (base - pre):6.1f} us", flush=True)
+    del other
     del copies
     torch.cuda.empty_cache()
