@@ -901,3 +901,27 @@ def test_conv3x3_halo_patch_batched(ops):
     ops.synchronize()
     ref = F.silu(F.conv2d(xs.float(), wt.float(), bias.float(), padding=1)).permute(0, 2, 3, 1).reshape(g.m, cout)
     check(out, ref, "batched halo conv")
+
+
+@pytest.mark.parametrize("h,w,cin,cout,ks,tile,split,pipeline", [(32, 32, 128, 256, 3, 3, 1, 5), (32, 32, 128, 256, 3, 1, 2, 7),
+                                                                  (16, 64, 256, 512, 1, 0, 1, 3), (64, 64, 64, 128, 3, 4, 1, 7),
+                                                                  (16, 16, 512, 256, 3, 2, 4, 3)])
+def test_every_workgroup_order_gives_the_same_bits(ops, h, w, cin, cout, ks, tile, split, pipeline):
+    """block -> tile orders (csrc/conv_kernels.h block_to_tile): whole weight-tile groups per XCD, whole M tiles per XCD, the
+    XCDs as a 2 x 4 / 4 x 2 grid -- placement only, never the result (VSD_CONV_ORDER forces one where the tile counts allow)."""
+    import os
+
+    x = rnd(1, cin, h, w, seed=1)
+    wt = rnd(cout, cin, ks, ks, seed=2, scale=(cin * ks * ks) ** -0.5)
+    b = rnd(cout, seed=3, scale=0.1)
+    outs = {}
+    try:
+        for order in ("0", "1", "2", "3", "1d"):
+            os.environ["VSD_CONV_ORDER"] = order
+            got, ref = run_conv(ops, [x], h, w, wt, b, ksize=ks, tile=tile, split_k=split, pipeline=pipeline, act=2)
+            outs[order] = got
+    finally:
+        os.environ.pop("VSD_CONV_ORDER", None)
+    check(outs["0"], ref, "conv, order 0")
+    for order, o in outs.items():
+        assert torch.equal(o, outs["0"]), order

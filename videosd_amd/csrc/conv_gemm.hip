@@ -157,8 +157,21 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     const int nslice = p.split_k < gx ? p.split_k : gx;               // K slices of the input one XCD touches
     const double by_w = w_bytes + a_bytes * (G < 8 ? G : 8) * nslice / (double)p.split_k;
     const double by_a = a_bytes + w_bytes * (p.tiles_m < 8 ? p.tiles_m : 8);
-    static const char* force = getenv("VSD_CONV_ORDER");
-    p.order = force ? atoi(force) : (by_a < by_w ? 1 : 0);
+    // the XCDs as a 2 x 4 / 4 x 2 grid over (M tiles, groups): rows cross 4 / 2 times, weights 2 / 4 times
+    const bool ok24 = p.tiles_m % 2 == 0 && G % 4 == 0, ok42 = p.tiles_m % 4 == 0 && G % 2 == 0;
+    const double by_24 = ok24 ? 4.0 * a_bytes + 2.0 * w_bytes : 1e300, by_42 = ok42 ? 2.0 * a_bytes + 4.0 * w_bytes : 1e300;
+    const char* force = getenv("VSD_CONV_ORDER");  // (tests / benchmarking: 0 / 1 / 2 / 3 where valid, "1d" = never a grid)
+    const bool no_grid = force && force[0] == '1' && force[1] == 'd';
+    p.order = by_a < by_w ? 1 : 0;
+    double best = by_a < by_w ? by_a : by_w;
+    if (!no_grid && by_24 < best) { p.order = 2; best = by_24; }
+    if (!no_grid && by_42 < best) { p.order = 3; best = by_42; }
+    if (force && !no_grid) {
+      const int f = atoi(force);
+      if (f <= 1 || (f == 2 && ok24) || (f == 3 && ok42)) p.order = f;
+    }
+    p.gx = p.order == 2 ? G / 4 : (p.order == 3 ? G / 2 : 1);
+    p.fd_gx = fast_div((unsigned)p.gx);
     const int S = p.order ? G : p.tiles_m;  // (block_to_tile)
     p.fd_span = fast_div(8u * (unsigned)S);
     p.fd_s = fast_div((unsigned)S);

@@ -68,7 +68,9 @@ struct ConvParams {
   const half_t* zeros;  // >= 16 zero bytes: source of out-of-bounds chunks for the direct-to-LDS loader
   int* counters;  // per-tile arrival tickets for the in-kernel split-K reduction (all zero between launches)
   int tiles_m, tiles_n;
-  int order;    // block_to_tile: 0 = workgroups sharing a weight tile share an XCD, 1 = workgroups sharing input rows do
+  int order;    // block_to_tile: 0 = workgroups sharing a weight tile share an XCD, 1 = workgroups sharing input rows do,
+                // 2 / 3 = the XCDs as a 2 x 4 / 4 x 2 grid over (M tiles, weight-tile groups)
+  int gx;       // orders 2 / 3: weight-tile groups per XCD
 #ifdef VSD_CONV_PROBE
   long long* probe;  // scripts/conv_probe.cpp: per-section shader-clock totals of wave 0 of workgroup 0
 #endif
@@ -82,7 +84,7 @@ struct ConvParams {
   int t_img;    // transposed output: columns per image (image b's rows m land at b * t_img + (m - b * hw_out))
   // launch constants as multipliers (common.h fdiv): block -> tile (span = 8 S, S, tiles_n: see block_to_tile), output row ->
   // (image, y, x) (hw_out, wo), halo patch -> (image, patch row / column) (tiles per image, patches per row)
-  FastDiv fd_span, fd_s, fd_tiles_n, fd_hw_out, fd_wo, fd_tpi, fd_ppr;
+  FastDiv fd_span, fd_s, fd_tiles_n, fd_hw_out, fd_wo, fd_tpi, fd_ppr, fd_gx;
 };
 
 #ifdef VSD_CONV_PROBE
@@ -355,8 +357,21 @@ __device__ __forceinline__ void prefetch_kernargs() {
 // workgroups that read the SAME activation rows (same tile_m) share the XCD instead: the rows cross the fabric once, the
 // (small) weights up to 8 times -- right for the wide, shallow layers of the 64x64 / 32x32 levels and TAESD, where round 1's
 // counters showed every N tile's XCD re-fetching the input rows (51 MB of fabric traffic per launch against 21 MB of
-// operands).  The host picks the cheaper one per launch.  Pure speed: any placement gives the same result.
+// operands).  orders 2 / 3: the eight XCDs form a 2 x 4 / 4 x 2 grid -- XCD (xm, xn) owns the M tiles of class xm and the
+// weight-tile groups of class xn, so the rows cross the fabric 4 / 2 times and the weights 2 / 4 times: cheaper than either
+// one-dimensional order when the two operands are of similar size (the 32x32 and 16x16 levels with several frames per
+// launch; needs tiles_m and the group count divisible by the grid).  The host picks the cheapest per launch.  Pure speed:
+// any placement gives the same result.
 __device__ __forceinline__ void block_to_tile(const ConvParams& p, int bid, int& tile_m, int& grp) {
+  if (p.order >= 2) {
+    const int x = bid & 7, q = bid >> 3;   // XCD, sequence number inside it
+    const int mc = p.order == 2 ? 2 : 4, nc = 8 / mc;
+    const int xm = x & (mc - 1), xn = x >> (p.order == 2 ? 1 : 2);
+    const int i = fdiv(q, p.fd_gx), j = q - i * p.gx;  // consecutive workgroups of an XCD share their M tile
+    tile_m = i * mc + xm;
+    grp = j * nc + xn;
+    return;
+  }
   const int G = p.tiles_n * p.split_k;
   const int P = p.order ? p.tiles_m : G;   // spread over the XCDs
   const int S = p.order ? G : p.tiles_m;   // share one XCD
