@@ -1,11 +1,12 @@
-"""tests/golden/fullsize_oracle.npz: the CPU oracle's output for the two slowest full-size parity cases (3 minutes of fp32
+"""tests/golden/fullsize_oracle.npz: the CPU oracle's output for the slowest full-size parity cases (1-3 minutes of fp32
 oracle each on the GPU box's 128 cores), so that the GPU suite checks them in seconds.
 
     gpurun -- 'python scripts/make_fullsize_golden.py gpurun_out/fullsize_oracle.npz'   then copy to tests/golden/
 
 Runs where the tests run (the seeded weights are synthesised with DEVICE generators: weights.synthesize(device="cuda")),
-with exactly the inputs of tests/test_sdxl_gpu.py::test_sdxl_1024_four_step_matches_oracle and
-tests/test_pipeline_gpu.py::test_baseline_config5_768_eight_step_scale2_matches_oracle.  Stored per case: the final denoised
+with exactly the inputs of tests/test_sdxl_gpu.py::test_sdxl_1024_four_step_matches_oracle,
+tests/test_pipeline_gpu.py::test_baseline_config5_768_eight_step_scale2_matches_oracle and
+...::test_reference_only_mode_512_four_step_matches_oracle.  Stored per case: the final denoised
 latents and the TAESD-encoded input latents (fp16) and every second row / column of the output image (uint8) -- the tests
 compute their latent rel-L2, mean |diff| and PSNR against these.  VSD_LIVE_ORACLE=1 makes the tests run the oracle instead."""
 import os
@@ -39,6 +40,14 @@ res["config5_image_half"] = img[::2, ::2].copy()
 res["config5_denoised"] = orc.trace["denoised"][-1][0].half().numpy()
 res["config5_init_latents"] = orc.trace["init_latents"][0].half().numpy()
 print(f"config5 768x768 8-step scale 2: {time.time() - t0:.0f} s", flush=True)
+# the reference-only mode at 512x512, 4 steps (tests/test_pipeline_gpu.py::test_reference_only_mode_512_four_step_matches_oracle)
+t0 = time.time()
+H = W_ = 512
+img = np.asarray(orc.infer(Image.fromarray(_frame(H, W_, seed=51), "RGB"), text[None].float(), height=H, width=W_, strength=0.6,
+                           steps=4, seed=23, ref_image=Image.fromarray(_frame(H, W_, seed=52), "RGB"), keep_trace=True))
+res["ref512_image_half"] = img[::2, ::2].copy()
+res["ref512_denoised"] = orc.trace["denoised"][-1][0].half().numpy()
+print(f"reference-only 512x512 4-step: {time.time() - t0:.0f} s", flush=True)
 del orc, wu, wc
 
 t0 = time.time()

@@ -337,13 +337,18 @@ def test_reference_only_mode_512_four_step_matches_oracle(sd15_setup):
     frame, refimg = _frame(H, W, seed=51), _frame(H, W, seed=52)
     eng.ops.upload(eng.ref_u8, torch.from_numpy(refimg))
     got = eng.infer_u8(frame)
-    want = np.asarray(orc.infer(Image.fromarray(frame, "RGB"), text[None].float(), height=H, width=W, strength=0.6, steps=4, seed=23,
-                                ref_image=Image.fromarray(refimg, "RGB"), keep_trace=True))
     den = eng.buffers["denoised"][:, :4].float().cpu().reshape(H // 8, W // 8, 4).permute(2, 0, 1)
-    ref_den = orc.trace["denoised"][-1][0]
+    if os.environ.get("VSD_LIVE_ORACLE") == "1":
+        want = np.asarray(orc.infer(Image.fromarray(frame, "RGB"), text[None].float(), height=H, width=W, strength=0.6, steps=4,
+                                    seed=23, ref_image=Image.fromarray(refimg, "RGB"), keep_trace=True))
+        ref_den, half = orc.trace["denoised"][-1][0], got
+    else:  # the oracle's output for exactly these inputs, stored by scripts/make_fullsize_golden.py (50 s of oracle otherwise)
+        with np.load(GOLDEN_FULLSIZE) as z:
+            want, ref_den = z["ref512_image_half"], torch.from_numpy(z["ref512_denoised"]).float()
+        half = got[::2, ::2]
     r1 = float((den - ref_den).norm() / ref_den.norm())
-    mad = float(np.abs(got.astype(int) - want.astype(int)).mean())
-    assert r1 <= 2e-2 and mad <= 1.5 and _psnr(got, want) >= 38.0, (r1, mad, _psnr(got, want))
+    mad = float(np.abs(half.astype(int) - want.astype(int)).mean())
+    assert r1 <= 2e-2 and mad <= 1.5 and _psnr(half, want) >= 38.0, (r1, mad, _psnr(half, want))
     assert np.array_equal(got, eng.infer_u8(frame))  # deterministic replay
     lat = []
     for _ in range(6):
