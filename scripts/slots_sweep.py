@@ -46,4 +46,7 @@ for pt in pts:
         for e in pool:
             e.ops.synchronize()
         res.append(n * b / (time.perf_counter() - t))
-    print(f"{pt}: overlap={eng.overlap_controlnet} fps {max(res):.1f} (runs {', '.join('%.1f' % r for r in res)})", flush=True)
+    where = ""
+    if os.environ.get("SWEEP_ADDR"):  # (where the slots' arenas landed: throughput turned out to depend on it)
+        where = "  arenas " + " | ".join(",".join(hex(c.data_ptr()) for c in e.arena.chunks[:3]) for e in pool)
+    print(f"{pt}: overlap={eng.overlap_controlnet} fps {max(res):.1f} (runs {', '.join('%.1f' % r for r in res)}){where}", flush=True)

@@ -430,6 +430,8 @@ class Engine:
         import os as _os
         if _os.environ.get("VSD_SIDE") is not None:  # A/B switch
             self.use_side_stream = _os.environ.get("VSD_SIDE") == "1"
+        if _os.environ.get("VSD_OVERLAP_CN") is not None:  # A/B switch (callers that set the attribute afterwards still win)
+            self.overlap_controlnet = _os.environ.get("VSD_OVERLAP_CN") == "1"
         self._ev_count = 0
         # what a slot shares with its parent besides the weights: the per-plan constant block (schedule coefficients,
         # ControlNet scales) that the captured graphs READ, so that `update_options` reaches every graph at once

@@ -401,6 +401,12 @@ class VideoSDPipeline:
             eng.use_prompt(prompt)
         if self.is_xl:  # micro-conditioning: original size = target size = the frame size, no crop
             eng.set_added_cond(self.encode_pooled(prompt_text if prompt_text is not None else ""), (height, width, 0, 0, height, width))
+        # The two encoders as parallel branches of the graph: a single frame gains ~4 ms from it (22.8 against 26.9 ms through
+        # this class), a coalesced launch running beside another lane's loses (106 against 110-115 frames/s as a stream: how the
+        # runtime maps a graph's branches onto its few hardware queues decides, and with two graphs in flight it collides
+        # more often than not -- DESIGN.md section 3).  One frame per launch is the latency case, several are the loaded one.
+        if os.environ.get("VSD_OVERLAP_CN") is None:
+            eng.overlap_controlnet = batch == 1
         eng.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch, ref_mode=use_ref,
                     autotune=self.tuning_mode != "table")
         eng._ref_epoch = None
