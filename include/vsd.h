@@ -49,10 +49,10 @@ enum vsd_family {
   VSD_FAM_ATTENTION = 4, VSD_FAM_ELEMENTWISE = 5, VSD_FAM_COUNT = 6
 };
 
-/* Version of this interface (bumped whenever a struct grows or an entry point is added; round 3 = 3) and the size in
+/* Version of this interface (bumped whenever a struct grows or an entry point is added; round 3 = 3, round 4 = 4) and the size in
  * bytes of vsd_conv_desc as the LIBRARY was built: a caller compares both with its own header before the first call
  * (videosd_amd/lib.py does) instead of passing a short struct to a stale libvsd.so. */
-#define VSD_VERSION 3
+#define VSD_VERSION 4
 int vsd_version(void);
 int vsd_conv_desc_size(void);
 
@@ -267,6 +267,40 @@ int vsd_graph_begin(vsd_ctx* ctx, void* stream);
 int vsd_graph_end(vsd_ctx* ctx, void* stream, void** graph_exec_out);
 int vsd_graph_launch(vsd_ctx* ctx, void* graph_exec, void* stream);
 int vsd_graph_destroy(vsd_ctx* ctx, void* graph_exec);
+
+/* ---- launch streams with a hardware queue and a command-processor pipe of their own; launch sequences (round 4) -----
+ * Replace the reference's N independent actors per node (server.py:132-137, 317-321: one process, one CUDA context, one
+ * set of streams per GPU worker) INSIDE one worker: several launches in flight on one GPU, placed deterministically.
+ * What the placement has to respect on MI355X (scripts/queue_probe.cpp, scripts/pipe_probe.cpp): plain HIP streams share 4
+ * hardware queues in creation order (aliasing = an accident of what the process created before); a CU-masked stream has a
+ * queue of its own, but queue i of a process is served by command-processor pipe i mod 4 and two busy queues on one pipe
+ * take turns in long slices (two frame-like chains: 2.55x the time of one; on different pipes 1.00x).
+ * vsd_stream_pool: THE four launch streams of this process on the context's device (VSD_POOL_STREAMS; created together on
+ *   the first call = four different pipes, never destroyed; every context of the process gets the same four).  Ordinary
+ *   hipStream_t values (pass them as `stream` everywhere; torch wraps them with torch.cuda.ExternalStream).  The host side
+ *   puts launch lane l on stream l mod 4 and its side branch on stream (l + 2) mod 4.
+ * vsd_stream_pool_check: chains of `chain` dependent 10 us kernels on all four streams at once / one chain alone: ~1.0 when
+ *   the four run side by side, >= 2 when two of them share a pipe.
+ * vsd_stream_create / _destroy: a further CU-masked stream (cu_mask NULL = all CUs; `words` 32-bit words, bit i = CU i) for
+ *   callers that partition the CUs themselves; its pipe is (number of CU-masked streams the process created before) mod 4.
+ * vsd_seq: a frame's program as an ordered list of (single-branch graph executable -> stream), (record event on stream) and
+ *   (stream waits for event) items; vsd_seq_launch issues them in order without waiting.  Graphs with parallel branches are
+ *   avoided on purpose: two such executables in flight run one after the other on this runtime, single-branch graphs on
+ *   different pipes overlap.  The sequence owns its graph executables and events. */
+#define VSD_POOL_STREAMS 4
+#define VSD_MAX_DEVICES 16
+int vsd_stream_pool(vsd_ctx* ctx, void** streams_out /* [VSD_POOL_STREAMS] */);
+int vsd_stream_pool_check(vsd_ctx* ctx, int chain, float* ratio_out);
+typedef struct vsd_seq vsd_seq;
+int vsd_stream_create(vsd_ctx* ctx, const uint32_t* cu_mask, int words, void** stream_out);
+int vsd_stream_destroy(vsd_ctx* ctx, void* stream);
+int vsd_seq_create(vsd_ctx* ctx, vsd_seq** seq_out);
+int vsd_seq_add_graph(vsd_ctx* ctx, vsd_seq* seq, void* graph_exec, void* stream);
+int vsd_seq_add_record(vsd_ctx* ctx, vsd_seq* seq, void* stream, int* event_out);
+int vsd_seq_add_wait(vsd_ctx* ctx, vsd_seq* seq, void* stream, int event);
+int vsd_seq_count(vsd_ctx* ctx, vsd_seq* seq, int* graphs, int* edges);
+int vsd_seq_launch(vsd_ctx* ctx, vsd_seq* seq);
+int vsd_seq_destroy(vsd_ctx* ctx, vsd_seq* seq);
 
 /* ---- per-family device timing ------------------------------------------------------------------------
  * While profiling is on, every launch is bracketed by HIP events on its stream (do not capture graphs

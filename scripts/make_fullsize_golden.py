@@ -8,7 +8,15 @@ with exactly the inputs of tests/test_sdxl_gpu.py::test_sdxl_1024_four_step_matc
 tests/test_pipeline_gpu.py::test_baseline_config5_768_eight_step_scale2_matches_oracle and
 ...::test_reference_only_mode_512_four_step_matches_oracle.  Stored per case: the final denoised
 latents and the TAESD-encoded input latents (fp16) and every second row / column of the output image (uint8) -- the tests
-compute their latent rel-L2, mean |diff| and PSNR against these.  VSD_LIVE_ORACLE=1 makes the tests run the oracle instead."""
+compute their latent rel-L2, mean |diff| and PSNR against these.  VSD_LIVE_ORACLE=1 makes the tests run the oracle instead.
+
+The fixture carries `guard_sha256` / `guard_files`: the digest of the oracle sources, videosd_amd/weights.py, videosd_amd/config.py and
+the case parameters it was computed from (tests/golden_guard.py); tests/test_oracle_golden.py fails when they no longer match.
+
+    python scripts/make_fullsize_golden.py OUT --only mini64     the small CPU-weights case alone (runs anywhere, seconds),
+                                                                 merged into the arrays OUT already holds
+    python scripts/make_fullsize_golden.py OUT --stamp           only re-stamp OUT with the current digest (when a guarded file
+                                                                 changed in a way that cannot change the oracle's numbers)"""
 import os
 import sys
 import time
@@ -22,10 +30,48 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle.pipeline import OraclePipeline  # noqa: E402
 from videosd_amd import config as C, weights as W  # noqa: E402
+import json  # noqa: E402
+
+import golden_guard as G  # noqa: E402
 from test_pipeline_gpu import _cpu, _frame  # noqa: E402
 
-out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "fullsize_oracle.npz")
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+out = args[0] if args else G.GOLDEN_FULLSIZE
+only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
 res = {}
+if (only or "--stamp" in sys.argv) and os.path.exists(out):
+    with np.load(out) as z:
+        res = {k: z[k] for k in z.files}
+
+
+def save():
+    total, per = G.digests()
+    res["guard_sha256"] = np.array(total)
+    res["guard_files"] = np.array(json.dumps(per, sort_keys=True))
+    np.savez_compressed(out, **res)
+    print(out, os.path.getsize(out), "bytes, guard", total[:16])
+
+
+if "--stamp" in sys.argv:
+    save()
+    sys.exit(0)
+
+# the small case on CPU-generator weights (tests/golden_guard.py CASES["mini64"])
+c = G.CASES["mini64"]
+wu, wc = W.synthesize(W.unet_spec(C.MINI_UNET), "unet."), W.synthesize(W.controlnet_spec(C.MINI_CONTROLNET), "cn.")
+text = (torch.randn(77, C.MINI_UNET.cross_dim, generator=torch.Generator().manual_seed(c["text_seed"])) * 0.5).half()
+orc = OraclePipeline(C.MINI_UNET, C.MINI_CONTROLNET, wu, wc, W.synthesize(W.taesd_spec(C.TAESD), "vae."))
+img = np.asarray(orc.infer(Image.fromarray(_frame(c["H"], c["W"], seed=c["frame_seed"]), "RGB"), text[None].float(), height=c["H"],
+                           width=c["W"], strength=c["strength"], steps=c["steps"], seed=23, controlnet_scale=c["cn_scale"],
+                           use_controlnet=True, keep_trace=True))
+res["mini64_image_half"] = img[::2, ::2].copy()
+res["mini64_denoised"] = orc.trace["denoised"][-1][0].half().numpy()
+res["mini64_init_latents"] = orc.trace["init_latents"][0].half().numpy()
+if only == "mini64":
+    save()
+    sys.exit(0)
+del orc, wu, wc
+
 wv = _cpu(W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda"))
 
 t0 = time.time()
@@ -63,5 +109,4 @@ img = np.asarray(orc.infer(Image.fromarray(_frame(H, W_, seed=2), "RGB"), text[N
 res["sdxl1024_image_half"] = img[::2, ::2].copy()
 res["sdxl1024_denoised"] = orc.trace["denoised"][-1][0].half().numpy()
 print(f"SDXL 1024x1024 4-step: {time.time() - t0:.0f} s", flush=True)
-np.savez_compressed(out, **res)
-print(out, os.path.getsize(out), "bytes")
+save()

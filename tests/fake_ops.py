@@ -317,3 +317,32 @@ class FakeOps:
 
     def graph_destroy(self, g):
         pass
+
+    # launch sequences (HipOps.seq_*): the emulator keeps the STRUCTURE the engine builds -- ("graph", stream, calls run while
+    # capturing) / ("record", stream, event) / ("wait", stream, event) -- so that Engine._capture is testable without a GPU
+    def seq_create(self):
+        return {"items": [], "events": 0, "open": None}
+
+    def seq_capture_begin(self, sidx):
+        self._calls = 0
+
+    def seq_capture_end(self, seq, sidx):
+        seq["items"].append(("graph", sidx))
+
+    def seq_record(self, seq, sidx):
+        seq["items"].append(("record", sidx, seq["events"]))
+        seq["events"] += 1
+        return seq["events"] - 1
+
+    def seq_wait(self, seq, sidx, ev):
+        assert 0 <= ev < seq["events"]
+        seq["items"].append(("wait", sidx, ev))
+
+    def seq_count(self, seq):
+        return sum(i[0] == "graph" for i in seq["items"]), sum(i[0] == "wait" for i in seq["items"])
+
+    def seq_launch(self, seq):
+        raise RuntimeError("FakeOps cannot launch a sequence")
+
+    def seq_destroy(self, seq):
+        seq["items"] = None

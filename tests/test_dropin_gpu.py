@@ -101,8 +101,7 @@ def test_slider_options_do_not_rebuild_the_plan(pipe):
     assert np.array_equal(np.asarray(pipe.collect_batch(h)[0]), base)
     other = np.asarray(pipe.collect_batch(h2)[0])
     assert np.abs(other.astype(int) - base.astype(int)).mean() > 1.0
-    assert np.array_equal(np.asarray(pipe.infer(img, **{**OPTS, "prompt": "another prompt"})), other) or \
-        np.abs(np.asarray(pipe.infer(img, **{**OPTS, "prompt": "another prompt"})).astype(int) - other.astype(int)).mean() < 0.5
+    assert np.array_equal(np.asarray(pipe.infer(img, **{**OPTS, "prompt": "another prompt"})), other)  # lane 0 == lane 1, bit for bit
     with pytest.raises(ValueError):
         pipe.infer(img, **{**OPTS, "strength": 0.01})  # empty schedule: the caller's error, typed as such
 
@@ -124,7 +123,7 @@ def test_warm_up_prepares_every_batch_size_and_lane_and_two_lanes_do_not_share_s
     h1 = p.submit_batch([b], lane=1, **OPTS)
     got = [np.asarray(p.collect_batch(h0)[0]), np.asarray(p.collect_batch(h1)[0])]
     assert np.array_equal(got[0], alone[0])                                  # lane 0 is the engine `infer` used
-    assert np.abs(got[1].astype(int) - alone[1].astype(int)).mean() < 0.5      # lane 1: same program on its own slot
+    assert np.array_equal(got[1], alone[1])                                  # lane 1: same program on its own slot, same bits
     assert not np.array_equal(got[0], got[1])
     pair = p.infer_batch([a, b], **OPTS)                                      # the batch-2 plan is warm too
     assert np.abs(np.asarray(pair[1]).astype(int) - alone[1].astype(int)).mean() < 0.5
@@ -161,7 +160,9 @@ def test_two_sessions_alternate_without_stalls():
     assert not p.needs_idle(**sa) and not p.needs_idle(**sb)
     got_b = np.asarray(p.collect_batch(hb)[0])
     got_a = np.asarray(p.collect_batch(ha)[0])
-    assert np.array_equal(got_a, want_a[1]) and np.abs(got_b.astype(int) - want_b[2].astype(int)).mean() < 0.5
+    # bit-identical, not "close": a lane's engine shares weights, tuning table and prompt bytes with lane 0's and the kernels
+    # are deterministic -- a loose bound here would hide a cross-lane race on shared scratch or counters
+    assert np.array_equal(got_a, want_a[1]) and np.array_equal(got_b, want_b[2])
     # prompt LRU: a third and a fourth prompt evict nothing that is needed (max_prompts = 8); programs: max_plans = 3
     p.max_prompts = 2
     p.infer(imgs[0], **dict(sa, prompt="third"))
@@ -170,7 +171,7 @@ def test_two_sessions_alternate_without_stalls():
     p.infer(imgs[0], **dict(sa, height=128, width=128))  # a third program: the least recently used one (sb's) goes
     assert len(p._plans) == 2 and not any(pk[0] == 256 for pk in p._plans)
     n_prep = len(p._host_ms["prepare"])
-    assert np.abs(np.asarray(p.infer(imgs[3], **sb)).astype(int) - want_b[3].astype(int)).mean() < 0.5  # rebuilt on demand
+    assert np.array_equal(np.asarray(p.infer(imgs[3], **sb)), want_b[3])  # rebuilt on demand: the same kernels, the same bits
     assert len(p._host_ms["prepare"]) == n_prep + 1
 
 

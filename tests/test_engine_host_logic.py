@@ -274,3 +274,40 @@ def test_arena_gives_oversized_tensors_their_own_chunk_and_rewinds_to_the_same_a
     assert [t.data_ptr() for t in first] == [t.data_ptr() for t in again] and a.peak == peak
     ptrs = sorted((t.data_ptr(), t.numel() * t.element_size()) for t in first + [small])
     assert all(p0 + n0 <= p1 for (p0, n0), (p1, _) in zip(ptrs, ptrs[1:]))  # nothing overlaps
+
+
+def test_captured_program_is_a_sequence_of_single_branch_graphs_and_event_edges(mini):
+    """Engine._capture: every run of kernel calls on one stream is one graph, every fork / join / signal / wait an event edge
+    (record on the producing stream, wait on the consuming one), in program order; without a second stream the frame is ONE
+    graph.  (Two forked hipGraphs in flight serialise on the HIP runtime: include/vsd.h vsd_seq.)"""
+    wu, wc, wv, text = mini
+    steps = 2
+
+    def build(overlap, side=False, cn=True):
+        eng = Engine(FakeOps(), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
+        eng.set_text_embeds(text)
+        eng.overlap_controlnet, eng.use_side_stream = overlap, side
+        eng.prepare(64, 64, steps, 0.6, use_controlnet=cn, use_graph=False)
+        seq = eng._capture(eng.program)
+        return eng, seq["items"]
+
+    eng, items = build(False)
+    assert items == [("graph", 0)]
+    eng, items = build(True, cn=False)
+    assert items == [("graph", 0)]
+    # the two encoders on two streams: per step  main | record(0) wait(1) | ControlNet graph on 1 | UNet encoder graph on 0 |
+    # record(1) wait(0), then the merges + decoder (+ next step's head) on 0
+    eng, items = build(True)
+    kinds = [i[:2] for i in items]
+    per_step = [("record", 0), ("wait", 1), ("graph", 1), ("graph", 0), ("record", 1), ("wait", 0)]
+    assert kinds == [("graph", 0)] + (per_step + [("graph", 0)]) * steps
+    waits = [i for i in items if i[0] == "wait"]
+    recs = {i[2]: i[1] for i in items if i[0] == "record"}
+    assert len(waits) == 2 * steps and all(recs[w[2]] != w[1] for w in waits)      # every wait is on the OTHER stream's event
+    assert all(items.index(("record", recs[w[2]], w[2])) < items.index(w) for w in waits)
+    assert eng.ops.seq_count({"items": items}) == (1 + 3 * steps, 2 * steps)
+    # the side-stream option (ControlNet skip merges beside the decoder): more, smaller graphs; every named wait has its record
+    eng, items = build(True, side=True)
+    recs = {i[2] for i in items if i[0] == "record"}
+    assert all(i[2] in recs for i in items if i[0] == "wait")
+    assert sum(i[0] == "graph" for i in items) > 1 + 3 * steps

@@ -71,3 +71,46 @@ def test_step_traces():
             assert _ulp_close(prev.flatten().numpy(), it["prev"], ulps=2)
             assert (prev is den) == it["prev_is_denoised"]
             lat = prev
+
+
+def test_stored_fullsize_oracle_outputs_belong_to_the_current_oracle_sources():
+    """tests/golden/fullsize_oracle.npz holds the oracle's OUTPUT for the slowest full-size cases; it is only a valid reference
+    while the files it was computed from are the ones in the tree (nothing tied it to them).  The fixture carries the
+    digest of oracle/*.py, videosd_amd/weights.py, videosd_amd/config.py and the case parameters (tests/golden_guard.py)."""
+    import json
+
+    import numpy as np
+
+    import golden_guard as G
+
+    with np.load(G.GOLDEN_FULLSIZE) as z:
+        assert "guard_sha256" in z.files, "fixture without a source digest: regenerate with scripts/make_fullsize_golden.py"
+        stored, stored_per = str(z["guard_sha256"]), json.loads(str(z["guard_files"]))
+        for case in G.CASES:
+            assert f"{case}_image_half" in z.files and f"{case}_denoised" in z.files, case
+    total, per = G.digests()
+    changed = sorted(k for k in set(per) | set(stored_per) if per.get(k) != stored_per.get(k))
+    assert total == stored and not changed, (
+        f"tests/golden/fullsize_oracle.npz was computed from other versions of {changed}: regenerate it on the GPU box with "
+        "`python scripts/make_fullsize_golden.py` (or, when the edit cannot change the oracle's numbers, re-stamp it with --stamp "
+        "and say why in the commit)")
+
+
+def test_the_guard_notices_an_edited_oracle_source(tmp_path, monkeypatch):
+    import shutil
+
+    import golden_guard as G
+
+    root = tmp_path / "tree"
+    for rel in G.guarded_files():
+        (root / rel).parent.mkdir(parents=True, exist_ok=True)
+        shutil.copy(G.ROOT + "/" + rel, root / rel)
+    monkeypatch.setattr(G, "ROOT", str(root))
+    before, _ = G.digests()
+    assert before == G.digests()[0]
+    with open(root / "oracle" / "nets.py", "a") as f:
+        f.write("\n# an edit\n")
+    after, per = G.digests()
+    assert after != before
+    monkeypatch.setitem(G.CASES["config5"], "cn_scale", 2.5)
+    assert G.digests()[0] != after

@@ -57,7 +57,7 @@ def _compare(eng, orc, frame, text, H, W, steps, cn, cn_scale=1.5):
     return r0, r1, float(diff.mean()), _psnr(got, ref), got
 
 
-GOLDEN_FULLSIZE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_oracle.npz")
+from golden_guard import CASES as GOLDEN_CASES, GOLDEN_FULLSIZE  # noqa: E402  (tests/test_oracle_golden.py guards the fixture's sources)
 
 
 def _compare_golden(eng, frame, H, W, case):
@@ -307,19 +307,54 @@ def test_baseline_config2_512_four_step_matches_oracle(sd15_setup):
     eng.prepare(H, W, 4, 0.6, controlnet_scale=1.0, use_controlnet=True, batch=1)
 
 
+def test_stored_and_live_oracle_comparisons_agree():
+    """The full-size cases are compared with the oracle's STORED output (`_compare_golden`), everything else with the live
+    oracle (`_compare`).  One small case goes through both in the same test -- same engine, same frame -- so that the two code
+    paths cannot drift apart: the stored numbers must be the live numbers (up to the fixture's fp16 latents / half-resolution
+    image).  CPU-generator weights: the fixture's `mini64` arrays are reproducible in any container (--only mini64)."""
+    from oracle.pipeline import OraclePipeline
+    from videosd_amd import config as C
+    from videosd_amd import weights as W
+    from videosd_amd.engine import Engine
+    from videosd_amd.ops import HipOps
+
+    c = GOLDEN_CASES["mini64"]
+    wu, wc, wv = (W.synthesize(W.unet_spec(C.MINI_UNET), "unet."), W.synthesize(W.controlnet_spec(C.MINI_CONTROLNET), "cn."),
+                  W.synthesize(W.taesd_spec(C.TAESD), "vae."))
+    text = (torch.randn(77, C.MINI_UNET.cross_dim, generator=torch.Generator().manual_seed(c["text_seed"])) * 0.5).half()
+    dev = lambda w: {k: v.cuda() for k, v in w.items()}  # noqa: E731
+    eng = Engine(HipOps(0), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, dev(wu), dev(wc), dev(wv))
+    eng.set_text_embeds(text)
+    eng.prepare(c["H"], c["W"], c["steps"], c["strength"], controlnet_scale=c["cn_scale"], use_controlnet=True)
+    frame = _frame(c["H"], c["W"], seed=c["frame_seed"])
+    orc = OraclePipeline(C.MINI_UNET, C.MINI_CONTROLNET, wu, wc, wv)
+    live = _compare(eng, orc, frame, text, c["H"], c["W"], c["steps"], True, cn_scale=c["cn_scale"])
+    stored = _compare_golden(eng, frame, c["H"], c["W"], "mini64")
+    assert np.array_equal(live[4], stored[4])                                          # the same engine frame both times
+    assert live[0] <= 5e-3 and live[1] <= 2e-2 and live[2] <= 1.5 and live[3] >= 38.0, live[:4]
+    assert abs(live[0] - stored[0]) < 2e-4 and abs(live[1] - stored[1]) < 2e-4, (live[:2], stored[:2])  # fp16 storage of the latents
+    assert abs(live[2] - stored[2]) < 0.1 and abs(live[3] - stored[3]) < 1.0, (live[2:4], stored[2:4])  # every second row / column
+    # and the stored image IS the live oracle's image
+    want = np.asarray(orc.infer(Image.fromarray(frame, "RGB"), text[None].float(), height=c["H"], width=c["W"], strength=c["strength"],
+                                steps=c["steps"], seed=23, controlnet_scale=c["cn_scale"], use_controlnet=True))
+    with np.load(GOLDEN_FULLSIZE) as z:
+        assert np.array_equal(z["mini64_image_half"], want[::2, ::2])
+
+
 @pytest.mark.slow
 def test_baseline_config5_768_eight_step_scale2_matches_oracle(sd15_setup):
     """BASELINE.json configs[4] at full size: 768x768, 8 steps, ControlNet scale 2, against the oracle's frame of exactly
     these inputs (tests/golden/fullsize_oracle.npz, written on the GPU box by scripts/make_fullsize_golden.py; with
     VSD_LIVE_ORACLE=1 the oracle runs here: about 3 minutes)."""
     eng, orc, text = sd15_setup
-    H = W = 768
-    eng.prepare(H, W, 8, 0.6, controlnet_scale=2.0, use_controlnet=True)
-    assert eng.plan["timesteps"] == [599, 539, 479, 419, 359, 299, 239, 179]
+    c = GOLDEN_CASES["config5"]
+    H, W = c["H"], c["W"]
+    eng.prepare(H, W, c["steps"], c["strength"], controlnet_scale=c["cn_scale"], use_controlnet=True)
+    assert (H, W) == (768, 768) and eng.plan["timesteps"] == [599, 539, 479, 419, 359, 299, 239, 179]
     if os.environ.get("VSD_LIVE_ORACLE") == "1":
-        r0, r1, mad, psnr, _ = _compare(eng, orc, _frame(H, W, seed=41), text, H, W, 8, True, cn_scale=2.0)
+        r0, r1, mad, psnr, _ = _compare(eng, orc, _frame(H, W, seed=c["frame_seed"]), text, H, W, c["steps"], True, cn_scale=c["cn_scale"])
     else:
-        r0, r1, mad, psnr, _ = _compare_golden(eng, _frame(H, W, seed=41), H, W, "config5")
+        r0, r1, mad, psnr, _ = _compare_golden(eng, _frame(H, W, seed=c["frame_seed"]), H, W, "config5")
     assert r0 <= 5e-3 and r1 <= 2e-2 and mad <= 1.5 and psnr >= 38.0, (r0, r1, mad, psnr)
 
 
@@ -332,9 +367,10 @@ def test_reference_only_mode_512_four_step_matches_oracle(sd15_setup):
     import time
 
     eng, orc, text = sd15_setup
-    H = W = 512
-    eng.prepare(H, W, 4, 0.6, use_controlnet=False, ref_mode=True)
-    frame, refimg = _frame(H, W, seed=51), _frame(H, W, seed=52)
+    c = GOLDEN_CASES["ref512"]
+    H, W = c["H"], c["W"]
+    eng.prepare(H, W, c["steps"], c["strength"], use_controlnet=False, ref_mode=True)
+    frame, refimg = _frame(H, W, seed=c["frame_seed"]), _frame(H, W, seed=c["ref_seed"])
     eng.ops.upload(eng.ref_u8, torch.from_numpy(refimg))
     got = eng.infer_u8(frame)
     den = eng.buffers["denoised"][:, :4].float().cpu().reshape(H // 8, W // 8, 4).permute(2, 0, 1)

@@ -262,7 +262,14 @@ def test_a_dead_group_member_does_not_stall_a_prompt_change():
             res = [await asyncio.wait_for(d.next_result(), timeout=30) for _ in range(n)]
             dt = time.time() - t0
             assert n >= 3 and all(not isinstance(r[1], Exception) for r in res), res
+            # ... and ONCE: more frames with the same prompt post nothing further (every frame used to send every
+            # worker a local-encode request once the group was broken)
+            more = [d.submit(_img(30 + k), prompt="a blue whale", **OPTS) for k in range(4)]
+            for _ in range(sum(1 for t in more if t is not None)):
+                await asyncio.wait_for(d.next_result(), timeout=30)
+            assert d.local_prompt_requests == 1
             st = [await ws[g].method("session_state").remote() for g in (0, 2)]
+            assert all(s["encodes"] <= 3 for s in st), st  # "a red fox" (group), "a blue whale" once -- not once per frame
             return dt, d.healthy, d.worker_faults, st, d.group_ok
 
         dt, healthy, faults, st, group_ok = asyncio.run(go())

@@ -1,6 +1,9 @@
 // Context, hipGraph capture/replay and per-family timing for libvsd.
 #include <stdarg.h>
 
+#include <chrono>
+#include <mutex>
+
 #include "common.h"
 
 extern "C" int vsd_version(void) { return VSD_VERSION; }
@@ -72,6 +75,183 @@ extern "C" int vsd_graph_launch(vsd_ctx* ctx, void* graph_exec, void* stream) {
 extern "C" int vsd_graph_destroy(vsd_ctx* ctx, void* graph_exec) {
   if (!ctx || !graph_exec) return VSD_ERR_ARG;
   VSD_HIP(ctx, hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return VSD_OK;
+}
+
+// ---- streams with a hardware queue AND a command-processor pipe of their own ----------------------------------------
+// Measured on MI355X (scripts/queue_probe.cpp, scripts/pipe_probe.cpp; DESIGN.md section 3 "launches in flight"):
+//  * plain HIP streams share GPU_MAX_HW_QUEUES (4) hardware queues in creation order, the null stream and every stream any
+//    library of the process made included (ten streams -> queues 0 1 2 2 1 0 3 2 1 0): which launches in flight alias is
+//    an accident of history;
+//  * a stream created with a CU mask (also the mask of all CUs) gets a hardware queue of its own;
+//  * but the command processor serves those queues through 4 pipes, queue i of a process sits on pipe (i mod 4), and two
+//    BUSY queues on one pipe take turns in long slices: two chains of 100 dependent kernels on queues 0 and 4 take 2.55x
+//    the time of one chain (worse than back to back), on queues 0 and 1 1.00x; four chains on queues {0,1,2,3} 1.02x.
+// So a process gets exactly four launch streams per device, created together (consecutive queues = four different pipes),
+// kept for its lifetime, and everything that can be in flight at once is placed on different ones of them.
+__global__ void vsd_spin_kernel(unsigned long long ticks) {
+  unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {
+  }
+}
+
+static std::mutex g_pool_mu;
+static hipStream_t g_pool[VSD_MAX_DEVICES][VSD_POOL_STREAMS];
+static bool g_pool_made[VSD_MAX_DEVICES];
+
+static int full_cu_mask(vsd_ctx* ctx, std::vector<uint32_t>& all) {
+  hipDeviceProp_t prop;
+  VSD_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  all.assign((size_t)(prop.multiProcessorCount + 31) / 32, 0xffffffffu);
+  if (prop.multiProcessorCount % 32) all.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+  return VSD_OK;
+}
+
+extern "C" int vsd_stream_create(vsd_ctx* ctx, const uint32_t* cu_mask, int words, void** stream_out) {
+  if (!ctx || !stream_out || (cu_mask && words <= 0)) return VSD_ERR_ARG;
+  VSD_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<uint32_t> all;
+  if (!cu_mask) {
+    int rc = full_cu_mask(ctx, all);
+    if (rc != VSD_OK) return rc;
+    cu_mask = all.data();
+    words = (int)all.size();
+  }
+  hipStream_t s = nullptr;
+  VSD_HIP(ctx, hipExtStreamCreateWithCUMask(&s, (uint32_t)words, cu_mask));
+  *stream_out = (void*)s;
+  return VSD_OK;
+}
+
+extern "C" int vsd_stream_destroy(vsd_ctx* ctx, void* stream) {
+  if (!ctx || !stream) return VSD_ERR_ARG;
+  VSD_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
+  return VSD_OK;
+}
+
+extern "C" int vsd_stream_pool(vsd_ctx* ctx, void** streams_out) {
+  if (!ctx || !streams_out) return VSD_ERR_ARG;
+  if (ctx->device < 0 || ctx->device >= VSD_MAX_DEVICES) return vsd_fail(ctx, VSD_ERR_ARG, "stream_pool: device %d", ctx->device);
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  if (!g_pool_made[ctx->device]) {
+    VSD_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> all;
+    int rc = full_cu_mask(ctx, all);
+    if (rc != VSD_OK) return rc;
+    for (int i = 0; i < VSD_POOL_STREAMS; ++i)
+      VSD_HIP(ctx, hipExtStreamCreateWithCUMask(&g_pool[ctx->device][i], (uint32_t)all.size(), all.data()));
+    g_pool_made[ctx->device] = true;
+  }
+  for (int i = 0; i < VSD_POOL_STREAMS; ++i) streams_out[i] = (void*)g_pool[ctx->device][i];
+  return VSD_OK;
+}
+
+// Self-test of the placement: a chain of `chain` dependent 10 us kernels on every pool stream at once against one chain
+// alone.  ~1.0 = the four streams run side by side; >= 2 = two of them share a pipe (another CU-masked stream was created
+// between ours, or the runtime's mapping changed): callers report it (bench.py) or refuse to go on (tests).
+extern "C" int vsd_stream_pool_check(vsd_ctx* ctx, int chain, float* ratio_out) {
+  if (!ctx || !ratio_out || chain <= 0) return VSD_ERR_ARG;
+  void* st[VSD_POOL_STREAMS];
+  int rc = vsd_stream_pool(ctx, st);
+  if (rc != VSD_OK) return rc;
+  auto run = [&](int k, double* us) -> int {
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {
+      for (int i = 0; i < k; ++i) VSD_HIP(ctx, hipStreamSynchronize((hipStream_t)st[i]));
+      auto t0 = std::chrono::steady_clock::now();
+      for (int j = 0; j < chain; ++j)
+        for (int i = 0; i < k; ++i) hipLaunchKernelGGL(vsd_spin_kernel, dim3(64), dim3(64), 0, (hipStream_t)st[i], 1000ull);
+      for (int i = 0; i < k; ++i) VSD_HIP(ctx, hipStreamSynchronize((hipStream_t)st[i]));
+      double t = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      if (t < best) best = t;
+    }
+    *us = best;
+    return VSD_OK;
+  };
+  double one = 0, all = 0;
+  if ((rc = run(1, &one)) != VSD_OK || (rc = run(VSD_POOL_STREAMS, &all)) != VSD_OK) return rc;
+  *ratio_out = (float)(all / one);
+  return VSD_OK;
+}
+
+// ---- launch sequences ----------------------------------------------------------------------------------------------
+// A frame's program = single-branch graphs on the caller's streams + event edges between those streams, issued in order.
+// (Why not one graph with parallel branches: this runtime executes a forked graph on device-wide internal streams, and two
+// forked graph executables in flight run one after the other -- queue_probe: 2 x (2 branches of 300 us) = 675 us, three:
+// 1039 us -- while single-branch graphs on streams of different queues overlap fully, 4 x 300 us in 328 us, and the fork
+// written with events outside the graphs costs the same ~50 us as the runtime's own.)
+struct vsd_seq_item {
+  int kind;  // 0 graph, 1 record, 2 wait
+  hipGraphExec_t graph;
+  hipStream_t stream;
+  int event;
+};
+struct vsd_seq {
+  std::vector<vsd_seq_item> items;
+  std::vector<hipEvent_t> events;
+};
+
+extern "C" int vsd_seq_create(vsd_ctx* ctx, vsd_seq** seq_out) {
+  if (!ctx || !seq_out) return VSD_ERR_ARG;
+  *seq_out = new vsd_seq();
+  return VSD_OK;
+}
+
+extern "C" int vsd_seq_add_graph(vsd_ctx* ctx, vsd_seq* seq, void* graph_exec, void* stream) {
+  if (!ctx || !seq || !graph_exec) return VSD_ERR_ARG;
+  seq->items.push_back({0, (hipGraphExec_t)graph_exec, (hipStream_t)stream, -1});
+  return VSD_OK;
+}
+
+extern "C" int vsd_seq_add_record(vsd_ctx* ctx, vsd_seq* seq, void* stream, int* event_out) {
+  if (!ctx || !seq || !event_out) return VSD_ERR_ARG;
+  hipEvent_t e = nullptr;
+  VSD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  seq->events.push_back(e);
+  *event_out = (int)seq->events.size() - 1;
+  seq->items.push_back({1, nullptr, (hipStream_t)stream, *event_out});
+  return VSD_OK;
+}
+
+extern "C" int vsd_seq_add_wait(vsd_ctx* ctx, vsd_seq* seq, void* stream, int event) {
+  if (!ctx || !seq) return VSD_ERR_ARG;
+  if (event < 0 || event >= (int)seq->events.size()) return vsd_fail(ctx, VSD_ERR_ARG, "seq_add_wait: no such event %d", event);
+  seq->items.push_back({2, nullptr, (hipStream_t)stream, event});
+  return VSD_OK;
+}
+
+extern "C" int vsd_seq_count(vsd_ctx* ctx, vsd_seq* seq, int* graphs, int* edges) {
+  if (!ctx || !seq) return VSD_ERR_ARG;
+  int g = 0, w = 0;
+  for (auto& it : seq->items) {
+    g += it.kind == 0;
+    w += it.kind == 2;
+  }
+  if (graphs) *graphs = g;
+  if (edges) *edges = w;
+  return VSD_OK;
+}
+
+extern "C" int vsd_seq_launch(vsd_ctx* ctx, vsd_seq* seq) {
+  if (!ctx || !seq) return VSD_ERR_ARG;
+  for (auto& it : seq->items) {
+    if (it.kind == 0) {
+      VSD_HIP(ctx, hipGraphLaunch(it.graph, it.stream));
+    } else if (it.kind == 1) {
+      VSD_HIP(ctx, hipEventRecord(seq->events[it.event], it.stream));
+    } else {
+      VSD_HIP(ctx, hipStreamWaitEvent(it.stream, seq->events[it.event], 0));
+    }
+  }
+  return VSD_OK;
+}
+
+extern "C" int vsd_seq_destroy(vsd_ctx* ctx, vsd_seq* seq) {
+  if (!ctx || !seq) return VSD_ERR_ARG;
+  for (auto& it : seq->items)
+    if (it.kind == 0) (void)hipGraphExecDestroy(it.graph);
+  for (auto e : seq->events) (void)hipEventDestroy(e);
+  delete seq;
   return VSD_OK;
 }
 

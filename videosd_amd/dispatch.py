@@ -230,9 +230,8 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ["MASTER_PORT"] = str(group["port"])
             to = datetime.timedelta(seconds=float(group.get("timeout", 120.0)))
-            # a collective that was given up (sync_timeout) stays queued inside the communicator: its watchdog must only log
-            # that, not take the (healthy) process down when the group timeout passes later
-            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+            # (a collective that was given up at `sync_timeout` is ABORTED with its communicator -- `abandon_group` below -- so
+            # the backend's watchdog never sees it time out; its error handling stays at the default)
             if group["backend"] == "nccl":
                 dev = torch.device("cuda", int(config.get("device", 0)))
                 torch.cuda.set_device(dev)
@@ -245,7 +244,9 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
             # frames of one stream to different ranks): no per-rank timing of shapes the shipped table lacks; rank 0's
             # measured choices arrive through `__sync_tuning__`
             config = dict(config, tuning_mode="table")
-        pipe = _resolve(factory)(**config)
+        # (`lanes`: how many launches this loop keeps in flight -- the pipeline places lane l on launch stream l and only runs a
+        #  lane's ControlNet encoder on a side stream when the lanes leave it a command-processor pipe of its own)
+        pipe = _resolve(factory)(**dict(config, lanes=config.get("lanes", lanes)))
         conn.send(("ready", None))
     except BaseException as e:  # construction errors travel to the parent (the reference re-raises KeyError)
         conn.send(("error", (type(e).__name__, str(e))))
@@ -318,6 +319,30 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
         pipe.set_prompt_embeds(buf, key=key)
         return {"epoch": int(got["epoch"]), "rank": rank, "via": dist.get_backend(), "checksum": float(buf.float().sum())}
 
+    def abandon_group():
+        """After a failed or timed-out collective the communicator is finished (a member is gone; it cannot be re-entered).
+        With RCCL the abandoned broadcast is a KERNEL that stays resident on the GPU waiting for its peer, and every later
+        device-wide synchronisation of this worker (Engine.prepare's, a prompt build's) would wait behind it until the call
+        watchdog kills the worker: abort the communicator so that the kernel is torn down, and never use the group
+        again.  gloo has nothing resident; destroying the group is enough."""
+        nonlocal dist
+        if dist is None:
+            return
+        d, dist = dist, None  # (sync_prompt / sync_tuning take the local path from now on)
+        try:
+            pg = d.distributed_c10d._get_default_group()
+            backend = pg._get_backend(dev) if dev.type == "cuda" else None
+            if backend is not None and hasattr(backend, "abort"):
+                backend.abort()       # ProcessGroupNCCL.abort: ncclCommAbort -> the stuck kernel exits
+            elif backend is not None and hasattr(backend, "_shutdown"):
+                backend._shutdown()
+        except Exception:
+            pass
+        try:
+            d.destroy_process_group()
+        except Exception:
+            pass
+
     def sync_tuning():
         """Rank 0's per-shape kernel choices (its table plus what its warm-up measured) to every rank: one object broadcast."""
         if dist is None or world == 1 or not hasattr(pipe, "export_tuning"):
@@ -345,6 +370,7 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
                 # the collective failed (a member died, the deadline passed): this worker still serves the prompt -- it
                 # encodes it itself -- and reports the failure so that the dispatcher stops using the group
                 try:
+                    abandon_group()
                     sync_prompt(args[0], None, collective=False)
                     conn.send((rid, True, {"epoch": epoch, "rank": rank, "via": "local-after-failed-sync", "error": f"{type(e).__name__}: {e}"}))
                 except BaseException as e2:
@@ -809,9 +835,11 @@ class FrameDispatcher:
 
         self._prompts_known = OrderedDict()
         self._prompts_pending = set()
+        self._plock = threading.Lock()  # the two above + the per-sync countdown: touched by the workers' reader threads too
         self.max_prompts_known = 4
         self.prompt_syncs = 0
         self.prompt_sync_failures = 0
+        self.local_prompt_requests = 0  # prompts the workers were asked to encode themselves (no usable group)
 
     # ---- prompt broadcast
     def _member_alive(self, g) -> bool:
@@ -824,11 +852,12 @@ class FrameDispatcher:
         key = prompt_key(prompt)
         if not self.group_ok and not self._had_group:
             return  # stand-alone handles: each worker encodes a prompt when its first frame with it arrives
-        if key in self._prompts_known:
-            self._prompts_known.move_to_end(key)
-            return
-        if key in self._prompts_pending:  # its sync is on the way (the workers serve calls in order: the frame comes after it)
-            return
+        with self._plock:  # (`done` below runs on the workers' reader threads)
+            if key in self._prompts_known:
+                self._prompts_known.move_to_end(key)
+                return
+            if key in self._prompts_pending:  # its sync is on the way (the workers serve calls in order: the frame comes after it)
+                return
         # A collective with a dead member leaves the survivors waiting: check every member when the sync is
         # posted; if one is gone the group is finished and every worker encodes for itself (it does so on demand, at its
         # first frame with that prompt).  The race that remains -- a member dying inside the collective -- ends at the
@@ -836,7 +865,16 @@ class FrameDispatcher:
         if self.group_ok and not all(self._member_alive(g) for g in range(self.n)):
             self._group_broken(-1)
         if not self.group_ok:
-            # no collective any more: tell every live worker to encode the prompt itself, ahead of its frames
+            # No collective any more: ask every live worker ONCE per new prompt to encode it itself, ahead of its frames, and
+            # remember the key like a synced one.  (Round 3 never recorded it, so after a single worker death EVERY frame posted a
+            # local-encode request to every worker -- a CLIP pass and 40 MB of prompt constants rebuilt per worker per frame,
+            # queued ahead of the frames: ADVICE r3.  A worker that misses the request -- respawned later -- encodes on demand at
+            # its first frame with the prompt: VideoSDPipeline.submit_batch -> _cache_prompt.)
+            with self._plock:
+                self._prompts_known[key] = True
+                while len(self._prompts_known) > self.max_prompts_known:
+                    self._prompts_known.popitem(last=False)
+            self.local_prompt_requests += 1
             for g, p in enumerate(self.pipelines):
                 if self._member_alive(g) and hasattr(p, "sync_prompt"):
                     try:
@@ -845,37 +883,43 @@ class FrameDispatcher:
                         pass
             return
         self.prompt_syncs += 1
-        self._prompts_pending.add(key)
+        with self._plock:
+            self._prompts_pending.add(key)
         header = {k: float(options[k]) for k in PROMPT_HEADER_KEYS if k in options and isinstance(options[k], (int, float))}
         state = {"left": self.n, "ok": True}
 
         def done(f, g):
+            # runs on a RemotePipeline's reader thread (one per worker), concurrently with the event-loop thread's lookups
+            # above: every touch of the shared bookkeeping is under the lock (a lost decrement left the key pending
+            # forever; concurrent OrderedDict mutation can corrupt the LRU order)
             bad = f.cancelled() or f.exception() is not None
             if not bad:
                 r = f.result()
                 bad = isinstance(r, dict) and str(r.get("via", "")).startswith("local-after")
-            if bad:
-                state["ok"] = False
-                self.prompt_sync_failures += 1
-                self._group_broken(g)
-            state["left"] -= 1
-            if state["left"] == 0:
-                self._prompts_pending.discard(key)
-                if state["ok"]:  # known only once EVERY member has it
-                    self._prompts_known[key] = True
-                    while len(self._prompts_known) > self.max_prompts_known:
-                        self._prompts_known.popitem(last=False)
+            with self._plock:
+                if bad:
+                    state["ok"] = False
+                    self.prompt_sync_failures += 1
+                    self._group_broken(g)
+                state["left"] -= 1
+                if state["left"] == 0:
+                    self._prompts_pending.discard(key)
+                    if state["ok"]:  # known only once EVERY member has it
+                        self._prompts_known[key] = True
+                        while len(self._prompts_known) > self.max_prompts_known:
+                            self._prompts_known.popitem(last=False)
 
         for g, p in enumerate(self.pipelines):
             try:
                 fut = p.sync_prompt.remote(prompt, header)
                 fut.add_done_callback(lambda f, g=g: done(f, g))
             except Exception:
-                state["ok"] = False
-                state["left"] -= 1
-                if state["left"] == 0:
-                    self._prompts_pending.discard(key)
-                self._group_broken(g)
+                with self._plock:
+                    state["ok"] = False
+                    state["left"] -= 1
+                    if state["left"] == 0:
+                        self._prompts_pending.discard(key)
+                    self._group_broken(g)
 
     def _group_broken(self, gpu):
         # a member is gone: the communicator cannot be repaired; every worker encodes for itself from now on

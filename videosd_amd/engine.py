@@ -446,7 +446,7 @@ class Engine:
         self.use_fused_tail = True          # 320-wide blocks: per-token chains as fused launches (csrc/fused_tail.hip)
         self.tail_b_min_rows = 1024         # ... the feed-forward chain from this many tokens per launch on (see _transformer)
 
-    def make_slot(self, share_plan: bool = True) -> "Engine":
+    def make_slot(self, share_plan: bool = True, lane: Optional[int] = None) -> "Engine":
         """A further engine on the same GPU and the same weights, with its own streams, arena, I/O buffers, prompt constants
         and graph.
         share_plan=True: a further frame in flight of THIS engine's plan -- shares its schedule constants (`update_options`
@@ -455,10 +455,12 @@ class Engine:
         first leaves between its small dependent kernels.)
         share_plan=False: an independent plan (another frame size / step count / session) with constants of its own: it is
         prepared and updated like a parent, while the other plans keep running (server.py:90-93: options are per session,
-        every session's frames go through the same actors)."""
+        every session's frames go through the same actors).
+        lane: the launch lane whose streams the engine uses (HipOps.clone; default: the next unused lane).  Engines of one lane
+        take turns on its streams, engines of different lanes run side by side."""
         e = Engine.__new__(Engine)
         e.__dict__.update(self.__dict__)
-        e.ops = self.ops.clone()
+        e.ops = self.ops.clone(lane)
         e._vt_pool = {}
         e.graph = None
         e.plan = None
@@ -484,9 +486,13 @@ class Engine:
         e = embeds.reshape(-1, embeds.shape[-1]).to(torch.float16).contiguous()
         text = ops.to_device(e)
         tl = text.shape[0]
-        lay = self.family.get("layout")
-        if lay is None or lay.tl != tl:
-            lay = self.family["layout"] = PromptLayout(self._nets(), tl)
+        # one layout OBJECT per text length for the whole family: prepared plans and cached prompt blocks compare layouts by
+        # identity, so a 77 -> other -> 77 sequence of prompt lengths must come back to the first object
+        lays = self.family.setdefault("layouts", {})
+        lay = lays.get(tl)
+        if lay is None:
+            lay = lays[tl] = PromptLayout(self._nets(), tl)
+        self.family["layout"] = lay
         blk = PromptBlock(ops, lay)
         blk.text = text
         for ni, net in enumerate(self._nets()):
@@ -980,7 +986,7 @@ class Engine:
             sizes.append(((ph + 1) // 2, (pw_ + 1) // 2))
         hw0 = h0 * w0
         if self.graph is not None:
-            ops.graph_destroy(self.graph)
+            ops.seq_destroy(self.graph)
             self.graph = None
         self.arena = Arena(ops, chunk_bytes=max(256 << 20, _ru(batch * H * W * 64 * 2, 1 << 20)))  # >= one TAESD tensor
         self._vt_pool, self._vt_count = getattr(self, "_vt_pool", {}), 0
@@ -1102,10 +1108,60 @@ class Engine:
         r.run()
         ops.synchronize()
         if self.use_graph:
-            ops.graph_begin()
-            r.run()
-            self.graph = ops.graph_end()
+            self.graph = self._capture(r)
+            self.plan["graphs"], self.plan["edges"] = ops.seq_count(self.graph)
         return self.plan
+
+    SYNC_OPS = ("use_stream", "fork", "join", "signal", "wait")
+
+    def _capture(self, r: Recorder):
+        """The recorded program -> a launch sequence (include/vsd.h vsd_seq): every run of kernel calls on one stream becomes ONE
+        single-branch hipGraph on that stream, every fork / join / signal / wait an event edge between the two streams, issued
+        in program order by `vsd_seq_launch`.  A program without a second stream is one graph, as before.  (One graph with
+        parallel branches is what rounds 1-3 captured; on this runtime two such graphs in flight serialise -- DESIGN.md
+        section 3, "launches in flight".)"""
+        ops = self.ops
+        seq = ops.seq_create()
+        cur, run, names = 0, [], {}
+
+        def flush():
+            nonlocal run
+            if run:
+                ops.seq_capture_begin(cur)
+                try:
+                    for fn, a, k in run:
+                        fn(*a, **k)
+                finally:
+                    ops.seq_capture_end(seq, cur)
+                run = []
+
+        try:
+            for fn, a, k in r.calls:
+                name = getattr(fn, "__name__", "")
+                if name not in self.SYNC_OPS:
+                    run.append((fn, a, k))
+                    continue
+                if name == "use_stream":
+                    if a[0] != cur:
+                        flush()
+                        cur = a[0]
+                    continue
+                flush()
+                if name == "fork":
+                    ops.seq_wait(seq, 1, ops.seq_record(seq, 0))
+                elif name == "join":
+                    ops.seq_wait(seq, 0, ops.seq_record(seq, 1))
+                elif name == "signal":
+                    names[a[0]] = ops.seq_record(seq, cur)
+                else:
+                    ops.seq_wait(seq, cur, names[a[0]])
+            flush()
+        except Exception:
+            ops.use_stream(0)
+            ops.seq_destroy(seq)
+            raise
+        ops.use_stream(0)
+        return seq
 
     def _write_constants(self, sched: LCMSchedule, controlnet_scale: float, use_controlnet: bool):
         """Schedule- and option-dependent constants -> the device block / time-embedding tables the graphs read."""
@@ -1174,7 +1230,7 @@ class Engine:
         """Enqueue one frame's work (frame_u8 -> out_u8) on the ops stream."""
         self._sync_prompt()
         if self.graph is not None:
-            self.ops.graph_launch(self.graph)
+            self.ops.seq_launch(self.graph)
         else:
             self.program.run()
 

@@ -7,10 +7,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # VSD_LIB: another build of the same sources (development: the instrumented libvsd_tl.so of build.build_timeline)
 LIB_PATH = os.environ.get("VSD_LIB") or os.path.join(HERE, "libvsd.so")
 
-VERSION = 3  # include/vsd.h VSD_VERSION
+VERSION = 4  # include/vsd.h VSD_VERSION
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_QUICKGELU, ACT_SOFTMAX = range(6)
 ACT_POST = 256
 SPLITK_MAX_TILES = 16384
+POOL_STREAMS = 4  # include/vsd.h VSD_POOL_STREAMS
 TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128, TILE_256x128, TILE_256x64 = range(6)
 TILE_DIMS = {TILE_128x128: (128, 128), TILE_128x64: (128, 64), TILE_64x64: (64, 64), TILE_64x128: (64, 128),
              TILE_256x128: (256, 128), TILE_256x64: (256, 64)}
@@ -90,6 +91,17 @@ SIGNATURES = {
     "vsd_graph_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "vsd_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsd_graph_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vsd_stream_pool": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "vsd_stream_pool_check": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "vsd_stream_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
+    "vsd_stream_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vsd_seq_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "vsd_seq_add_graph": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsd_seq_add_record": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "vsd_seq_add_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vsd_seq_count": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vsd_seq_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vsd_seq_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vsd_profile_begin": (C.c_int, [C.c_void_p]),
     "vsd_profile_end": (C.c_int, [C.c_void_p]),
     "vsd_profile_overhead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),

@@ -81,19 +81,34 @@ class HipOps:
     name = "hip"
 
     def __init__(self, device_id: int = 0, stream: Optional[torch.cuda.Stream] = None, make_current: bool = True,
-                 tile_override: Optional[dict] = None):
+                 tile_override: Optional[dict] = None, lane: int = 0, _lanes: Optional[list] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("HipOps needs a ROCm GPU; there is no CPU fallback in the product path")
         self.device = torch.device("cuda", device_id)
         torch.cuda.set_device(self.device)
         self.ctx = L.Context(device_id)
-        self.stream = stream or torch.cuda.Stream(device=self.device)
+        # Launch lanes.  Everything that can be in flight at once on this GPU must sit on a hardware queue AND a command-processor
+        # pipe of its own; with plain streams both are accidents of what the process created before (DESIGN.md section 3,
+        # "launches in flight").  libvsd keeps four launch streams per process and device (vsd_stream_pool: four queues on four
+        # pipes); lane l launches on pool stream l mod 4 and runs its side branch (the ControlNet encoder beside the UNet
+        # encoder) on stream (l + 2) mod 4: two lanes with side branches, or four lanes without, never share a pipe.
+        # VSD_STREAMS=plain takes torch's pool streams instead (A/B measurements only).
+        self.lane = int(lane)
+        self._lanes = _lanes if _lanes is not None else [1]  # shared with every clone: the next free lane number
+        self._plain = _os.environ.get("VSD_STREAMS") == "plain"
+        if stream is not None:
+            self.streams = [stream, torch.cuda.Stream(device=self.device)]
+        elif self._plain:
+            self.streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+        else:
+            pool = self.pool_streams()
+            self.streams = [pool[self.lane % L.POOL_STREAMS], pool[(self.lane + 2) % L.POOL_STREAMS]]
+        self.stream = self.streams[0]
         # torch-side plumbing (allocation fills, H2D/D2H copies) must be ordered with the kernels: make the
         # kernel stream this thread's current torch stream.
         if make_current:
             torch.cuda.set_stream(self.stream)
         self.device_id = device_id
-        self.streams = [self.stream, torch.cuda.Stream(device=self.device)]
         self._sidx = 0
         self._events = {}
         self._ws = {}
@@ -109,41 +124,68 @@ class HipOps:
         self.stream.synchronize()
 
     # ------------------------------------------------------------------ helpers
+    def pool_streams(self):
+        """the process's four launch streams on this device, as torch streams (include/vsd.h vsd_stream_pool)"""
+        h = (C.c_void_p * L.POOL_STREAMS)()
+        self.ctx.call("vsd_stream_pool", h)
+        return [torch.cuda.ExternalStream(int(h[i]), device=self.device) for i in range(L.POOL_STREAMS)]
+
+    def pool_check(self, chain: int = 100) -> float:
+        """time of four frame-like kernel chains on the four launch streams at once / one chain alone: ~1.0 when they run side
+        by side, >= 2 when two of them share a command-processor pipe (vsd_stream_pool_check)"""
+        r = C.c_float()
+        self.ctx.call("vsd_stream_pool_check", int(chain), C.byref(r))
+        return float(r.value)
+
+    def _stream(self, idx: int):
+        return self.streams[idx]
+
     @property
     def s(self):
-        return C.c_void_p(self.streams[self._sidx].cuda_stream)
+        return C.c_void_p(self._stream(self._sidx).cuda_stream)
 
-    # ---- two-stream fork/join (become parallel branches of a captured hipGraph)
+    def raw_stream(self, idx: int = 0):
+        return C.c_void_p(self._stream(idx).cuda_stream)
+
+    # ---- two-stream fork/join.  Run live (eager mode) these are events between the two streams; in a captured program the
+    #      engine turns them into the edges of a launch sequence (Engine._capture), never into branches of one graph.
     def use_stream(self, idx: int):
         self._sidx = idx
 
     def fork(self):
         e = torch.cuda.Event()
-        e.record(self.streams[0])
-        self.streams[1].wait_event(e)
+        e.record(self._stream(0))
+        self._stream(1).wait_event(e)
 
     def join(self):
         e = torch.cuda.Event()
-        e.record(self.streams[1])
-        self.streams[0].wait_event(e)
+        e.record(self._stream(1))
+        self._stream(0).wait_event(e)
 
     # ---- named dependencies between the two streams (edges of the captured graph): `signal` marks a point of the
     #      current stream, `wait` makes the current stream wait for it
     def signal(self, name: str):
         e = torch.cuda.Event()
-        e.record(self.streams[self._sidx])
+        e.record(self._stream(self._sidx))
         self._events[name] = e
 
     def wait(self, name: str):
-        self.streams[self._sidx].wait_event(self._events[name])
+        self._stream(self._sidx).wait_event(self._events[name])
 
     @staticmethod
     def _p(t):
         return None if t is None else C.c_void_p(t.data_ptr())
 
-    def clone(self) -> "HipOps":
-        """Same GPU, own context / streams / scratch, shared tuning table: a second frame in flight."""
-        return HipOps(self.device_id, make_current=False, tile_override=self.tile_override)
+    def clone(self, lane: Optional[int] = None) -> "HipOps":
+        """Same GPU, own context / scratch, shared tuning table, the streams of launch lane `lane` (default: the next unused
+        one): a further frame in flight.  Objects of ONE lane share its streams -- they are meant to take turns (the engines of a
+        lane's several plans / batch sizes); objects of different lanes run side by side."""
+        if lane is None:
+            lane = self._lanes[0]
+            self._lanes[0] += 1
+        else:
+            self._lanes[0] = max(self._lanes[0], int(lane) + 1)
+        return HipOps(self.device_id, make_current=False, tile_override=self.tile_override, lane=lane, _lanes=self._lanes)
 
     def empty(self, *shape, dtype=torch.float16):
         with torch.cuda.stream(self.stream):
@@ -188,8 +230,8 @@ class HipOps:
         return cur
 
     def synchronize(self):
-        self.streams[1].synchronize()
-        self.stream.synchronize()
+        for st in reversed(self.streams):
+            st.synchronize()
 
     def upload(self, dst: torch.Tensor, src_cpu: torch.Tensor):
         """H2D on the kernel stream.  Asynchronous only from PINNED memory (the caller keeps that buffer alive, e.g. the
@@ -517,6 +559,40 @@ class HipOps:
 
     def graph_destroy(self, g):
         self.ctx.call("vsd_graph_destroy", g)
+
+    # ---- launch sequences (include/vsd.h vsd_seq): single-branch graphs on this object's streams + event edges between them
+    def seq_create(self):
+        q = C.c_void_p()
+        self.ctx.call("vsd_seq_create", C.byref(q))
+        return q
+
+    def seq_capture_begin(self, sidx: int):
+        self._sidx = sidx
+        self.ctx.call("vsd_graph_begin", self.raw_stream(sidx))
+
+    def seq_capture_end(self, seq, sidx: int):
+        g = C.c_void_p()
+        self.ctx.call("vsd_graph_end", self.raw_stream(sidx), C.byref(g))
+        self.ctx.call("vsd_seq_add_graph", seq, g, self.raw_stream(sidx))
+
+    def seq_record(self, seq, sidx: int) -> int:
+        ev = C.c_int()
+        self.ctx.call("vsd_seq_add_record", seq, self.raw_stream(sidx), C.byref(ev))
+        return int(ev.value)
+
+    def seq_wait(self, seq, sidx: int, ev: int):
+        self.ctx.call("vsd_seq_add_wait", seq, self.raw_stream(sidx), int(ev))
+
+    def seq_count(self, seq):
+        g, e = C.c_int(), C.c_int()
+        self.ctx.call("vsd_seq_count", seq, C.byref(g), C.byref(e))
+        return int(g.value), int(e.value)
+
+    def seq_launch(self, seq):
+        self.ctx.call("vsd_seq_launch", seq)
+
+    def seq_destroy(self, seq):
+        self.ctx.call("vsd_seq_destroy", seq)
 
     def profile_begin(self):
         self.ctx.call("vsd_profile_begin")

@@ -19,6 +19,7 @@ import torch
 from PIL import Image
 
 from . import config as C
+from . import checkpoints as CK
 from . import weights as W
 
 
@@ -38,16 +39,17 @@ def _weights_dir() -> Optional[str]:
     return d if d and os.path.isdir(d) else None
 
 
-def load_or_synthesize(spec, prefix: str, filename: str, device) -> Dict[str, torch.Tensor]:
-    """Real safetensors (diffusers key names) from $VSD_WEIGHTS/<filename> when present, else seeded synthetic."""
+def load_or_synthesize(spec, prefix: str, filename: str, device, snapshot_file: Optional[str] = None):
+    """-> (weights, source).  In this order: the safetensors file of a `from_pretrained` directory (`snapshot_file`, found by
+    weights.checkpoint_file), `$VSD_WEIGHTS/<filename>` (flat layout), seeded synthetic tensors (no checkpoint exists offline).
+    A file that lacks a tensor of the architecture, or holds it in another shape, is refused with the tensor's name."""
     d = _weights_dir()
-    if d and os.path.exists(os.path.join(d, filename)):
-        w = W.load_safetensors(os.path.join(d, filename), device=device)
-        missing = [n for n, _, _ in spec if n not in w]
-        if missing:
-            raise KeyError(f"{filename}: missing tensors {missing[:4]}...")
-        return w
-    return W.synthesize(spec, prefix, device=device)
+    path = snapshot_file or (os.path.join(d, filename) if d and os.path.exists(os.path.join(d, filename)) else None)
+    if path is not None:
+        w = CK.load_safetensors(path, device=device)
+        CK.check_against_spec(w, spec, path if snapshot_file else filename)
+        return w, path
+    return W.synthesize(spec, prefix, device=device), "synthetic"
 
 
 class VideoSDPipeline:
@@ -62,6 +64,9 @@ class VideoSDPipeline:
         self.honor_ref_flag = bool(kwargs.get("honor_ref_flag", False))
         self._ref_img = None
         self._ref_epoch = 0
+        # launch lanes this instance may keep in flight (`submit_batch(lane=...)`, the worker loop of dispatch.py): lane l runs on
+        # launch stream l (ops.HipOps); with at most two lanes every lane also has a stream for its side branch
+        self.max_lanes = max(1, int(kwargs.get("lanes", 2)))
         try:
             self.load_model(kwargs["model"], kwargs["controlnet"])
         except KeyError:
@@ -108,23 +113,46 @@ class VideoSDPipeline:
         # without a ControlNet tower; prompts then need 2048-wide embeddings + a 1280-wide pooled vector.
         self.is_xl = "xl" in str(model_name).lower()
         self.unet_cfg = C.SDXL_UNET if self.is_xl else C.SD15_UNET
+        # What `from_pretrained` reads (videopipeline.py:51-69), offline: `model` / `controlnet` given as DIRECTORIES in the
+        # Hugging Face snapshot layout -- <model>/unet/diffusion_pytorch_model.safetensors, <model>/text_encoder/model.safetensors,
+        # <model>/tokenizer/{vocab.json, merges.txt}; the ControlNet's and TAESD's diffusion_pytorch_model.safetensors at the top
+        # level of theirs -- or hub ids with a snapshot in the local HF cache; fp32 or fp16 tensors, cast to fp16 like
+        # torch_dtype=float16.  Then the flat $VSD_WEIGHTS/*.safetensors files, then seeded synthetic tensors.  Like the
+        # reference, a hub id that is not SimianLuo/LCM_Dreamshaper_v7 still gets that UNet (it hard-codes the id, :57); the VAE is
+        # `madebyollin/taesd` (:68) unless the extension kwarg `vae=` names another directory.
+        kw = getattr(self, "_kwargs", {})
+        mdir = CK.find_snapshot(model_name) or (None if self.is_xl else CK.find_snapshot("SimianLuo/LCM_Dreamshaper_v7"))
+        vdir = CK.find_snapshot(kw.get("vae") or ("madebyollin/taesdxl" if self.is_xl else "madebyollin/taesd"))
+        self.weight_sources = {}
         if self.is_xl:
-            wu = load_or_synthesize(W.unet_spec(C.SDXL_UNET), "sdxl.", "unet_sdxl.safetensors", dev)
-            wv = load_or_synthesize(W.taesd_spec(C.TAESD), "vae.", "taesdxl.safetensors", dev)
+            wu, self.weight_sources["unet"] = load_or_synthesize(W.unet_spec(C.SDXL_UNET), "sdxl.", "unet_sdxl.safetensors", dev,
+                                                                 CK.checkpoint_file(mdir, "unet"))
+            wv, self.weight_sources["vae"] = load_or_synthesize(W.taesd_spec(C.TAESD), "vae.", "taesdxl.safetensors", dev,
+                                                                CK.checkpoint_file(vdir))
             self.model = Engine(ops, C.SDXL_UNET, None, C.TAESD, wu, None, wv)
             self.text_encoder = None
             return self.model
-        wu = load_or_synthesize(W.unet_spec(C.SD15_UNET), "unet.", "unet.safetensors", dev)
-        wc = load_or_synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", "controlnet.safetensors", dev)
-        wv = load_or_synthesize(W.taesd_spec(C.TAESD), "vae.", "taesd.safetensors", dev)
+        cdir = CK.find_snapshot(controlnet_model)
+        wu, self.weight_sources["unet"] = load_or_synthesize(W.unet_spec(C.SD15_UNET), "unet.", "unet.safetensors", dev,
+                                                             CK.checkpoint_file(mdir, "unet"))
+        wc, self.weight_sources["controlnet"] = load_or_synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", "controlnet.safetensors", dev,
+                                                                   CK.checkpoint_file(cdir))
+        wv, self.weight_sources["vae"] = load_or_synthesize(W.taesd_spec(C.TAESD), "vae.", "taesd.safetensors", dev,
+                                                            CK.checkpoint_file(vdir))
         self.model = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
         self.text_encoder = None
         d = _weights_dir()
-        if d and os.path.exists(os.path.join(d, "text_encoder.safetensors")):
+        clip_file = CK.checkpoint_file(mdir, "text_encoder", stems=("model",))
+        tok_dir = os.path.join(mdir, "tokenizer") if mdir and os.path.isdir(os.path.join(mdir, "tokenizer")) else d
+        if clip_file is None and d and os.path.exists(os.path.join(d, "text_encoder.safetensors")):
+            clip_file = os.path.join(d, "text_encoder.safetensors")
+        self.weight_sources["text_encoder"] = clip_file or "stand-in embeddings seeded by the prompt text"
+        if clip_file is not None:
             from .clip import ClipTextEncoder
 
-            self.text_encoder = ClipTextEncoder(ops, C.CLIP_L, W.load_safetensors(os.path.join(d, "text_encoder.safetensors"),
-                                                                               device=dev))
+            wt = CK.load_safetensors(clip_file, device=dev)
+            CK.check_against_spec(wt, W.clip_spec(C.CLIP_L), clip_file)
+            self.text_encoder = ClipTextEncoder(ops, C.CLIP_L, wt, tokenizer_dir=tok_dir)
         return self.model
 
     def compile_model(self):
@@ -160,6 +188,13 @@ class VideoSDPipeline:
 
     def _cache_prompt(self, key, embeds=None, prompt=None):
         blk = self._prompts.get(key)
+        if blk is not None and embeds is not None and blk.text is not None:
+            # the same embeddings for a key this worker already holds (a repeated sync, a dispatcher that lost track of what the
+            # workers know): keep the block -- rebuilding it is 23 K / V GEMMs + 16 folds + a synchronise, and every engine
+            # would re-copy its 40 MB at its next launch
+            e = embeds.reshape(-1, embeds.shape[-1]).to(device=blk.text.device, dtype=torch.float16)
+            if e.shape == blk.text.shape and bool(torch.equal(e, blk.text)):
+                embeds = None
         if blk is None or embeds is not None:
             t0 = time.perf_counter()
             blk = self.model.build_prompt(embeds if embeds is not None else self.encode_prompt(prompt))
@@ -273,6 +308,8 @@ class VideoSDPipeline:
         """First half of `infer_batch`: crop / resize, upload, enqueue -- returns a handle for `collect_batch` without
         waiting for the GPU.  `lane` picks one of the prepared engines of that (options, batch size): two lanes keep two
         launches in flight while the host works on the frames around them (the worker loop of dispatch.py does that)."""
+        if not 0 <= int(lane) < self.max_lanes:
+            raise ValueError(f"lane {lane}: this pipeline was built for {self.max_lanes} launch lane(s) (kwarg `lanes`)")
         t0 = time.perf_counter()
         imgs = [center_crop_resize(im, width, height) for im in imgs]
         self._note("crop_resize", t0)
@@ -391,22 +428,23 @@ class VideoSDPipeline:
                 if not self._plan_busy(self._plans[pk]):
                     for e in self._plans.pop(pk)["engines"].values():
                         if e.graph is not None:
-                            e.ops.graph_destroy(e.graph)
+                            e.ops.seq_destroy(e.graph)
                             e.graph = None
-            eng = self.model.make_slot(share_plan=False)  # its own schedule constants: the other programs keep running
+            eng = self.model.make_slot(share_plan=False, lane=lane)  # its own schedule constants: the other programs keep running
             plan = self._plans[plan_key] = {"root": eng, "opts": opts, "engines": {}}
         else:
-            eng = plan["root"].make_slot()
+            eng = plan["root"].make_slot(lane=lane)
         if prompt is not None:
             eng.use_prompt(prompt)
         if self.is_xl:  # micro-conditioning: original size = target size = the frame size, no crop
             eng.set_added_cond(self.encode_pooled(prompt_text if prompt_text is not None else ""), (height, width, 0, 0, height, width))
-        # The two encoders as parallel branches of the graph: a single frame gains ~4 ms from it (22.8 against 26.9 ms through
-        # this class), a coalesced launch running beside another lane's loses (106 against 110-115 frames/s as a stream: how the
-        # runtime maps a graph's branches onto its few hardware queues decides, and with two graphs in flight it collides
-        # more often than not -- DESIGN.md section 3).  One frame per launch is the latency case, several are the loaded one.
+        # The ControlNet encoder beside the UNet encoder (a side stream of the lane: engine.Engine._capture).  ONE policy with
+        # bench.py: on whenever the lanes leave every lane a command-processor pipe for its side stream (at most two lanes),
+        # whatever the frames per launch -- a single frame gains ~4 ms, a coalesced launch beside another lane's ~4 %.  (Rounds
+        # 1-3 captured the two encoders as parallel branches of ONE graph and had to switch them off for coalesced launches:
+        # two such graphs in flight serialise on this runtime, DESIGN.md section 3 "launches in flight".)
         if os.environ.get("VSD_OVERLAP_CN") is None:
-            eng.overlap_controlnet = batch == 1
+            eng.overlap_controlnet = self.max_lanes <= 2
         eng.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch, ref_mode=use_ref,
                     autotune=self.tuning_mode != "table")
         eng._ref_epoch = None
