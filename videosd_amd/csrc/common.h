@@ -127,6 +127,10 @@ static inline unsigned long long* wgtl_claim(int grid) {  // host: the next laun
 #define WGTL_START() const unsigned long long wgtl_t0 = __builtin_amdgcn_s_memrealtime(); unsigned long long wgtl_t1 = 0, wgtl_ta = 0, wgtl_tb = 0, wgtl_tc = 0;
 #define WGTL_LOOP() wgtl_t1 = __builtin_amdgcn_s_memrealtime();
 #define WGTL_MARK(W_) wgtl_t##W_ = __builtin_amdgcn_s_memrealtime();  /* W_ = a, b or c: further points inside the epilogue */
+/* the tile epilogue is a function of its own (conv_tile_epilogue): its marks a / b are the kernel's variables, by reference */
+#define WGTL_EPI_PARAM , unsigned long long& wgtl_ta, unsigned long long& wgtl_tb
+#define WGTL_EPI_ARG , wgtl_ta, wgtl_tb
+#define WGTL_EPI_MARK(W_) wgtl_t##W_ = __builtin_amdgcn_s_memrealtime();
 #define WGTL_END(KIND_)                                                                                   \
   if (p.wgtl && threadIdx.x == 0) {                                                                       \
     unsigned long long* d_ = p.wgtl + 8 * (size_t)blockIdx.x;                                             \
@@ -140,5 +144,8 @@ static inline unsigned long long* wgtl_claim(int grid) {  // host: the next laun
 #define WGTL_START()
 #define WGTL_LOOP()
 #define WGTL_MARK(W_)
+#define WGTL_EPI_PARAM
+#define WGTL_EPI_ARG
+#define WGTL_EPI_MARK(W_)
 #define WGTL_END(KIND_)
 #endif
