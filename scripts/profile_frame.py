@@ -36,7 +36,7 @@ for fn, a, k in eng.program.calls:
         if tile is None:
             tile, sk = choose_tile(g.m, w.n, w.kp, w.geglu, k.get("t_col0", 0) if k.get("out_t") is not None else 0)
             split = sk if split is None else split
-        key = ops.conv_key(g, w, k.get("t_col0", 0), k.get("rowstat_out") is not None or k.get("chanstat_out") is not None)
+        key = ops.conv_key_of(g, w, k)
         ink = True
         if k.get("tile") is None and key in ops.tile_override:
             tile, split, ink, _pl = ops.tile_override[key]

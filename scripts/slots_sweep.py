@@ -25,12 +25,14 @@ slots = [eng]
 for pt in pts:
     force = pt[-1] if pt[-1] in "on" else None
     b, s = (int(x) for x in pt.rstrip("on").split("x"))
-    eng.overlap_controlnet = (s < 3) if force is None else (force == "o")
+    eng.overlap_controlnet = True
+    ovl = (s < 3) if force is None else (force == "o")
     while len(slots) < s:
         slots.append(eng.make_slot())
     pool = slots[:s]
     for e in pool:
-        e.overlap_controlnet = eng.overlap_controlnet
+        e.overlap_controlnet = True
+        e.overlap_launch = ovl
         e.prepare(512, 512, 4, 0.6, use_controlnet=True, batch=b)
     f = np.random.default_rng(0).integers(0, 256, (512, 512, 3) if b == 1 else (b, 512, 512, 3), dtype=np.uint8)
     for e in pool:
@@ -49,4 +51,4 @@ for pt in pts:
     where = ""
     if os.environ.get("SWEEP_ADDR"):  # (where the slots' arenas landed: throughput turned out to depend on it)
         where = "  arenas " + " | ".join(",".join(hex(c.data_ptr()) for c in e.arena.chunks[:3]) for e in pool)
-    print(f"{pt}: overlap={eng.overlap_controlnet} fps {max(res):.1f} (runs {', '.join('%.1f' % r for r in res)}){where}", flush=True)
+    print(f"{pt}: overlap={ovl} fps {max(res):.1f} (runs {', '.join('%.1f' % r for r in res)}){where}", flush=True)

@@ -15,7 +15,7 @@ eng.prepare(512, 512, 4, 0.6, use_controlnet=True, use_graph=False, autotune=Fal
 cnt = collections.Counter(); first = {}
 for fn, a, k in eng.program.calls:
     if fn.__name__ != "conv": continue
-    key = ops.conv_key(a[2], a[3], k.get("t_col0", 0), k.get("rowstat_out") is not None)
+    key = ops.conv_key_of(a[2], a[3], k)
     cnt[key] += 1; first.setdefault(key, (a, k))
 rows = []
 for key, (a, k) in first.items():

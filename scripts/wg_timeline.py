@@ -67,7 +67,7 @@ for fn, a, k in eng.program.calls:
     if fn.__name__ != "conv":
         continue
     g, w = a[2], a[3]
-    key = ops.conv_key(g, w, k.get("t_col0", 0), k.get("rowstat_out") is not None or k.get("chanstat_out") is not None)
+    key = ops.conv_key_of(g, w, k)
     cfg = ops.tile_override.get(key)
     kind = ("geglu" if w.geglu else "softmax" if w.tile128 else "qkv" if k.get("out_t") is not None else
             "ln" if k.get("ln_part") is not None else "plain")

@@ -35,7 +35,7 @@ class FakeOps:
     def copy_(self, dst, src):
         dst.copy_(src)
 
-    def clone(self):
+    def clone(self, lane=None):
         return FakeOps()
 
     def use_stream(self, idx):

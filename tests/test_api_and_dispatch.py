@@ -316,3 +316,21 @@ def test_two_rank_gloo_broadcast_and_sharding():
         flat = sorted(sum(out, []))
         assert [k for k, _ in flat] == list(range(11)) and all(r == k % 2 for k, r in flat)
         assert tmax == pytest.approx(0.2)
+
+
+def test_side_stream_policy_is_a_function_of_the_launches_in_flight():
+    """VideoSDPipeline._overlap_now: a launch runs its ControlNet encoder on the lane's side stream only while it has a
+    command-processor pipe for it -- at most two launches in flight, all on lanes 0 / 1 (lane l's side stream is lane l + 2's
+    own stream: videosd_amd/ops.py).  bench.py's engine legs state the same rule (`overlap_launch = slots < 3`)."""
+    from videosd_amd.pipeline import VideoSDPipeline
+
+    p = VideoSDPipeline.__new__(VideoSDPipeline)
+    os.environ.pop("VSD_OVERLAP_CN", None)
+    p._lanes_busy = []
+    assert p._overlap_now(0) and p._overlap_now(1) and not p._overlap_now(2) and not p._overlap_now(3)
+    p._lanes_busy = [0]
+    assert p._overlap_now(1) and not p._overlap_now(2)
+    p._lanes_busy = [0, 1]
+    assert not p._overlap_now(0) and not p._overlap_now(2)   # a third launch: three lanes busy
+    p._lanes_busy = [2]
+    assert not p._overlap_now(0)                             # lane 0's side stream IS lane 2's stream

@@ -307,6 +307,32 @@ def test_baseline_config2_512_four_step_matches_oracle(sd15_setup):
     eng.prepare(H, W, 4, 0.6, controlnet_scale=1.0, use_controlnet=True, batch=1)
 
 
+def test_side_stream_and_single_stream_sequences_give_the_same_bits(mini_setup):
+    """Every engine is captured twice (Engine._capture): the ControlNet encoder on the lane's side stream (graphs + event
+    edges) and everything on the lane's own stream (one graph).  Same kernels, same buffers: the frame must not depend on
+    which of the two a launch takes -- nor on another lane running beside it."""
+    eng, orc, text = mini_setup
+    eng.overlap_controlnet = True
+    eng.prepare(128, 128, 4, 0.6, controlnet_scale=1.5, use_controlnet=True)
+    assert eng.plan["edges"] == 2 * 4 and eng.plan["graphs"] == 1 + 3 * 4 and eng.graph_serial is not eng.graph
+    assert eng.ops.seq_count(eng.graph_serial) == (1, 0)
+    f = _frame(128, 128, seed=9)
+    eng.overlap_launch = True
+    a = eng.infer_u8(f)
+    eng.overlap_launch = False
+    b = eng.infer_u8(f)
+    assert np.array_equal(a, b)
+    other = eng.make_slot()          # lane 1, busy beside lane 0
+    other.prepare(128, 128, 4, 0.6, controlnet_scale=1.5, use_controlnet=True)
+    for ov in (True, False):
+        other.submit_u8(_frame(128, 128, seed=10), overlap=ov)
+        eng.submit_u8(f, overlap=ov)
+        assert np.array_equal(eng.collect_u8(), a)
+        other.collect_u8()
+    eng.overlap_launch = True
+    assert eng.ops.pool_check() < 1.5  # the four launch streams sit on four different command-processor pipes
+
+
 def test_stored_and_live_oracle_comparisons_agree():
     """The full-size cases are compared with the oracle's STORED output (`_compare_golden`), everything else with the live
     oracle (`_compare`).  One small case goes through both in the same test -- same engine, same frame -- so that the two code

@@ -1,5 +1,6 @@
 // Context, hipGraph capture/replay and per-family timing for libvsd.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <chrono>
 #include <mutex>
@@ -23,6 +24,8 @@ extern "C" vsd_ctx* vsd_create(int device_id) {
     c->fam_flops[i] = 0;
     c->fam_launch[i] = 0;
   }
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->num_cus = cus;
   return c;
 }
 
@@ -129,6 +132,21 @@ extern "C" int vsd_stream_destroy(vsd_ctx* ctx, void* stream) {
   return VSD_OK;
 }
 
+// The pool's streams are destroyed at process exit, BEFORE the HIP runtime's own teardown (atexit handlers run in reverse
+// order of registration, and the runtime registered its own long before the pool exists): left to the runtime, CU-masked
+// queues were torn down in an order that crashed rocprofv3's finalisation (SIGSEGV in __cxa_finalize under --kernel-trace).
+static void pool_destroy_at_exit() {
+  for (int d = 0; d < VSD_MAX_DEVICES; ++d) {
+    if (!g_pool_made[d]) continue;
+    if (hipSetDevice(d) != hipSuccess) continue;
+    for (int i = 0; i < VSD_POOL_STREAMS; ++i) {
+      (void)hipStreamSynchronize(g_pool[d][i]);
+      (void)hipStreamDestroy(g_pool[d][i]);
+    }
+    g_pool_made[d] = false;
+  }
+}
+
 extern "C" int vsd_stream_pool(vsd_ctx* ctx, void** streams_out) {
   if (!ctx || !streams_out) return VSD_ERR_ARG;
   if (ctx->device < 0 || ctx->device >= VSD_MAX_DEVICES) return vsd_fail(ctx, VSD_ERR_ARG, "stream_pool: device %d", ctx->device);
@@ -141,6 +159,11 @@ extern "C" int vsd_stream_pool(vsd_ctx* ctx, void** streams_out) {
     for (int i = 0; i < VSD_POOL_STREAMS; ++i)
       VSD_HIP(ctx, hipExtStreamCreateWithCUMask(&g_pool[ctx->device][i], (uint32_t)all.size(), all.data()));
     g_pool_made[ctx->device] = true;
+    static bool registered = false;
+    if (!registered) {
+      registered = true;
+      atexit(pool_destroy_at_exit);
+    }
   }
   for (int i = 0; i < VSD_POOL_STREAMS; ++i) streams_out[i] = (void*)g_pool[ctx->device][i];
   return VSD_OK;

@@ -29,6 +29,7 @@ struct vsd_ctx {
   bool capturing = false;
   std::vector<ProfEvent> events;
   void* zero_page = nullptr;  // 4 KiB of zeros in HBM (out-of-bounds source for LDS-DMA loads)
+  int num_cus = 256;          // compute units of the device (grid of the persistent kernels)
   double fam_flops[VSD_FAM_COUNT];
   int64_t fam_launch[VSD_FAM_COUNT];
 };

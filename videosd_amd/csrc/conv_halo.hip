@@ -4,24 +4,65 @@
 namespace {
 
 // ---------------------------------------------------------------- split-K reducer
+// One thread = 8 consecutive outputs of one row: the sum of the slabs in slab order, then the layer's epilogue.  A launch of
+// this kernel is a few hundred KB to a few MB of fp32 spread over the chip -- latency, not bandwidth: every load of a thread
+// (up to 8 slabs at a time and the residual chunk) is issued BEFORE the first is consumed, so that the
+// thread pays one memory round trip instead of one per slab (the first form's runtime-bounded loop: a dependent chain of
+// split_k round trips, then the epilogue's own loads).  The additions run in the same order: same bits.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
   const int nch = (p.N + 7) / 8;
   const size_t total = (size_t)p.M * nch;
+  const size_t slab = (size_t)p.M * p.N;
   for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
     int m = (int)(q / nch);
     int n = (int)(q - (size_t)m * nch) * 8;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const size_t slab = (size_t)p.M * p.N;
     const float* s = p.ws_partial + (size_t)m * p.N + n;
-    if (n + 8 <= p.N) {
-      for (int k = 0; k < p.split_k; ++k) {
-        f32x4 lo = *reinterpret_cast<const f32x4*>(s + k * slab);
-        f32x4 hi = *reinterpret_cast<const f32x4*>(s + k * slab + 4);
+    const bool full = n + 8 <= p.N;
+    const bool transposed = p.out_t && n >= p.t_col0;
+    // the epilogue's operands of these 8 columns, fetched beside the slabs
+    const bool pre_res = full && p.residual != nullptr && !transposed;
+    // (bias and time vector stay with epilogue_store8: it adds them one after the other, as the halo kernel's in-launch
+    //  epilogue does -- the two forms of a split halo conv must give the same bits -- and they are L2-resident row vectors)
+    const bool pre_brv = false;
+    half8 rres = (half8){0, 0, 0, 0, 0, 0, 0, 0}, braw = rres, rvraw = rres;
+    if (full) {
+      constexpr int NB = 8;
+      f32x4 lo[NB], hi[NB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[i] += lo[i];
-          v[4 + i] += hi[i];
+      for (int k = 0; k < NB; ++k) {
+        const int kk = k < p.split_k ? k : 0;  // (clamped: surplus loads hit slab 0's line again)
+        lo[k] = *reinterpret_cast<const f32x4*>(s + kk * slab);
+        hi[k] = *reinterpret_cast<const f32x4*>(s + kk * slab + 4);
+      }
+      if (pre_res) rres = *reinterpret_cast<const half8*>(p.residual + (size_t)m * p.ldr + n);
+      if (pre_brv && p.bias) braw = *reinterpret_cast<const half8*>(p.bias + n);
+      if (pre_brv && p.rowvec) rvraw = *reinterpret_cast<const half8*>(p.rowvec + n);
+#pragma unroll
+      for (int k = 0; k < NB; ++k)
+        if (k < p.split_k) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] += lo[k][i];
+            v[4 + i] += hi[k][i];
+          }
         }
+      for (int k0 = NB; k0 < p.split_k; k0 += NB) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          const int kk = k0 + k < p.split_k ? k0 + k : 0;
+          lo[k] = *reinterpret_cast<const f32x4*>(s + kk * slab);
+          hi[k] = *reinterpret_cast<const f32x4*>(s + kk * slab + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+          if (k0 + k < p.split_k) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              v[i] += lo[k][i];
+              v[4 + i] += hi[k][i];
+            }
+          }
       }
     } else {
       for (int k = 0; k < p.split_k; ++k) {
@@ -36,7 +77,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
       ln_transform8(p, n, mean, rstd, v);
     }
     float rs = 0.f, rq = 0.f;
-    epilogue_store8(p, m, n, v, rs, rq);
+    f32x4 blo, bhi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      blo[i] = (float)braw[i] + (float)rvraw[i];
+      bhi[i] = (float)braw[4 + i] + (float)rvraw[4 + i];
+    }
+    epilogue_store8(p, m, n, v, rs, rq, pre_res, rres, pre_brv, blo, bhi);
   }
 }
 

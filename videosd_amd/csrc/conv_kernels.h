@@ -85,6 +85,9 @@ struct ConvParams {
   // launch constants as multipliers (common.h fdiv): block -> tile (span = 8 S, S, tiles_n: see block_to_tile), output row ->
   // (image, y, x) (hw_out, wo), halo patch -> (image, patch row / column) (tiles per image, patches per row)
   FastDiv fd_span, fd_s, fd_tiles_n, fd_hw_out, fd_wo, fd_tpi, fd_ppr, fd_gx;
+  // persistent stream-K form (conv_streamk.hip): units = tiles * KT in tile-major order, workgroup g owns units [g q, (g + 1) q)
+  int sk_units, sk_q;
+  FastDiv fd_kt, fd_q;
 };
 
 #ifdef VSD_CONV_PROBE
@@ -115,6 +118,8 @@ void vsd_launch_conv_64x128(const ConvParams& p, int grid, int stages, hipStream
 void vsd_launch_conv_256x128(const ConvParams& p, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_halo(const ConvParams& p, int bm, int bn, int grid, hipStream_t s);
 void vsd_launch_splitk_reduce(const ConvParams& p, int grid, hipStream_t s);
+void vsd_launch_conv_streamk(const ConvParams& p, int bm, int bn, int grid, hipStream_t s);
+int vsd_streamk_lds_bytes(int bm, int bn);
 
 namespace {
 

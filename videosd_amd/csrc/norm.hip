@@ -41,7 +41,7 @@ __device__ __forceinline__ half8 gn_load(const GnParams& p, int row, int ch8) {
 // its row loads four at a time before consuming them, and the partial folds are spread over all threads with every
 // load of a thread independent of the others, so each phase costs about one memory round trip.
 __global__ void gn_stats_kernel(const GnParams p) {
-  extern __shared__ float sm[];  // [rpp][c][2] per-thread channel sums, folded in a fixed order
+  extern __shared__ float sm[];  // [16 planes][threads] per-thread channel sums (see below), folded in a fixed order
   const int t = threadIdx.x;
   const int ch8 = t % p.c8;
   const int rl = t / p.c8;
@@ -71,29 +71,38 @@ __global__ void gn_stats_kernel(const GnParams p) {
       s[i] += v3; q[i] += v3 * v3;
     }
   }
-  float* mine = sm + ((size_t)rl * p.c + ch8 * 8) * 2;
+  // LDS layout: 16 planes (channel-in-chunk i, sum | sumsq) of one word per THREAD -- sm[(2 i + which) * T + t].  A wave's
+  // store then hits 64 consecutive words (no bank conflict); the first form kept each thread's 16 values together
+  // (sm[rl][c][2]: a 64-byte stride between lanes, every second lane on the same bank -- LDS_BANK_CONFLICT / IDX_ACTIVE 0.62
+  // in the round-3 counters).  The additions below run in the same order as before: same bits.
+  const int T = blockDim.x;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    mine[2 * i] = s[i];
-    mine[2 * i + 1] = q[i];
+    sm[(2 * i) * T + t] = s[i];
+    sm[(2 * i + 1) * T + t] = q[i];
   }
   __syncthreads();
   // Fold in two steps, both in a fixed order (deterministic): (1) every (channel, sum | sumsq) over the rpp row lanes --
-  // consecutive threads read consecutive LDS words, rpp reads each; (2) every (group, sum | sumsq) over its cpg channels.
+  // thread j owns (plane, channel chunk): consecutive threads read consecutive words, rpp reads each, the result goes to row
+  // lane 0's word (read and written by this thread only); (2) every (group, sum | sumsq) over its cpg channels.
   // (The first form did both in one loop of rpp * cpg dependent LDS reads on 2 * groups threads -- 120 reads deep at
   // C = 320 with the other 400 threads idle, a third of the kernel's ~10 us.)
-  const int nval = p.c * 2;
-  for (int i = t; i < nval; i += blockDim.x) {
+  const int nval = 16 * p.c8;
+  for (int j = t; j < nval; j += T) {
+    const int pl = j / p.c8, c8i = j - pl * p.c8;
+    float* w = sm + pl * T + c8i;
     float acc = 0.f;
-    for (int rr = 0; rr < p.rpp; ++rr) acc += sm[(size_t)rr * nval + i];
-    sm[i] = acc;  // row lane 0's slot: read (rr = 0) and written by this thread only
+    for (int rr = 0; rr < p.rpp; ++rr) acc += w[rr * p.c8];
+    w[0] = acc;
   }
   __syncthreads();
-  for (int i = t; i < p.groups * 2; i += blockDim.x) {
+  for (int i = t; i < p.groups * 2; i += T) {
     const int g = i >> 1, which = i & 1;
-    const float* row = sm + (size_t)g * p.cpg * 2 + which;
     float acc = 0.f;
-    for (int c = 0; c < p.cpg; ++c) acc += row[2 * c];
+    for (int k = 0; k < p.cpg; ++k) {
+      const int c = g * p.cpg + k;
+      acc += sm[(2 * (c & 7) + which) * T + (c >> 3)];
+    }
     p.part[((size_t)blockIdx.y * p.nblk + blockIdx.x) * p.groups * 2 + i] = acc;
   }
 }

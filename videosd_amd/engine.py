@@ -420,7 +420,9 @@ class Engine:
         self.use_graph = True
         self.is_slot = False
         self.batch = 1
-        self.overlap_controlnet = True  # run the ControlNet encoder on a second stream, parallel to the UNet encoder
+        self.overlap_controlnet = True  # record the ControlNet encoder for a second stream, parallel to the UNet encoder
+        self.overlap_launch = True      # ... and launch it that way by default (`launch(overlap=...)` decides per launch)
+        self.graph_serial = None
         # ... and, optionally, while that stream is otherwise idle: the ControlNet skip merges beside the mid block / decoder
         # start and Sobel + conditioning embedding beside the TAESD encoder (`use_side_stream`).  Measured on MI355X (512x512,
         # 4 steps): one frame alone 23.8 -> 23.2 ms, but with two launches in flight 97 -> 81 frames/s -- four busy hardware
@@ -463,6 +465,7 @@ class Engine:
         e.ops = self.ops.clone(lane)
         e._vt_pool = {}
         e.graph = None
+        e.graph_serial = None
         e.plan = None
         e._stage = None  # own pinned staging buffers and events (a copy of the parent's would be SHARED with it)
         e.pblock = None
@@ -935,7 +938,7 @@ class Engine:
         for fn, a, k in self.program.calls:
             if fn.__name__ != "conv":
                 continue
-            key = ops.conv_key(a[2], a[3], k.get("t_col0", 0), k.get("rowstat_out") is not None or k.get("chanstat_out") is not None)
+            key = ops.conv_key_of(a[2], a[3], k)
             if key in seen or key in ops.tile_override or k.get("tile") is not None:
                 continue
             best, table = ops.tune_conv(a, k)
@@ -985,9 +988,7 @@ class Engine:
             ph, pw_ = sizes[-1]
             sizes.append(((ph + 1) // 2, (pw_ + 1) // 2))
         hw0 = h0 * w0
-        if self.graph is not None:
-            ops.seq_destroy(self.graph)
-            self.graph = None
+        self._destroy_graphs()
         self.arena = Arena(ops, chunk_bytes=max(256 << 20, _ru(batch * H * W * 64 * 2, 1 << 20)))  # >= one TAESD tensor
         self._vt_pool, self._vt_count = getattr(self, "_vt_pool", {}), 0
         # persistent per-frame I/O and constants
@@ -1108,14 +1109,20 @@ class Engine:
         r.run()
         ops.synchronize()
         if self.use_graph:
+            # two launch sequences of the SAME program (same kernels, same buffers): the ControlNet encoder on the lane's side
+            # stream (a lone launch: ~4 ms less per frame), and everything on the lane's own stream (what a launch takes when
+            # three or four lanes are busy: the side stream IS another lane's stream).  `launch(overlap=...)` picks per launch.
             self.graph = self._capture(r)
             self.plan["graphs"], self.plan["edges"] = ops.seq_count(self.graph)
+            self.graph_serial = self._capture(r, serial=True) if self.plan["edges"] else self.graph
         return self.plan
 
     SYNC_OPS = ("use_stream", "fork", "join", "signal", "wait")
 
-    def _capture(self, r: Recorder):
-        """The recorded program -> a launch sequence (include/vsd.h vsd_seq): every run of kernel calls on one stream becomes ONE
+    def _capture(self, r: Recorder, serial: bool = False):
+        """serial=True: every call on stream 0, no edges (the program's fork / join / signal / wait markers are dropped: in one
+        in-order stream they hold by construction) -- one graph.
+        The recorded program -> a launch sequence (include/vsd.h vsd_seq): every run of kernel calls on one stream becomes ONE
         single-branch hipGraph on that stream, every fork / join / signal / wait an event edge between the two streams, issued
         in program order by `vsd_seq_launch`.  A program without a second stream is one graph, as before.  (One graph with
         parallel branches is what rounds 1-3 captured; on this runtime two such graphs in flight serialise -- DESIGN.md
@@ -1141,6 +1148,8 @@ class Engine:
                 if name not in self.SYNC_OPS:
                     run.append((fn, a, k))
                     continue
+                if serial:
+                    continue
                 if name == "use_stream":
                     if a[0] != cur:
                         flush()
@@ -1162,6 +1171,14 @@ class Engine:
             raise
         ops.use_stream(0)
         return seq
+
+    def _destroy_graphs(self):
+        g, gs = self.graph, getattr(self, "graph_serial", None)
+        self.graph = self.graph_serial = None
+        if g is not None:
+            self.ops.seq_destroy(g)
+        if gs is not None and gs is not g:
+            self.ops.seq_destroy(gs)
 
     def _write_constants(self, sched: LCMSchedule, controlnet_scale: float, use_controlnet: bool):
         """Schedule- and option-dependent constants -> the device block / time-embedding tables the graphs read."""
@@ -1226,11 +1243,14 @@ class Engine:
         return d, torch.cat(ref_draws, dim=0).reshape(n_steps, 4, h * w).contiguous()
 
     # ---------------------------------------------------------------- per frame
-    def launch(self):
-        """Enqueue one frame's work (frame_u8 -> out_u8) on the ops stream."""
+    def launch(self, overlap: Optional[bool] = None):
+        """Enqueue one frame's work (frame_u8 -> out_u8) on the lane's stream(s).  overlap: run the ControlNet encoder on the
+        lane's side stream (default: `self.overlap_launch`); pass False when a launch of the lane that OWNS that stream
+        (lane + 2 mod 4) may be in flight -- two busy queues on one command-processor pipe take turns (ops.HipOps)."""
         self._sync_prompt()
         if self.graph is not None:
-            self.ops.seq_launch(self.graph)
+            ov = self.overlap_launch if overlap is None else overlap
+            self.ops.seq_launch(self.graph if ov else self.graph_serial)
         else:
             self.program.run()
 
@@ -1250,9 +1270,9 @@ class Engine:
             self._stage = st
         return st
 
-    def submit_u8(self, frame: np.ndarray):
+    def submit_u8(self, frame: np.ndarray, overlap: Optional[bool] = None):
         """Upload + enqueue one frame (or batch) without waiting: pair with `collect_u8`.  Lets the host prepare the
-        next frames / post-process the previous ones while this one is on the GPU."""
+        next frames / post-process the previous ones while this one is on the GPU.  overlap: see `launch`."""
         want = self._want_shape()
         if frame.shape != want or frame.dtype != np.uint8:
             raise ValueError(f"frame must be uint8 {want}, got {frame.dtype} {frame.shape}")
@@ -1261,7 +1281,7 @@ class Engine:
         self.ops.upload(self.frame_u8, hin)
         if e0 is not None:
             e0.record(self.ops.stream)
-        self.launch()
+        self.launch(overlap)
         if e1 is not None:
             e1.record(self.ops.stream)
 

@@ -263,18 +263,13 @@ class HipOps:
         c0 = c0 if c0 is not None else (w.cin - c1)
         if w.geglu:
             act = L.ACT_GEGLU
-        key = self.conv_key(g, w, t_col0, rowstat_out is not None or chanstat_out is not None)
+        key = self.conv_key(g, w, t_col0, self.epilogue_class(w, rowstat_out, ln_part, chanstat_out, residual2, out2, out_scale_dev, out_scale, act))
         inkernel = self.inkernel_splitk
         if tile is None:
             if key in self.tile_override:
+                # (the key names the epilogue class since round 4: an entry always fits the call it is looked up for -- rounds
+                #  2-3 keyed on the shape alone and widened 64-column tiles / left the halo form after the fact)
                 tile, split_k, inkernel, pipeline = self.tile_override[key]
-                if w.tile128 or w.geglu:
-                    # these epilogues need whole 128-column tiles.  The shape key does not say which epilogue a layer has, so a
-                    # table entry found for a plain layer of the same (M, N, K) may name a 64-column tile or a form without
-                    # them: widen it instead of failing at `prepare`
-                    tile = {L.TILE_128x64: L.TILE_128x128, L.TILE_64x64: L.TILE_64x128, L.TILE_256x64: L.TILE_256x128}.get(tile, tile)
-                    if pipeline == 7:
-                        pipeline = 3
             else:
                 tile, sk = choose_tile(m, w.n, w.kp, w.geglu or w.tile128, t_col0 if out_t is not None else 0)
                 split_k = sk if split_k is None else split_k
@@ -284,7 +279,7 @@ class HipOps:
         if pipeline == 7 and (self.no_halo or out_scale_dev is not None or
                               not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out,
                                                      chanstat_out, ln_part)):
-            # a tuning-table entry found for another call of the same shape: this one needs the general epilogue
+            # (safety net: a plain-class entry shared by a call the halo form cannot take -- e.g. SiLU after the residual)
             pipeline = 3
             tile = {L.TILE_256x128: L.TILE_128x128, L.TILE_256x64: L.TILE_128x64}.get(tile, tile)
             inkernel = True
@@ -320,6 +315,12 @@ class HipOps:
         d.batch, d.t_img = g.batch, t_img
         d.tile, d.split_k = tile, split_k
         d.pipeline = self.default_pipeline if pipeline is None else pipeline
+        if d.pipeline == 8:
+            # persistent stream-K form (csrc/conv_streamk.hip): split_k = the most parts one tile's K range may be shared among
+            # (the workspace holds that many fp32 slabs); parts meet through arrival tickets, never through the reducer kernel
+            inkernel = True
+            if w.geglu:
+                split_k = d.split_k = 1  # (the GEGLU epilogue reads the accumulator tile itself: whole tiles only)
         if split_k > 1:
             ws = workspace if workspace is not None else self.workspace("splitk", split_k * m * w.n * 4)
             d.workspace = self._p(ws)
@@ -336,17 +337,41 @@ class HipOps:
         return (plain and not w.geglu and g.ksize == 3 and g.stride == 1 and w.cin % 64 == 0 and (c1 or 0) % 64 == 0 and
                 w.n % 8 == 0 and out_scale == 1.0 and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_SILU, L.ACT_RELU | L.ACT_POST))
 
+    # Epilogue classes of the tuning key.  By scripts/wg_timeline.py the epilogue kind moves a workgroup's fixed cost from 1.0
+    # to 4.6 us, and some classes exclude kernel forms (statistics outputs: no reducer kernel; softmax: 128-column tiles;
+    # anything but the plain one: no halo-patch form) -- layers of one (M, N, K) with different epilogues get their own entry.
+    EPI_PLAIN, EPI_LN, EPI_ROWSTAT, EPI_LN_ROWSTAT, EPI_SOFTMAX, EPI_GENERAL, EPI_PLAIN_ACT = range(7)
+
+    @classmethod
+    def epilogue_class(cls, w: PackedConv, rowstat_out=None, ln_part=None, chanstat_out=None, residual2=None, out2=None,
+                       out_scale_dev=None, out_scale=1.0, act=0) -> int:
+        if w.tile128 or (act & 0xff) == L.ACT_SOFTMAX:
+            return cls.EPI_SOFTMAX
+        if chanstat_out is not None or residual2 is not None or out2 is not None or out_scale_dev is not None or out_scale != 1.0:
+            return cls.EPI_GENERAL
+        if ln_part is not None:
+            return cls.EPI_LN_ROWSTAT if rowstat_out is not None else cls.EPI_LN
+        if rowstat_out is not None:
+            return cls.EPI_ROWSTAT
+        # (activations other than none / ReLU / SiLU / ReLU-after-residual leave the halo-patch form: quick-GELU of CLIP)
+        return cls.EPI_PLAIN if (act & 0xff) in (L.ACT_NONE, L.ACT_RELU, L.ACT_SILU, L.ACT_GEGLU) else cls.EPI_PLAIN_ACT
+
     @staticmethod
-    def conv_key(g: Geom, w: PackedConv, t_col0: int = 0, rowstat: bool = False):
-        # `rowstat` = any fused statistics output (restricts split-K to the in-kernel reduction)
-        return (g.m, w.n, w.kp, g.ksize, g.stride, g.hi != g.hs or g.wi != g.ws, w.geglu, t_col0, rowstat)
+    def conv_key(g: Geom, w: PackedConv, t_col0: int = 0, epi: int = 0):
+        return (g.m, w.n, w.kp, g.ksize, g.stride, g.hi != g.hs or g.wi != g.ws, w.geglu, t_col0, int(epi))
+
+    def conv_key_of(self, g: Geom, w: PackedConv, kwargs: dict):
+        """the tuning key of a recorded conv call (args[2], args[3], its keyword arguments)"""
+        return self.conv_key(g, w, kwargs.get("t_col0", 0), self.epilogue_class(
+            w, kwargs.get("rowstat_out"), kwargs.get("ln_part"), kwargs.get("chanstat_out"), kwargs.get("residual2"), kwargs.get("out2"),
+            kwargs.get("out_scale_dev"), kwargs.get("out_scale", 1.0), kwargs.get("act", L.ACT_NONE)))
 
     def tune_conv(self, args, kwargs, reps: int = 12):
         """Time every (tile, split_k, reduction form) candidate for one recorded conv call on the GPU and
         remember the fastest in tile_override.  Returns (best, table)."""
         g, w = args[2], args[3]
         t_col0 = kwargs.get("t_col0", 0)
-        key = self.conv_key(g, w, t_col0, kwargs.get("rowstat_out") is not None or kwargs.get("chanstat_out") is not None)
+        key = self.conv_key_of(g, w, kwargs)
         kt = w.kp // 64
         wide = w.geglu or w.tile128  # epilogues that need whole 128-column tiles and no split-K
         tiles = [L.TILE_128x128, L.TILE_64x128] if wide else [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64]
@@ -385,6 +410,26 @@ class HipOps:
                     if kwargs.get("rowstat_out") is None and kwargs.get("chanstat_out") is None and not w.tile128:
                         cands.append((t, sp, False, pl))
                     cands.append((t, sp, True, pl))
+        # persistent stream-K form (pipeline 8; buffer-load operand path: Cin % 64 == 0 per source, no resize): the launch's
+        # (tile, K step) units spread evenly over as many workgroups as the chip holds; `sp` = the most parts a tile may be
+        # shared among (1 = whole tiles only: a persistent data-parallel walk)
+        c1_ = kwargs.get("c1", 0) or 0
+        # Measured on MI355X (scripts/streamk_bench.py, 24 layer shapes at 1 and 5 frames per launch): 8-25 % SLOWER than the best
+        # tiled form on every one of them -- these layers run at the LDS-capacity x latency bound of the L2 -> LDS fill, which a
+        # better spread of the same tiles does not move.  So: a parity-tested form, a tuner candidate only
+        # on request (VSD_TUNE_STREAMK=1).
+        sk_ok = (w.cin % 64 == 0 and c1_ % 64 == 0 and (g.hi, g.wi) == (g.hs, g.ws) and bool(_os.environ.get("VSD_TUNE_STREAMK")) and
+                 (kwargs.get("rowstat_out") is None or w.n % 64 == 0))
+        if sk_ok:
+            for t in tiles:
+                if t == L.TILE_256x128:
+                    continue
+                if kwargs.get("out_t") is not None and t_col0 % L.TILE_DIMS[t][1]:
+                    continue
+                for sp in ((1,) if w.geglu else (1, 2, 3, 4, 6)):
+                    if sp > 1 and sp - 1 > kt:
+                        break
+                    cands.append((t, sp, True, 8))
         if halo_ok:  # 16x16 patches (8 waves): half the weight traffic of the 8x16 patch
             for t in (L.TILE_256x128, L.TILE_256x64):
                 bn = L.TILE_DIMS[t][1]
@@ -459,6 +504,8 @@ class HipOps:
         n = 0
         for k, v in d.get("table", []):
             key = tuple(bool(x) if isinstance(x, bool) else x for x in k)
+            if isinstance(key[-1], bool):
+                continue  # a round-3 table (last field: "has a statistics output"): its entries name no epilogue class
             if key not in self.tile_override:
                 self.tile_override[key] = (int(v[0]), int(v[1]), bool(v[2]), int(v[3]))
                 n += 1

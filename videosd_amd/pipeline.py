@@ -86,6 +86,7 @@ class VideoSDPipeline:
         self._plans = OrderedDict()
         self.max_plans = int(kwargs.get("max_plans", 3))
         self._outstanding = []  # engines with a submitted, not yet collected launch
+        self._lanes_busy = []   # ... and the lane each of them runs on
         self._host_ms = {"crop_resize": [], "upload_enqueue": [], "wait_download": [], "to_pil": [], "gpu": [], "prepare": [], "update_options": [],
                          "prompt": []}
 
@@ -342,10 +343,20 @@ class VideoSDPipeline:
         np.random.seed(seed)  # kept for parity with videopipeline.py:112 (nothing downstream consumes it)
         t0 = time.perf_counter()
         frames = np.stack([np.asarray(im if im.mode == "RGB" else im.convert("RGB"), dtype=np.uint8) for im in imgs])
-        eng.submit_u8(frames[0] if len(imgs) == 1 else frames)
+        eng.submit_u8(frames[0] if len(imgs) == 1 else frames, overlap=self._overlap_now(lane))
         self._outstanding.append(eng)
+        self._lanes_busy.append(int(lane))
         self._note("upload_enqueue", t0)
         return (eng, len(imgs))
+
+    def _overlap_now(self, lane: int) -> bool:
+        """ONE policy for every caller (bench.py's engine legs follow the same rule): a launch runs its ControlNet encoder on
+        the lane's side stream when it will have a command-processor pipe to itself -- at most two launches in flight, all on
+        lanes 0 / 1 (lane l's side stream is lane l + 2's own stream).  A lone frame gains ~4 ms from it; with three or four
+        lanes busy the side streams ARE the other lanes' streams and the launch stays on its own."""
+        if os.environ.get("VSD_OVERLAP_CN") is not None:
+            return os.environ.get("VSD_OVERLAP_CN") == "1"
+        return int(lane) < 2 and all(l < 2 for l in self._lanes_busy) and len(self._lanes_busy) < 2
 
     def collect_batch(self, handle):
         eng, n = handle
@@ -354,7 +365,9 @@ class VideoSDPipeline:
             out = eng.collect_u8()
         finally:
             if eng in self._outstanding:
-                self._outstanding.remove(eng)
+                i = self._outstanding.index(eng)
+                self._outstanding.pop(i)
+                self._lanes_busy.pop(i)
         self._note("wait_download", t0)
         if getattr(eng, "last_gpu_ms", None) is not None:
             self._host_ms["gpu"].append(eng.last_gpu_ms)
@@ -427,9 +440,7 @@ class VideoSDPipeline:
                     break
                 if not self._plan_busy(self._plans[pk]):
                     for e in self._plans.pop(pk)["engines"].values():
-                        if e.graph is not None:
-                            e.ops.seq_destroy(e.graph)
-                            e.graph = None
+                        e._destroy_graphs()
             eng = self.model.make_slot(share_plan=False, lane=lane)  # its own schedule constants: the other programs keep running
             plan = self._plans[plan_key] = {"root": eng, "opts": opts, "engines": {}}
         else:
@@ -438,13 +449,8 @@ class VideoSDPipeline:
             eng.use_prompt(prompt)
         if self.is_xl:  # micro-conditioning: original size = target size = the frame size, no crop
             eng.set_added_cond(self.encode_pooled(prompt_text if prompt_text is not None else ""), (height, width, 0, 0, height, width))
-        # The ControlNet encoder beside the UNet encoder (a side stream of the lane: engine.Engine._capture).  ONE policy with
-        # bench.py: on whenever the lanes leave every lane a command-processor pipe for its side stream (at most two lanes),
-        # whatever the frames per launch -- a single frame gains ~4 ms, a coalesced launch beside another lane's ~4 %.  (Rounds
-        # 1-3 captured the two encoders as parallel branches of ONE graph and had to switch them off for coalesced launches:
-        # two such graphs in flight serialise on this runtime, DESIGN.md section 3 "launches in flight".)
-        if os.environ.get("VSD_OVERLAP_CN") is None:
-            eng.overlap_controlnet = self.max_lanes <= 2
+        # (every engine is captured both ways -- ControlNet encoder on the lane's side stream / everything on the lane's own
+        #  stream; `submit_batch` picks per launch, see `_overlap_now`)
         eng.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch, ref_mode=use_ref,
                     autotune=self.tuning_mode != "table")
         eng._ref_epoch = None
