@@ -540,7 +540,9 @@ def run_rank(args):
 
     # ---- dominant kernel (implicit-GEMM conv) against the MFMA roofline: HIP events around every launch of
     #      one eager pass of the same program on the same stream
+    eng.overlap_controlnet = False  # (one stream: a launch's event bracket must not include another stream's kernel beside it)
     eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, use_graph=False, batch=B)
+    eng.overlap_controlnet = True
     one_frame(0, [eng])
     ops.synchronize()
     ops.profile_begin()

@@ -274,7 +274,7 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
             conn.send((r, False, (type(e).__name__, str(e))))
 
     def finish_oldest():
-        group_, handle, t_in, _kw = inflight.pop(0)
+        group_, handle, t_in, _kw, _lane = inflight.pop(0)
         try:
             outs = pipe.collect_batch(handle)
             dt = time.time() - t_in
@@ -428,14 +428,17 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
                 # prompt constants per lane); only a pipeline that says so (or cannot say) makes it wait
                 if not hasattr(pipe, "needs_idle") or pipe.needs_idle(**kwargs):
                     drain()
+            # the LOWEST free lane (not round-robin): a lone frame always lands on lane 0 and one beside it on lane 1 -- the lanes
+            # whose launches may use a side stream for the ControlNet encoder (VideoSDPipeline._overlap_now)
+            busy = {e[4] for e in inflight}
+            lane = next(l for l in range(lanes) if l not in busy)
             try:
                 handle = pipe.submit_batch([a[0] for _, a, _s in group_], lane=lane, **kwargs)
             except BaseException as e:
                 drain()
                 fail(group_, e)
                 continue
-            lane = (lane + 1) % lanes
-            inflight.append((group_, handle, t_in, kwargs))
+            inflight.append((group_, handle, t_in, kwargs, lane))
             if len(inflight) >= lanes:  # every lane has a launch on the GPU: hand back the oldest before taking more
                 finish_oldest()
             continue
