@@ -397,494 +397,6 @@ __device__ __forceinline__ void block_to_tile(const ConvParams& p, int bid, int&
   grp = p.order ? sec : prim;
 }
 
-// ---------------------------------------------------------------- tile epilogue (shared by the one-tile-per-workgroup kernel
-// and the persistent stream-K kernel): residual / bias prefetch, accumulators -> LDS (fp32) -> row-contiguous 8-wide chunks,
-// the split-K / stream-K hand-over (part `part` of `nparts` of this tile's K range: fp32 slab + arrival ticket, the last
-// arriver sums the slabs in part order), then the layer's epilogue.  `smem` is the workgroup's LDS block: the accumulator
-// tile uses its first BM * (BN + 4) * 4 bytes, the fused LayerNorm's per-row (mean, rstd) live at `rowms`.
-template <int BM, int BN>
-struct TileGeom {
-  static constexpr int WM = 2, WN = 2;
-  static constexpr int TM = BM / WM, TN = BN / WN;
-  static constexpr int FM = TM / 16, FN = TN / 16;
-  static constexpr int BNP = BN + 4;
-};
-
-template <int BM, int BN>
-__device__ __forceinline__ void conv_tile_epilogue(const ConvParams& p, unsigned char* smem, float* rowms,
-                                                   f32x4 (&acc)[TileGeom<BM, BN>::FM][TileGeom<BM, BN>::FN], const int tile_m,
-                                                   const int tile_n, const int part, const int nparts WGTL_EPI_PARAM) {
-  constexpr int TM = TileGeom<BM, BN>::TM, TN = TileGeom<BM, BN>::TN, FM = TileGeom<BM, BN>::FM, FN = TileGeom<BM, BN>::FN;
-  constexpr int BNP = TileGeom<BM, BN>::BNP;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  // ---- residual prefetch.  The epilogue below walks this thread's 8-wide output chunks one after the other; loading
-  // each chunk's residual inside that walk exposes one full memory round trip PER CHUNK (measured: 7.4k of the 17k
-  // cycles a 128x64 workgroup of a K=320 layer lives).  The addresses do not depend on the GEMM, so the loads are
-  // issued here, before the accumulator transpose, and land while it and its barrier run.
-  constexpr int CHP = BN / 8;
-  constexpr int NITP = BM * CHP / 256;
-  constexpr int NPRE = NITP <= 8 ? NITP : 8;
-  half8 rpre[NPRE];
-  const bool use_pre = p.residual != nullptr && nparts == 1 && (p.act & 0xff) != VSD_ACT_GEGLU &&
-                       (p.act & 0xff) != VSD_ACT_SOFTMAX && !(p.out_t && n0 >= p.t_col0);
-  // bias + rowvec of this thread's 8 columns (the same columns in every chunk it handles: 256 % CHP == 0)
-  float brv[8];
-  const int pre_n = n0 + (tid % CHP) * 8;
-  const bool use_brv = pre_n + 8 <= p.N && (p.act & 0xff) != VSD_ACT_GEGLU && (p.act & 0xff) != VSD_ACT_SOFTMAX &&
-                       !(p.out_t && n0 >= p.t_col0);
-  // Issue order: the residual chunks first (they come from HBM / the Infinity Cache: the longest latency of the epilogue),
-  // then bias and time vector as RAW halfs -- converting them here would make the wave wait for them before the
-  // residual loads are even issued (vmcnt retires in order; measured: one L2 round trip per workgroup, serialised in
-  // front of the residual's).  They are converted after the accumulator transpose and its barrier.
-  if (use_pre) {
-#pragma unroll
-    for (int j = 0; j < NPRE; ++j) {
-      const int q = tid + j * 256;
-      const int r = q / CHP, c8 = (q - r * CHP) * 8;
-      const int m = m0 + r, n = n0 + c8;
-      const bool ok = m < p.M && n + 8 <= p.N;  // (otherwise an in-range dummy address; the value is not used)
-      rpre[j] = *reinterpret_cast<const half8*>(p.residual + (ok ? (size_t)m * p.ldr + n : 0));
-    }
-  }
-  half8 braw = (half8){0, 0, 0, 0, 0, 0, 0, 0}, rvraw = braw;
-  f32x4 lns0 = (f32x4){0.f, 0.f, 0.f, 0.f}, lns1 = lns0, lnt0 = lns0, lnt1 = lns0;  // fused input LayerNorm: s / t of these columns
-  if (use_brv) {
-    if (p.bias) braw = *reinterpret_cast<const half8*>(p.bias + pre_n);
-    if (p.rowvec) rvraw = *reinterpret_cast<const half8*>(p.rowvec + pre_n);
-    if (p.ln_part) {
-      lns0 = *reinterpret_cast<const f32x4*>(p.ln_s + pre_n);
-      lns1 = *reinterpret_cast<const f32x4*>(p.ln_s + pre_n + 4);
-      lnt0 = *reinterpret_cast<const f32x4*>(p.ln_t + pre_n);
-      lnt1 = *reinterpret_cast<const f32x4*>(p.ln_t + pre_n + 4);
-    }
-  }
-
-  // ---- epilogue: accumulators -> LDS (fp32) -> row-contiguous 8-wide chunks
-  float* Cs = reinterpret_cast<float*>(smem);
-
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      int col = wn * TN + j * 16 + fr;
-      int row = wm * TM + i * 16 + fq * 4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Cs[(row + r) * BNP + col] = acc[i][j][r];
-    }
-  __syncthreads();
-  WGTL_EPI_MARK(a)
-#pragma unroll
-  for (int i = 0; i < 8; ++i) brv[i] = (float)braw[i] + (float)rvraw[i];
-  WGTL_EPI_MARK(b)
-
-  bool from_slabs = false;
-  if (nparts > 1) {
-    constexpr int CH = BN / 8;
-    float* slab = p.ws_partial + (size_t)part * p.M * p.N;
-    // With the in-kernel reduction the slabs are stored WRITE-THROUGH (sc1): they are then visible to the
-    // reducing workgroup on any XCD without an L2 write-back fence on every producer (cdna guide, G16 R1).
-    const bool wt = p.counters != nullptr;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        slab, 0, (int)min((size_t)p.M * p.N * sizeof(float), (size_t)0x7fffffff), 0x00020000);
-    for (int q = tid; q < BM * CH; q += 256) {
-      int r = q / CH, c8 = (q - r * CH) * 8;
-      int m = m0 + r, n = n0 + c8;
-      if (m >= p.M || n >= p.N) continue;
-      const float* s = Cs + r * BNP + c8;
-      float* d = slab + (size_t)m * p.N + n;
-      if (n + 8 <= p.N) {
-        if (wt) {
-          int off = (int)(((size_t)m * p.N + n) * sizeof(float));
-          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(s), rsrc, off, 0, 16);
-          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(s + 4), rsrc, off + 16, 0, 16);
-        } else {
-          *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(s);
-          *reinterpret_cast<f32x4*>(d + 4) = *reinterpret_cast<const f32x4*>(s + 4);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (n + i < p.N) {
-            if (wt) __hip_atomic_store(d + i, s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else d[i] = s[i];
-          }
-      }
-    }
-    if (!p.counters) return;  // two-kernel form: splitk_reduce_kernel finishes the job
-    // In-launch reduction: the LAST workgroup to arrive at this tile sums the slabs and runs the epilogue.
-    // Write-through slab stores, every wave drains them (vmcnt(0)), barrier, one relaxed agent-scope ticket;
-    // agent-scope acquire on the reducer
-    // (cdna guide, "In-launch split-K reduction").  Placement independent; the counter is left at zero.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* lastflag = reinterpret_cast<int*>(smem);
-    if (tid == 0) {
-      int* cnt = p.counters + tile_n * p.tiles_m + tile_m;
-      int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int last = ticket == nparts - 1;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      *lastflag = last;
-    }
-    __syncthreads();
-    if (!*lastflag) return;
-    from_slabs = true;
-  }
-
-  if ((p.act & 0xff) == VSD_ACT_GEGLU) {
-    constexpr int CH = BN / 16;  // chunks over the hidden half
-    const int no = p.N >> 1;
-    for (int q = tid; q < BM * CH; q += 256) {
-      int r = q / CH, c8 = (q - r * CH) * 8;
-      int m = m0 + r;
-      if (m >= p.M) continue;
-      const float* s = Cs + r * BNP + c8;
-      half8 o;
-      if (p.ln_part) {
-        const float mean = rowms[2 * r], rstd = rowms[2 * r + 1];
-        const int nh = n0 + c8, ng = n0 + BN / 2 + c8;
-        float hv[8], gv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          hv[i] = s[i];
-          gv[i] = s[BN / 2 + i];
-        }
-        ln_transform8(p, nh, mean, rstd, hv);
-        ln_transform8(p, ng, mean, rstd, gv);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (half_t)(hv[i] * gelu_erf_f(gv[i]));
-      } else {
-        half8 bh = *reinterpret_cast<const half8*>(p.bias + n0 + c8);
-        half8 bg = *reinterpret_cast<const half8*>(p.bias + n0 + BN / 2 + c8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float h = s[i] + (float)bh[i];
-          float g = s[BN / 2 + i] + (float)bg[i];
-          o[i] = (half_t)(h * gelu_erf_f(g));
-        }
-      }
-      int n = (n0 >> 1) + c8;
-      if (n < no) *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
-    }
-    return;
-  }
-
-  if ((p.act & 0xff) == VSD_ACT_SOFTMAX) {
-    // Row softmax inside each 128-column tile, over its first p.softmax_cols columns (the others become 0): the scores of
-    // ONE attention head against a short, fixed key set (the 77 text tokens) are a GEMM tile when the key projections are
-    // folded into the query weights (packing.pack_cross_attention) -- the epilogue finishes the attention probabilities.
-    // The 16 lanes that hold one row's 8-column chunks are consecutive: 4 xor-shuffles per reduction.
-    if constexpr (BN == 128) {
-      constexpr int CH = BN / 8;  // 16
-      constexpr int NIT = BM * CH / 256;
-      const int nv = p.softmax_cols;
-#pragma unroll
-      for (int j = 0; j < NIT; ++j) {
-        const int q = tid + j * 256;
-        const int r = q / CH, c8 = (q - r * CH) * 8;
-        const int m = m0 + r, n = n0 + c8;
-        float v[8];
-        load_chunk8(p, Cs, BNP, from_slabs, nparts, r, c8, m, n, v);  // (split-K: the last arriver sums the slabs, then normalises)
-        if (p.ln_part) ln_transform8(p, n, rowms[2 * r], rowms[2 * r + 1], v);
-        else if (p.bias) {
-          half8 b = *reinterpret_cast<const half8*>(p.bias + n);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] += (float)b[i];
-        }
-        float mx = -3.0e38f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          v[i] = (c8 + i < nv) ? v[i] * 1.4426950408889634f : -3.0e38f;
-          mx = fmaxf(mx, v[i]);
-        }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          v[i] = (c8 + i < nv) ? __builtin_amdgcn_exp2f(v[i] - mx) : 0.f;
-          sum += v[i];
-        }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
-        const float inv = 1.0f / sum;
-        half8 o8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o8[i] = (half_t)(v[i] * inv);
-        if (m < p.M) *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o8;
-      }
-    }
-    return;
-  }
-
-  const bool transposed_tile = p.out_t && n0 >= p.t_col0;
-  const bool use_brv_all = (p.act & 0xff) != VSD_ACT_GEGLU && (p.act & 0xff) != VSD_ACT_SOFTMAX;  // (brv / lns hold zeros for a thread whose columns lie beyond N: it stores nothing)
-  if (transposed_tile) {
-    // V^T tiles (the attention V operand is produced transposed: out_t[n - t_col0][column of row m]).  A thread owns ONE
-    // output column n and 8 consecutive rows m: the 8 values are one 16-byte piece of an out_t row.  The first form of
-    // this path (a thread = one row, eight 2-byte stores) issued 8x the store instructions of an ordinary tile: the V
-    // third of the qkv projection took as long as the Q and K thirds together.  Lane -> (column = lane % 16, row chunk =
-    // lane / 16): a wave's store instruction writes 16 out_t rows x 64 contiguous bytes; the LDS reads of the fp32 tile
-    // (column-wise: a row chunk is 8 * BNP floats = 0 mod 32 banks away) are 2-way conflicted ds_read_b32.
-    constexpr int MCH = BM / 8;  // row chunks of the tile
-    const int act_t = (p.act & VSD_ACT_POST) ? VSD_ACT_NONE : (p.act & 0xff);  // (as epilogue_store8: no residual, no post-activation here)
-    const float sc_t = p.out_scale_dev ? *p.out_scale_dev : p.out_scale;
-    const bool vec_ok = (p.hw_out & 7) == 0 && (p.t_img & 7) == 0 && (p.ldt & 7) == 0 && ((size_t)p.out_t & 15) == 0;
-    for (int q = tid; q < BN * MCH; q += 256) {
-      const int cl = q & 15, rest = q >> 4;
-      const int rc = rest % MCH, cg = rest / MCH;
-      const int c = cg * 16 + cl, r8 = rc * 8;
-      const int n = n0 + c, m = m0 + r8;
-      if (n >= p.N || m >= p.M) continue;
-      float v[8];
-      if (from_slabs) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float a = 0.f;
-          if (m + i < p.M)
-            for (int k = 0; k < nparts; ++k) a += p.ws_partial[((size_t)k * p.M + m + i) * p.N + n];
-          v[i] = a;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = Cs[(r8 + i) * BNP + c];
-      }
-      if (p.ln_part) {
-        const float s_n = p.ln_s[n], t_n = p.ln_t[n];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = rowms[2 * (r8 + i) + 1] * (v[i] - rowms[2 * (r8 + i)] * s_n) + t_n;
-      }
-      float add = 0.f;
-      if (p.bias) add += (float)p.bias[n];
-      if (p.rowvec) add += (float)p.rowvec[n];
-      half8 o;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float x = v[i] + add;
-        if (act_t == VSD_ACT_RELU) x = fmaxf(x, 0.f);
-        else if (act_t == VSD_ACT_SILU) x = silu_f(x);
-        else if (act_t == VSD_ACT_QUICKGELU) x = quick_gelu_f(x);
-        o[i] = (half_t)(x * sc_t);
-      }
-      half_t* row = p.out_t + (size_t)(n - p.t_col0) * p.ldt;
-      int b = 0, mm = m;
-      if (p.batch > 1) {
-        b = fdiv(m, p.fd_hw_out);
-        mm = m - b * p.hw_out;
-      }
-      if (vec_ok && m + 8 <= p.M) {  // the 8 rows lie in one image (hw_out % 8 == 0) and the piece is 16-byte aligned
-        *reinterpret_cast<half8*>(row + (size_t)b * p.t_img + mm) = o;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int mi = m + i;
-          if (mi < p.M) {
-            int col = mi;
-            if (p.batch > 1) {
-              const int bi = fdiv(mi, p.fd_hw_out);
-              col = bi * p.t_img + (mi - bi * p.hw_out);
-            }
-            row[col] = o[i];
-          }
-        }
-      }
-    }
-  } else if (!p.chanstat_out && !p.out2 && !p.residual2 && !from_slabs && (p.N & 7) == 0 && NITP <= NPRE &&
-             (!p.residual || use_pre) && use_brv_all &&
-             ((!p.ln_part && !p.rowstat_out) || (p.act & 0xff) == VSD_ACT_NONE)) {
-    // ---- the epilogues the networks actually run, each as its own straight-line walk: bias / time vector, one
-    // activation, a scale, one residual; and (activation none) the fused LayerNorm of the input and / or the row
-    // statistics of the output.  The general loop below tests ~25 uniform flags per 8-wide chunk, inlines every
-    // activation twice and falls back to scalar code for ragged N (15k instructions, 1.3k branches per kernel): by
-    // scripts/wg_timeline.py a 64x128 workgroup spent 4.6 us in it against 1.0 us here -- 40 % of a short-K workgroup's life.
-    constexpr int CH = BN / 8;
-    const float sc = p.out_scale_dev ? *p.out_scale_dev : p.out_scale;  // (x * 1.0f is exact: no separate unscaled form)
-    const float lns[8] = {lns0[0], lns0[1], lns0[2], lns0[3], lns1[0], lns1[1], lns1[2], lns1[3]};
-    const float lnt[8] = {lnt0[0], lnt0[1], lnt0[2], lnt0[3], lnt1[0], lnt1[1], lnt1[2], lnt1[3]};
-    auto walk = [&](auto act_tag, auto ln_tag, auto rs_tag) __attribute__((always_inline)) {
-      constexpr int ACT = decltype(act_tag)::value;  // 0 none, 1 relu, 2 silu, 3 relu AFTER the residual, 4 quick-gelu
-      constexpr bool LN = decltype(ln_tag)::value, RS = decltype(rs_tag)::value;
-#pragma unroll
-      for (int j = 0; j < NITP; ++j) {
-        const int q = tid + j * 256;
-        const int r = q / CH, c8 = (q - r * CH) * 8;
-        const int m = m0 + r, n = n0 + c8;
-        const bool valid = m < p.M && n < p.N;
-        float rs = 0.f, rq = 0.f;
-        if (valid) {
-          f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8);
-          f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8 + 4);
-          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          float mean = 0.f, rstd = 0.f;
-          if (LN) {
-            mean = rowms[2 * r];
-            rstd = rowms[2 * r + 1];
-          }
-          half8 o;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float x = v[i];
-            if (LN) x = rstd * (x - mean * lns[i]) + lnt[i];
-            x += brv[i];
-            if (ACT == 1) x = fmaxf(x, 0.f);
-            if (ACT == 2) x = silu_f(x);
-            if (ACT == 4) x = quick_gelu_f(x);
-            x *= sc;
-            if (p.residual) x += (float)rpre[j < NPRE ? j : 0][i];
-            if (ACT == 3) x = fmaxf(x, 0.f);
-            o[i] = (half_t)x;
-            if (RS) {  // statistics of the STORED (rounded) values
-              const float f = (float)o[i];
-              rs += f;
-              rq += f * f;
-            }
-          }
-          *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
-        }
-        if (RS) {
-          // the 8 lanes of one (row, 64-column group) are consecutive: fold their sums and let the first write
-#pragma unroll
-          for (int o = 1; o < 8; o <<= 1) {
-            rs += __shfl_xor(rs, o);
-            rq += __shfl_xor(rq, o);
-          }
-          if ((tid & 7) == 0 && valid) {
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<f32x2*>(p.rowstat_out + ((size_t)m * (p.N >> 6) + (n >> 6)) * 2) = (f32x2){rs, rq};
-          }
-        }
-      }
-    };
-    const int act = p.act & 0xff;
-    const bool post = (p.act & VSD_ACT_POST) != 0;
-    using T = std::true_type;
-    using F = std::false_type;
-    if (act == VSD_ACT_NONE) {
-      if (p.ln_part && p.rowstat_out) walk(std::integral_constant<int, 0>{}, T{}, T{});
-      else if (p.ln_part) walk(std::integral_constant<int, 0>{}, T{}, F{});
-      else if (p.rowstat_out) walk(std::integral_constant<int, 0>{}, F{}, T{});
-      else walk(std::integral_constant<int, 0>{}, F{}, F{});
-    } else if (act == VSD_ACT_RELU && !post) walk(std::integral_constant<int, 1>{}, F{}, F{});
-    else if (act == VSD_ACT_SILU && !post) walk(std::integral_constant<int, 2>{}, F{}, F{});
-    else if (act == VSD_ACT_RELU && post) walk(std::integral_constant<int, 3>{}, F{}, F{});
-    else if (act == VSD_ACT_QUICKGELU && !post) walk(std::integral_constant<int, 4>{}, F{}, F{});
-    else {  // (activation after the residual other than ReLU: not used by the networks; keep it correct)
-#pragma unroll
-      for (int j = 0; j < NITP; ++j) {
-        const int q = tid + j * 256;
-        const int r = q / CH, c8 = (q - r * CH) * 8;
-        const int m = m0 + r, n = n0 + c8;
-        if (m < p.M && n < p.N) {
-          float v[8], rs = 0.f, rq = 0.f;
-          load_chunk8(p, Cs, BNP, false, 1, r, c8, m, n, v);
-          epilogue_store8(p, m, n, v, rs, rq);
-        }
-      }
-    }
-  } else {
-    constexpr int CH = BN / 8;
-    const f32x4 brv_lo = (f32x4){brv[0], brv[1], brv[2], brv[3]}, brv_hi = (f32x4){brv[4], brv[5], brv[6], brv[7]};
-    float cs[8], cq[8];  // this thread's 8 columns (fixed: c8 = (tid % CH) * 8), summed over its rows
-#pragma unroll
-    for (int i = 0; i < 8; ++i) cs[i] = cq[i] = 0.f;
-#pragma unroll
-    for (int j = 0; j < NITP; ++j) {  // BM*CH is a multiple of 256: every lane runs every iteration
-      const int q = tid + j * 256;
-      int r = q / CH, c8 = (q - r * CH) * 8;
-      int m = m0 + r, n = n0 + c8;
-      const bool valid = m < p.M && n < p.N;
-      float rs = 0.f, rq = 0.f;
-      if (valid) {
-        float v[8];
-        load_chunk8(p, Cs, BNP, from_slabs, nparts, r, c8, m, n, v);
-        if (p.ln_part) ln_transform8(p, n, rowms[2 * r], rowms[2 * r + 1], v);
-        epilogue_store8(p, m, n, v, rs, rq, use_pre && j < NPRE, rpre[j < NPRE ? j : 0], use_brv, brv_lo, brv_hi);
-        if (p.chanstat_out) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            cs[i] += v[i];
-            cq[i] += v[i] * v[i];
-          }
-        }
-      }
-      if (p.rowstat_out) {
-        // the 8 lanes of one (row, 64-column group) are consecutive: fold their sums and let the first write
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-          rs += __shfl_xor(rs, o);
-          rq += __shfl_xor(rq, o);
-        }
-        if ((tid & 7) == 0 && valid) {
-          float* dst = p.rowstat_out + ((size_t)m * (p.N >> 6) + (n >> 6)) * 2;
-          dst[0] = rs;
-          dst[1] = rq;
-        }
-      }
-    }
-    if (p.chanstat_out) {
-      // ---- fused GroupNorm statistics of the tensor just written.  (1) fold this tile's rows per column in a
-      // fixed order through LDS; (2) store the tile's column partials write-through; (3) ticket: the last of the
-      // tiles_m workgroups of this column block adds the partials in tile order and publishes chan[N][2].
-      // Deterministic; placement independent (agent-scope acquire on the reducer, cdna guide G16).
-      constexpr int RG = 256 / CH;
-      __syncthreads();
-      float* red = reinterpret_cast<float*>(smem);  // [RG][BN][2]
-      {
-        const int rg = tid / CH, c8 = (tid - rg * CH) * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          red[(rg * BN + c8 + i) * 2] = cs[i];
-          red[(rg * BN + c8 + i) * 2 + 1] = cq[i];
-        }
-      }
-      __syncthreads();
-      if (tid < BN && n0 + tid < p.N) {
-        float S = 0.f, Q = 0.f;
-        for (int g = 0; g < RG; ++g) {
-          S += red[(g * BN + tid) * 2];
-          Q += red[(g * BN + tid) * 2 + 1];
-        }
-        float* dst = p.chanstat_part + ((size_t)tile_m * p.N + n0 + tid) * 2;
-        __hip_atomic_store(dst, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, Q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      int* lastflag = reinterpret_cast<int*>(smem);
-      if (tid == 0) {
-        int* cnt = p.chan_counters + tile_n;
-        int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int last = ticket == p.tiles_m - 1;
-        if (last) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *lastflag = last;
-      }
-      __syncthreads();
-      if (*lastflag && tid < BN && n0 + tid < p.N) {
-        float S = 0.f, Q = 0.f;
-        const float* src = p.chanstat_part + ((size_t)(n0 + tid)) * 2;
-        for (int tm = 0; tm < p.tiles_m; ++tm) {
-          S += src[(size_t)tm * p.N * 2];
-          Q += src[(size_t)tm * p.N * 2 + 1];
-        }
-        p.chanstat_out[(n0 + tid) * 2] = S;
-        p.chanstat_out[(n0 + tid) * 2 + 1] = Q;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------- main kernel
 // STAGES == 0: register-staged double buffer (global -> VGPR -> LDS), one tile of prefetch.
 // STAGES >= 3: direct-to-LDS ring (global_load_lds, 16 B per lane) with STAGES-1 tiles in flight behind counted
@@ -1397,7 +909,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   }
 
   WGTL_LOOP()
-  conv_tile_epilogue<BM, BN>(p, smem, rowms, acc, tile_m, tile_n, split, p.split_k WGTL_EPI_ARG);
+#define EPI_PART split
+#define EPI_NPARTS p.split_k
+#define EPI_EXIT { WGTL_END(0) return; }
+#include "conv_epilogue.inc"
+#undef EPI_PART
+#undef EPI_NPARTS
+#undef EPI_EXIT
   CPROBE(6)
   CPROBE_OUT()
   WGTL_END(0)

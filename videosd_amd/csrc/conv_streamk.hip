@@ -23,6 +23,7 @@ namespace {
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_streamk_kernel(const ConvParams p) {
   prefetch_kernargs();
+  WGTL_START()
   constexpr int WM = 2, WN = 2;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / 16, FN = TN / 16;
@@ -101,9 +102,11 @@ __global__ __launch_bounds__(256) void conv_streamk_kernel(const ConvParams p) {
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;                                 \
         apix[i] = b * p.img_in + (iy0 + p.pad) * p.ws + (ix0 + p.pad);                                       \
         unsigned mk = 0;                                                                                     \
-        for (int ky = 0; ky < p.ksize; ++ky)                                                                 \
-          for (int kx = 0; kx < p.ksize; ++kx) {                                                             \
-            const bool in = mv && (unsigned)(iy0 + ky) < (unsigned)p.hi && (unsigned)(ix0 + kx) < (unsigned)p.wi; \
+        /* (ksize is 1 or 3: compile-time loop bounds keep the row loop unrolled and apix / tapmask in registers) */ \
+        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                                     \
+          _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                 \
+            const bool in = mv && ky < p.ksize && kx < p.ksize && (unsigned)(iy0 + ky) < (unsigned)p.hi &&   \
+                            (unsigned)(ix0 + kx) < (unsigned)p.wi;                                           \
             mk |= (in ? 1u : 0u) << (ky * p.ksize + kx);                                                     \
           }                                                                                                  \
         tapmask[i] = mk;                                                                                     \
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(256) void conv_streamk_kernel(const ConvParams p) {
 
   SK_SETUP(u)
   SK_ISSUE(NSLOT - 1)
+  WGTL_MARK(c)
   while (true) {
     const int m0 = tile_m * BM;
     // ---- this segment: K tile t sits in slot (NSLOT - 1 + t) mod NSLOT; tile 0 is already on its way
@@ -207,18 +211,34 @@ __global__ __launch_bounds__(256) void conv_streamk_kernel(const ConvParams p) {
       if (++slot == NSLOT) slot = 0;
     }
     __syncthreads();  // every wave is done with the ring before the epilogue's accumulator tile (slots 0 .. NSLOT - 2) is written
+    WGTL_LOOP()
     // ---- the next segment's first K tile goes out now (into the slot the epilogue leaves alone), then this one's epilogue
     const int e_tile_m = tile_m, e_tile_n = tile_n, e_part = part, e_nparts = nparts;
+    (void)lane;
     u += nt;
     const bool more = u < u_end;
     if (more) {
       SK_SETUP(u)
       SK_ISSUE(NSLOT - 1)
     }
-    conv_tile_epilogue<BM, BN>(p, smem, rowms, acc, e_tile_m, e_tile_n, e_part, e_nparts);
+    {
+      // (the kernel-level tile_m / tile_n already belong to the NEXT segment: the epilogue text sees this segment's through
+      //  these shadowing names)
+      const int tile_m = e_tile_m, tile_n = e_tile_n;
+      const int m0 = tile_m * BM, n0 = tile_n * BN;
+#define EPI_PART e_part
+#define EPI_NPARTS e_nparts
+#define EPI_EXIT goto epilogue_done;  /* (timeline builds: a workgroup's LAST segment is the one logged) */
+#include "conv_epilogue.inc"
+#undef EPI_PART
+#undef EPI_NPARTS
+#undef EPI_EXIT
+    }
+  epilogue_done:
     if (!more) break;
     __syncthreads();  // the accumulator tile has been read: its slots may take the next segment's K tiles
   }
+  WGTL_END(2)
 #undef SK_SETUP
 #undef SK_ISSUE
 }
