@@ -1,5 +1,6 @@
 """fps of the BASELINE.json configs that fit this engine (1: 256^2 1-step, 2: 512^2 4-step, 5: 768^2 8-step + ControlNet,
-plus the UI's live 768x432 4-step) with 1 and 3 frames in flight.  Reporting only; bench.py is the contract."""
+plus the UI's live 768x432 4-step), one frame per launch: a frame alone (ControlNet encoder on the lane's side stream) and four
+launch lanes busy.  Reporting only; bench.py is the contract."""
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,35 +14,35 @@ wc = W.synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", device="cuda")
 wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda")
 eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
 eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half())
-slots = [eng, eng.make_slot(), eng.make_slot()]
+slots = [eng, eng.make_slot(), eng.make_slot(), eng.make_slot()]
 out = []
 for name, H, Wd, steps, cn, scale in [("config1 256x256 1-step +CN", 256, 256, 1, True, 1.0), ("config2 512x512 4-step +CN", 512, 512, 4, True, 1.0),
                                        ("config2 512x512 4-step no CN", 512, 512, 4, False, 1.0), ("config5 768x768 8-step +CN scale 2", 768, 768, 8, True, 2.0),
                                        ("UI live 768x432 4-step +CN scale 2", 432, 768, 4, True, 2.0)]:
     f = np.random.default_rng(0).integers(0, 256, (H, Wd, 3), dtype=np.uint8)
-    eng.overlap_controlnet = True
+    eng.overlap_launch = True
     eng.prepare(H, Wd, steps, 0.6, controlnet_scale=scale, use_controlnet=cn)
     lat = []
     for i in range(12):
         t = time.perf_counter(); eng.infer_u8(f); lat.append((time.perf_counter() - t) * 1e3)
     for e in slots:
-        e.overlap_controlnet = False
+        e.overlap_launch = False
         e.prepare(H, Wd, steps, 0.6, controlnet_scale=scale, use_controlnet=cn)
         e.ops.upload(e.frame_u8, torch.from_numpy(f))
-    for i in range(6): slots[i % 3].launch()
+    for i in range(8): slots[i % 4].launch()
     for e in slots: e.ops.synchronize()
-    n = 45
+    n = 48
     t = time.perf_counter()
-    for i in range(n): slots[i % 3].launch()
+    for i in range(n): slots[i % 4].launch()
     for e in slots: e.ops.synchronize()
-    fps3 = n / (time.perf_counter() - t)
-    row = {"config": name, "p50_latency_ms_1_in_flight": round(sorted(lat)[6], 2), "fps_3_in_flight": round(fps3, 1)}
+    fps4 = n / (time.perf_counter() - t)
+    row = {"config": name, "p50_latency_ms_1_in_flight": round(sorted(lat)[6], 2), "fps_4_lanes": round(fps4, 1)}
     out.append(row)
     print(json.dumps(row), flush=True)
 
 # ---- the reference-only mode (lcm_reference_pipeline.py:855-890: a WRITE pass and a READ pass of the UNet per step,
 #      no ControlNet, one frame per launch): what `ref=True` costs next to the plain UNet-only frame above
-eng.overlap_controlnet = True
+eng.overlap_launch = True
 eng.prepare(512, 512, 4, 0.6, use_controlnet=False, ref_mode=True)
 f = np.random.default_rng(0).integers(0, 256, (512, 512, 3), dtype=np.uint8)
 eng.ops.upload(eng.ref_u8, torch.from_numpy(np.random.default_rng(1).integers(0, 256, (512, 512, 3), dtype=np.uint8)))
