@@ -67,7 +67,7 @@ f = np.random.default_rng(0).integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
 lat = []
 for i in range(8):
     t = time.perf_counter(); xl.infer_u8(f); lat.append((time.perf_counter() - t) * 1e3)
-s2 = xl.make_slot(); s2.prepare(1024, 1024, 4, 0.6, use_controlnet=False)
+s2 = xl.make_slot(lane=1); s2.prepare(1024, 1024, 4, 0.6, use_controlnet=False)  # (explicit: this process already handed out lanes 0-3)
 for e in (xl, s2):
     e.ops.upload(e.frame_u8, torch.from_numpy(f))
 for i in range(4): (xl, s2)[i % 2].launch()

@@ -244,6 +244,12 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
         }
       }
       PROBE(1)
+      // Issue priority: LOW while this wave runs its softmax VALU stream, HIGH from the PV MFMAs through the next tile's QK
+      // MFMAs.  A SIMD holds two or three of these waves in different phases; with equal priorities a wave's MFMAs wait their
+      // turn behind the other waves' VALU instructions and the matrix pipe drains between them.  Measured on MI355X
+      // (scripts/attn_bench.py, same box): 4096 keys d = 40, 5 images 243.9 -> 228.2 us, 3 images 128.2 -> 123.5, 1024 keys d = 80
+      // 32.5 -> 30.9; the opposite assignment (softmax high) 248.6 / 123.1 / 32.5.  Bit-identical (scheduling only).
+      __builtin_amdgcn_s_setprio(0);
   };
   // ---- masking, online softmax of the score tile `s` (keys key0..key0+63), O^T += V^T P^T with V^T in LDS buffer `buf`
   auto softmax_pv = [&](const int buf, const int key0, auto masked, f32x16 (&s)[QB][2]) __attribute__((always_inline)) {
@@ -306,6 +312,7 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
       }
 
       PROBE(2)
+      __builtin_amdgcn_s_setprio(3);
       // ---- O^T += V^T P^T (each V^T fragment feeds all QB query blocks)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
