@@ -358,6 +358,9 @@ def run_rank(args):
     # the side streams ARE the other lanes' streams.  The single-frame latency below therefore runs with it.
     B = max(1, args.batch)
     eng.overlap_launch = args.slots < 3
+    # kernel choices: with three or four lanes the forms that cost least when four lanes are busy, else the forms that are
+    # fastest alone (the drop-in class's rule, VideoSDPipeline._engine_for); the latency leg below always takes the latter
+    eng.tune_for_lanes = args.slots >= 3 and B > 1 and not os.environ.get("VSD_NO_LANE_TUNING")
     t_prep = time.perf_counter()
     plan = eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=B)
     prepare_ms = (time.perf_counter() - t_prep) * 1e3
@@ -372,6 +375,7 @@ def run_rank(args):
     for _ in range(max(1, args.slots) - 1):
         sl = eng.make_slot()
         sl.overlap_launch = eng.overlap_launch
+        sl.tune_for_lanes = eng.tune_for_lanes
         sl.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=B)
         engines.append(sl)
 
@@ -469,6 +473,7 @@ def run_rank(args):
                 e.launch()
         sync_all()
     eng.overlap_launch = True
+    eng.tune_for_lanes = False
     eng.use_side_stream = True  # one frame in flight: the second stream also takes the ControlNet merges (engine.py)
     plan1 = eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
     eng.use_side_stream = False
@@ -492,6 +497,7 @@ def run_rank(args):
             while len(pool) < nslots:
                 pool.append(eng.make_slot())
             for e in pool:
+                e.tune_for_lanes = nslots >= 3 and b > 1 and not os.environ.get("VSD_NO_LANE_TUNING")
                 e.overlap_launch = overlap and nslots < 3
                 e.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=b)
             for i in range(2 * nslots):
@@ -524,6 +530,7 @@ def run_rank(args):
     # ---- the same graph without the ControlNet tower (engine extension)
     for e in engines:
         e.overlap_launch = args.slots < 3
+        e.tune_for_lanes = args.slots >= 3 and B > 1 and not os.environ.get("VSD_NO_LANE_TUNING")
         e.prepare(H, W, LCM_STEPS, STRENGTH, use_controlnet=False, batch=B)
     for i in range(3):
         one_frame(i)
@@ -541,6 +548,7 @@ def run_rank(args):
     # ---- dominant kernel (implicit-GEMM conv) against the MFMA roofline: HIP events around every launch of
     #      one eager pass of the same program on the same stream
     eng.overlap_controlnet = False  # (one stream: a launch's event bracket must not include another stream's kernel beside it)
+    eng.tune_for_lanes = False      # (... and each layer in the form that is fastest ALONE: the bracket times a kernel alone)
     eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, use_graph=False, batch=B)
     eng.overlap_controlnet = True
     one_frame(0, [eng])

@@ -173,6 +173,39 @@ def test_streamk_on_a_launch_larger_than_the_chip(ops):
     assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
 
 
+def test_throughput_mode_tuning_times_candidates_with_four_lanes_busy(ops):
+    """HipOps.tune_conv with tune_mode = 1: every candidate alone first, then the shortlist with four copies in flight on the four
+    launch lanes (captured graphs); the choice lands under a key of its own (last field 1) beside the latency-mode entry, and a
+    conv run with it still matches the reference."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_linear
+
+    m, n, k = 1280, 640, 640
+    x, res = rnd(m, k, seed=1), rnd(m, n, seed=2)
+    wt, b = rnd(n, k, seed=3, scale=k ** -0.5), rnd(n, seed=4, scale=0.1)
+    pw = ops.to_device_pack(pack_linear(wt, b))
+    out = torch.zeros(m, n, dtype=torch.float16, device="cuda")
+    args, kw = (x.cuda(), None, Geom.linear(m), pw, out), dict(residual=res.cuda())
+    saved = dict(ops.tile_override)
+    try:
+        ops.tune_mode = 0
+        best0, table0 = ops.tune_conv(args, kw)
+        key0 = ops.conv_key_of(args[2], pw, kw)
+        ops.tune_mode = 1
+        best1, table1 = ops.tune_conv(args, kw)
+        key1 = ops.conv_key_of(args[2], pw, kw)
+        assert key0[:-1] == key1[:-1] and (key0[-1], key1[-1]) == (0, 1)
+        assert key0 in ops.tile_override and key1 in ops.tile_override
+        assert 1 <= len(table1) <= len(table0) and all(us > 0 for us, *_ in table1)
+        ops.conv(*args, **kw)   # (takes the throughput-mode entry: tune_mode is still 1)
+        ops.synchronize()
+        check(out, F.linear(x.float(), wt.float(), b.float()) + res.float(), "conv with the throughput-mode choice")
+    finally:
+        ops.tune_mode = 0
+        ops.tile_override.clear()
+        ops.tile_override.update(saved)
+
+
 @pytest.mark.parametrize("pipeline", [0, 3, 4, 5, 6])
 def test_pipelines_are_bit_identical_and_handle_short_k(ops, pipeline):
     # K = 1..5 tiles (shorter than the ring), ragged M and N

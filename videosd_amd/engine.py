@@ -422,6 +422,9 @@ class Engine:
         self.batch = 1
         self.overlap_controlnet = True  # record the ControlNet encoder for a second stream, parallel to the UNet encoder
         self.overlap_launch = True      # ... and launch it that way by default (`launch(overlap=...)` decides per launch)
+        # kernel choices of the plan: False = each layer's fastest form ALONE on an idle GPU (a lone launch: latency), True = the
+        # form that costs least with four launch lanes busy (throughput; ops.HipOps.tune_conv).  Fixed per plan at `prepare`.
+        self.tune_for_lanes = False
         self.graph_serial = None
         # ... and, optionally, while that stream is otherwise idle: the ControlNet skip merges beside the mid block / decoder
         # start and Sobel + conditioning embedding beside the TAESD encoder (`use_side_stream`).  Measured on MI355X (512x512,
@@ -964,6 +967,8 @@ class Engine:
         if batch < 1:
             raise ValueError("batch must be >= 1")
         self.batch = batch
+        if hasattr(self.ops, "tune_mode"):
+            self.ops.tune_mode = 1 if self.tune_for_lanes else 0
         if H % 8 or W % 8:
             raise ValueError("height and width must be multiples of 8 (TAESD / latent stride)")
         src = self._want if self._want is not None else self.family.get("prompt")
@@ -1099,7 +1104,7 @@ class Engine:
         r.postprocess_rgb(dec_out, 8, B * H * W, out_b)
         self.program = r
         self.plan = dict(H=H, W=W, steps=steps, strength=strength, cn_scale=controlnet_scale, cn=use_controlnet, n=n, batch=B,
-                         ref_mode=bool(ref_mode),
+                         ref_mode=bool(ref_mode), tuned_for_lanes=bool(self.tune_for_lanes),
                          sizes=sizes, timesteps=sched.timesteps, n_ops=len(r.calls), arena_bytes=a.peak)
         # per-shape kernel configuration (timed once per shape, cached in ops.tile_override), warm-up, capture
         torch.cuda.synchronize() if torch.cuda.is_available() else None  # allocation fills vs. kernel streams
@@ -1252,6 +1257,8 @@ class Engine:
             ov = self.overlap_launch if overlap is None else overlap
             self.ops.seq_launch(self.graph if ov else self.graph_serial)
         else:
+            if hasattr(self.ops, "tune_mode"):
+                self.ops.tune_mode = 1 if self.tune_for_lanes else 0
             self.program.run()
 
     def _want_shape(self):

@@ -451,6 +451,10 @@ class VideoSDPipeline:
             eng.set_added_cond(self.encode_pooled(prompt_text if prompt_text is not None else ""), (height, width, 0, 0, height, width))
         # (every engine is captured both ways -- ControlNet encoder on the lane's side stream / everything on the lane's own
         #  stream; `submit_batch` picks per launch, see `_overlap_now`)
+        # Kernel choices: coalesced launches of a worker with three or four lanes are the loaded case -- the forms that cost least
+        # with four lanes busy; one-frame launches and workers with one or two lanes are the latency case -- the forms that are
+        # fastest alone.  Fixed per plan, the same on every lane (same bits whichever lane a frame lands on).
+        eng.tune_for_lanes = self.max_lanes >= 3 and batch > 1
         eng.prepare(height, width, steps, strength, controlnet_scale=cn_scale, use_controlnet=use_cn, batch=batch, ref_mode=use_ref,
                     autotune=self.tuning_mode != "table")
         eng._ref_epoch = None
