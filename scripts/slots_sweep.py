@@ -34,6 +34,8 @@ for pt in pts:
         e.overlap_controlnet = True
         e.overlap_launch = ovl
         e.tune_for_lanes = s >= 3 and b > 1 and not os.environ.get("VSD_NO_LANE_TUNING")  # (bench.py's and the drop-in class's rule)
+        if os.environ.get("SWEEP_LANE_TUNING") is not None:  # (experiments: force the kernel-choice mode)
+            e.tune_for_lanes = os.environ["SWEEP_LANE_TUNING"] == "1"
         e.prepare(512, 512, 4, 0.6, use_controlnet=True, batch=b)
     f = np.random.default_rng(0).integers(0, 256, (512, 512, 3) if b == 1 else (b, 512, 512, 3), dtype=np.uint8)
     for e in pool:
