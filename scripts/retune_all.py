@@ -32,6 +32,7 @@ for (h, w, steps, b, cn) in plans:
 # the coalesced plans again in THROUGHPUT mode (every candidate with four copies in flight on the four launch lanes: the key's last
 # field = 1): what bench.py and a worker with three or four lanes run for launches of more than one frame
 eng.tune_for_lanes = True
+ops.tune_lanes_online = True
 for (h, w, steps, b, cn) in [(512, 512, 4, b, True) for b in (5, 2, 3, 4, 8, 6)] + [(512, 512, 4, 5, False)]:
     t0 = time.time()
     eng.prepare(h, w, steps, 0.6, use_controlnet=cn, use_graph=False, batch=b)

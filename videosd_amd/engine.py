@@ -938,16 +938,30 @@ class Engine:
         if not hasattr(ops, "tune_conv"):
             return {}
         seen = {}
-        for fn, a, k in self.program.calls:
-            if fn.__name__ != "conv":
-                continue
-            key = ops.conv_key_of(a[2], a[3], k)
-            if key in seen or key in ops.tile_override or k.get("tile") is not None:
-                continue
-            best, table = ops.tune_conv(a, k)
-            seen[key] = best
-            if verbose:
-                print("tune", key, "->", best, flush=True)
+        # throughput-mode plans: candidates are timed with four lanes busy only offline / on request (ops.tune_lanes_online);
+        # otherwise a shape without a throughput-mode entry takes its alone-timed choice, timed now if that is missing too
+        mode = getattr(ops, "tune_mode", 0)
+        online = mode == 0 or getattr(ops, "tune_lanes_online", False)
+        try:
+            for fn, a, k in self.program.calls:
+                if fn.__name__ != "conv":
+                    continue
+                ops.tune_mode = mode
+                key = ops.conv_key_of(a[2], a[3], k)
+                if key in seen or key in ops.tile_override or k.get("tile") is not None:
+                    continue
+                if not online:
+                    ops.tune_mode = 0
+                    key = ops.conv_key_of(a[2], a[3], k)
+                    if key in seen or key in ops.tile_override:
+                        continue
+                best, table = ops.tune_conv(a, k)
+                seen[key] = best
+                if verbose:
+                    print("tune", key, "->", best, flush=True)
+        finally:
+            if hasattr(ops, "tune_mode"):
+                ops.tune_mode = mode
         return seen
 
     def prepare(self, H: int, W: int, steps: int, strength: float, controlnet_scale: float = 1.0,

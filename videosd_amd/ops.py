@@ -118,6 +118,10 @@ class HipOps:
         # it records / captures; part of the tuning key.
         self.tune_mode = 0
         self._tune_lanes = None
+        # timing with four lanes busy takes ~80 s per plan: done offline (scripts/retune_all.py sets this) or on request
+        # (VSD_TUNE_LANES=1); a live worker that meets a shape the table has no throughput-mode entry for takes the alone-timed
+        # choice (a second or two per plan, as before) instead of stalling a stream for minutes
+        self.tune_lanes_online = bool(_os.environ.get("VSD_TUNE_LANES"))
         self.inkernel_splitk = True
         self.one_launch_bias_us = float(_os.environ.get("VSD_ONE_LAUNCH_BIAS_US", "0.5"))  # tune_conv: see there
         self.no_halo = bool(__import__("os").environ.get("VSD_NO_HALO"))  # debugging: run halo-tuned shapes on the generic ring
@@ -271,6 +275,8 @@ class HipOps:
         key = self.conv_key(g, w, t_col0, self.epilogue_class(w, rowstat_out, ln_part, chanstat_out, residual2, out2, out_scale_dev, out_scale, act))
         inkernel = self.inkernel_splitk
         if tile is None:
+            if key not in self.tile_override and key[-1] == 1 and key[:-1] + (0,) in self.tile_override:
+                key = key[:-1] + (0,)  # (no throughput-mode entry for this shape: the alone-timed choice)
             if key in self.tile_override:
                 # (the key names the epilogue class since round 4: an entry always fits the call it is looked up for -- rounds
                 #  2-3 keyed on the shape alone and widened 64-column tiles / left the halo form after the fact)
