@@ -810,6 +810,43 @@ def test_graph_replay_equals_eager(ops):
     ops.graph_destroy(g)
 
 
+def test_launch_sequence_orders_graphs_on_two_streams_by_its_event_edges(ops):
+    """include/vsd.h vsd_seq / vsd_stream_pool at the C-ABI level: a sequence of three single-branch graphs on two of the
+    process's launch streams -- A on the lane's stream, B on its side stream AFTER A (edge), C on the lane's stream AFTER B
+    (edge) -- must produce the dependent result every replay, and the four pool streams must be four different handles on
+    four different command-processor pipes."""
+    pool = ops.pool_streams()
+    assert len({st.cuda_stream for st in pool}) == 4 and ops.streams[0].cuda_stream == pool[ops.lane % 4].cuda_stream
+    assert ops.streams[1].cuda_stream == pool[(ops.lane + 2) % 4].cuda_stream
+    assert ops.pool_check(chain=60) < 1.5
+    n = 1 << 20
+    a = torch.full((n,), 1.0, dtype=torch.float16, device="cuda")
+    b = torch.full((n,), 2.0, dtype=torch.float16, device="cuda")
+    x, y, z = (torch.zeros(n, dtype=torch.float16, device="cuda") for _ in range(3))
+    ops.synchronize()
+    seq = ops.seq_create()
+    ops.seq_capture_begin(0)
+    ops.axpy(a, b, 3.0, n, x)           # A: x = 1 + 2 * 3 = 7
+    ops.seq_capture_end(seq, 0)
+    ops.seq_wait(seq, 1, ops.seq_record(seq, 0))
+    ops.seq_capture_begin(1)
+    ops.axpy(x, b, 0.5, n, y)           # B (side stream): y = x + 2 * 0.5 = 8
+    ops.seq_capture_end(seq, 1)
+    ops.seq_wait(seq, 0, ops.seq_record(seq, 1))
+    ops.seq_capture_begin(0)
+    ops.axpy(y, x, 1.0, n, z)           # C: z = y + x = 15
+    ops.seq_capture_end(seq, 0)
+    ops.use_stream(0)
+    assert ops.seq_count(seq) == (3, 2)
+    for rep in range(5):
+        for t in (x, y, z):
+            ops.zero_(t)
+        ops.seq_launch(seq)
+        ops.synchronize()
+        assert float(z.float().min()) == 15.0 and float(z.float().max()) == 15.0, rep
+    ops.seq_destroy(seq)
+
+
 def test_errors_are_reported_not_fatal(ops):
     from videosd_amd.ops import Geom
     from videosd_amd.packing import pack_conv
