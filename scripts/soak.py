@@ -1,4 +1,5 @@
-"""Concurrency soak: the bench configuration (SOAK_BATCH frames per launch, 2 launches in flight on two engine slots)
+"""Concurrency soak: the bench configuration (SOAK_BATCH frames per launch, SOAK_LANES launches in flight on as many launch lanes;
+SOAK_SIDE=1: two lanes, each with its ControlNet encoder on the lane's side stream -- all four launch streams busy)
 replayed a few hundred times; every result must be bit-identical to the sequential result of the same input (no
 interference between the slots, no state leaking across replays). On a mismatch the first differing stage buffer is
 named. Exit code 1 on any mismatch.   python scripts/soak.py [launches]   env: SOAK_BATCH (3), SOAK_SIZE (512), SOAK_NO_CN, SOAK_EAGER"""
@@ -10,7 +11,7 @@ from videosd_amd.engine import Engine
 from videosd_amd.ops import HipOps
 
 
-def run(n=300, batch=3, controlnet=True, use_graph=True, size=512, verbose=True):
+def run(n=300, batch=3, controlnet=True, use_graph=True, size=512, verbose=True, lanes=2, side=False):
     ops = HipOps(0)
     ops.load_tuning(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tuning_mi355x.json"))
     wu = W.synthesize(W.unet_spec(C.SD15_UNET), "unet.", device="cuda")
@@ -18,10 +19,16 @@ def run(n=300, batch=3, controlnet=True, use_graph=True, size=512, verbose=True)
     wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda")
     eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
     eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half())
-    eng.overlap_controlnet = False
+    lanes = 2 if side else max(1, min(4, lanes))
+    eng.overlap_controlnet = bool(side)
+    eng.overlap_launch = bool(side)
+    eng.tune_for_lanes = lanes >= 3 and batch > 1   # (bench.py's and the drop-in class's rule)
     eng.prepare(size, size, 4, 0.6, use_controlnet=controlnet, batch=batch, use_graph=use_graph)
-    s2 = eng.make_slot(); s2.prepare(size, size, 4, 0.6, use_controlnet=controlnet, batch=batch, use_graph=use_graph)
-    slots = [eng, s2]
+    slots = [eng]
+    while len(slots) < lanes:
+        sl = eng.make_slot()
+        sl.prepare(size, size, 4, 0.6, use_controlnet=controlnet, batch=batch, use_graph=use_graph)
+        slots.append(sl)
     rng = np.random.default_rng(0)
     shape = (size, size, 3) if batch == 1 else (batch, size, size, 3)
     inputs = [rng.integers(0, 256, shape, dtype=np.uint8) for _ in range(4)]
@@ -53,8 +60,8 @@ def run(n=300, batch=3, controlnet=True, use_graph=True, size=512, verbose=True)
     t0 = time.time()
     pending = []
     for i in range(n):
-        e = slots[i % 2]
-        if len(pending) == 2:
+        e = slots[i % lanes]
+        if len(pending) == lanes:
             check(*pending.pop(0))
         e.submit_u8(inputs[i % 4])
         pending.append((e, i % 4))
@@ -72,4 +79,5 @@ def run(n=300, batch=3, controlnet=True, use_graph=True, size=512, verbose=True)
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     sys.exit(1 if run(n, int(os.environ.get("SOAK_BATCH", "3")), not os.environ.get("SOAK_NO_CN"), not os.environ.get("SOAK_EAGER"),
-                      size=int(os.environ.get("SOAK_SIZE", "512"))) else 0)
+                      size=int(os.environ.get("SOAK_SIZE", "512")), lanes=int(os.environ.get("SOAK_LANES", "2")),
+                      side=bool(os.environ.get("SOAK_SIDE"))) else 0)

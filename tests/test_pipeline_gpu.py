@@ -455,6 +455,24 @@ def test_soak_two_launches_in_flight_full_size_bit_identical(batch):
     assert soak.run(n={1: 60, 3: 30}.get(batch, 20), batch=batch, verbose=False) == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,lanes,side", [(5, 4, False), (1, 4, False), (1, 2, True), (3, 2, True)])
+def test_soak_four_launch_streams_busy_full_size_bit_identical(batch, lanes, side):
+    """Round 4's concurrency machinery under load, at full size: four launch lanes in flight (the bench's 5 x 4 operating point
+    with its throughput-mode kernel choices; four one-frame launches), and two lanes whose ControlNet encoders run on the
+    lanes' side streams (launch sequences of 13 graphs + 8 event edges each: all four launch streams busy).  Every result
+    bit-identical to the sequential result of the same input -- no interference through shared scratch, split-K tickets,
+    prompt constants or the streams themselves."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location(
+        "vsd_soak", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "soak.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    assert soak.run(n={1: 64}.get(batch, 24), batch=batch, verbose=False, lanes=lanes, side=side) == 0
+
+
 def test_no_kernel_reads_uninitialised_memory():
     """VSD_POISON=1 fills everything the engine allocates "uninitialised" with NaN bytes: the live program and the
     reference-only program still match the oracle, at sizes whose token counts are ragged against the 64-key attention
