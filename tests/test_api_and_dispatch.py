@@ -318,6 +318,40 @@ def test_two_rank_gloo_broadcast_and_sharding():
         assert tmax == pytest.approx(0.2)
 
 
+def test_plan_cache_respects_its_memory_budget():
+    """VideoSDPipeline._trim_memory: over the budget, idle programs go least recently used first, then the idle slots of the
+    program being extended; the program's root and anything with a launch in flight stay."""
+    from collections import OrderedDict
+
+    from videosd_amd.pipeline import VideoSDPipeline
+
+    class E:
+        def __init__(self, gb):
+            self.gb, self.destroyed = gb, False
+
+        def _destroy_graphs(self):
+            self.destroyed = True
+
+    p = VideoSDPipeline.__new__(VideoSDPipeline)
+    p._plans, p._outstanding, p.evictions = OrderedDict(), [], 0
+
+    def plan(*gbs):
+        es = [E(g) for g in gbs]
+        return {"root": es[0], "opts": (0.6, 1.0), "engines": {(i + 1, 0): e for i, e in enumerate(es)}}
+
+    p._plans["old"], p._plans["busy"], p._plans["mid"], p._plans["cur"] = plan(6, 6), plan(5), plan(4), plan(3, 2, 2)
+    p._outstanding = [p._plans["busy"]["root"], p._plans["cur"]["engines"][(2, 0)]]
+    p._memory_used_and_limit = lambda before=None: (sum(e.gb for pl in p._plans.values() for e in pl["engines"].values()), 20)
+    assert p._trim_memory(keep="cur") == 2 and list(p._plans) == ["busy", "mid", "cur"]   # 28 -> 16: "old" alone is enough
+    p._memory_used_and_limit = lambda before=None: (sum(e.gb for pl in p._plans.values() for e in pl["engines"].values()), 9)
+    cur = p._plans["cur"]
+    idle_slot = cur["engines"][(3, 0)]
+    assert p._trim_memory(keep="cur") == 2                                                # "mid", then cur's one idle slot
+    assert list(p._plans) == ["busy", "cur"] and sorted(cur["engines"]) == [(1, 0), (2, 0)] and idle_slot.destroyed
+    assert not cur["root"].destroyed and not p._plans["busy"]["root"].destroyed and p.evictions == 4
+    assert p._trim_memory(keep="cur") == 0                                                # nothing idle left: allocation goes ahead
+
+
 def test_side_stream_policy_is_a_function_of_the_launches_in_flight():
     """VideoSDPipeline._overlap_now: a launch runs its ControlNet encoder on the lane's side stream only while it has a
     command-processor pipe for it -- at most two launches in flight, all on lanes 0 / 1 (lane l's side stream is lane l + 2's

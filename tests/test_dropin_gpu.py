@@ -173,6 +173,13 @@ def test_two_sessions_alternate_without_stalls():
     n_prep = len(p._host_ms["prepare"])
     assert np.array_equal(np.asarray(p.infer(imgs[3], **sb)), want_b[3])  # rebuilt on demand: the same kernels, the same bits
     assert len(p._host_ms["prepare"]) == n_prep + 1
+    # memory budget: over it, the next new engine first drops every idle program (their arenas return to the allocator)
+    held, ev = torch.cuda.memory_allocated(), p.evictions
+    p.memory_budget = 1e-6
+    p.infer(imgs[0], **dict(sa, height=64, width=64))
+    assert p.evictions >= ev + 2 and len(p._plans) == 1 and torch.cuda.memory_allocated() < held
+    assert np.array_equal(np.asarray(p.infer(imgs[3], **sb)), want_b[3]) and len(p._plans) == 1
+    assert p.metrics()["stage_ms_p50"]["engines_evicted_for_memory"] == p.evictions
 
 
 def test_reference_only_mode_through_the_drop_in_class():

@@ -78,13 +78,18 @@ class VideoSDPipeline:
         #            GPU in ~1 ms); an engine takes a cached prompt with one device-to-device copy on its own stream;
         #   plans:   (size, steps, timestep count, ControlNet, ref) -> {engines by (frames per launch, lane), constants}: each
         #            plan has its own schedule constants, so sessions with different sizes / steps alternate frame by frame
-        #            with their graphs intact.  `max_plans` counts PROGRAMS; a plan's engines are never evicted one by one.
+        #            with their graphs intact.  `max_plans` counts PROGRAMS.  Every engine owns its activation arena (1-6 GB
+        #            at 512x512, one to five frames per launch): `memory_budget` (fraction of the device's memory, default
+        #            0.6) bounds what the cache may hold -- least recently used idle programs go first, then the idle slots
+        #            of the program being extended (`_trim_memory`); an engine that is needed again is prepared again.
         from collections import OrderedDict
 
         self._prompts = OrderedDict()
         self.max_prompts = int(kwargs.get("max_prompts", 8))
         self._plans = OrderedDict()
         self.max_plans = int(kwargs.get("max_plans", 3))
+        self.memory_budget = float(kwargs.get("memory_budget", 0.6))
+        self.evictions = 0
         self._outstanding = []  # engines with a submitted, not yet collected launch
         self._lanes_busy = []   # ... and the lane each of them runs on
         self._host_ms = {"crop_resize": [], "upload_enqueue": [], "wait_download": [], "to_pil": [], "gpu": [], "prepare": [], "update_options": [],
@@ -238,7 +243,10 @@ class VideoSDPipeline:
         out["plans_cached"] = len(self._engines)
         out["programs_cached"] = len(self._plans)
         out["prompts_cached"] = len(self._prompts)
-        return {"stage_ms_p50": out}
+        out["engines_evicted_for_memory"] = self.evictions
+        free, total = torch.cuda.mem_get_info(int(self.device))  # what a leak across plan / prompt changes would show in
+        return {"stage_ms_p50": out, "device_free_mb": free >> 20, "device_total_mb": total >> 20,
+                "allocated_mb": torch.cuda.memory_allocated(int(self.device)) >> 20}
 
     def stage_profile(self, batch: int = 1):
         """Per-kernel-family device ms of ONE eager pass of the current plan (vsd_stage_times; the captured graph cannot be
@@ -433,6 +441,7 @@ class VideoSDPipeline:
                     raise RuntimeError("this lane's previous launch has not been collected")
                 return eng
         t0 = time.perf_counter()
+        self._trim_memory(keep=plan_key)
         if plan is None:
             # least recently used PROGRAMS go first, but never one with a launch still running (the cache then grows)
             for pk in list(self._plans):
@@ -461,6 +470,50 @@ class VideoSDPipeline:
         plan["engines"][(batch, lane)] = eng
         self._note("prepare", t0)
         return eng
+
+    def _memory_used_and_limit(self, before=None):
+        dev = int(self.device)
+        used = torch.cuda.memory_allocated(dev)
+        if before is not None and used >= before:  # an evicted engine still referenced from a cycle: collect it now
+            import gc
+
+            gc.collect()
+            used = torch.cuda.memory_allocated(dev)
+        return used, self.memory_budget * torch.cuda.mem_get_info(dev)[1]
+
+    def _trim_memory(self, keep=None):
+        """Before another engine (= another arena) is allocated: while the allocator holds more than the budget, drop idle
+        cached state, cheapest to rebuild last -- other programs (least recently used first), then the idle slots of the
+        program `keep` itself (never its root: it owns the schedule constants the slots share).  Engines with a launch in
+        flight are never touched; if nothing idle is left the allocation goes ahead (and may fail loudly in the allocator)."""
+        used, limit = self._memory_used_and_limit()
+        if used <= limit:
+            return 0
+        dropped = 0
+        for pk in list(self._plans):
+            if pk == keep or self._plan_busy(self._plans[pk]):
+                continue
+            for e in self._plans.pop(pk)["engines"].values():
+                e._destroy_graphs()
+                dropped += 1
+            e = None
+            used = self._memory_used_and_limit(before=used)[0]
+            if used <= limit:
+                break
+        plan = self._plans.get(keep)
+        if plan is not None and used > limit:
+            for k, e in list(plan["engines"].items()):
+                if e is plan["root"] or e in self._outstanding:
+                    continue
+                del plan["engines"][k]
+                e._destroy_graphs()
+                dropped += 1
+                e = None
+                used = self._memory_used_and_limit(before=used)[0]
+                if used <= limit:
+                    break
+        self.evictions += dropped
+        return dropped
 
     def set_tuning_mode(self, mode: str):
         """ "auto" (time the candidates of shapes the table lacks at `prepare`) or "table" (never: deterministic heuristic)."""
