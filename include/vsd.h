@@ -36,6 +36,7 @@ enum vsd_status {
 enum vsd_act { VSD_ACT_NONE = 0, VSD_ACT_RELU = 1, VSD_ACT_SILU = 2, VSD_ACT_GEGLU = 3, VSD_ACT_QUICKGELU = 4,
                VSD_ACT_SOFTMAX = 5 /* row softmax inside every 128-column tile over its first softmax_cols columns (tile
                                       128-wide, N % 128 == 0, split-K only with `counters`): cross-attention probabilities, see softmax_cols */,
+               VSD_ACT_GELU = 6 /* erf GELU (the MLP of SDXL's second text encoder; general epilogue walk) */,
                VSD_ACT_POST = 256 /* flag: apply the activation AFTER the residual adds (TAESD block) */ };
 
 /* tile shapes of the implicit-GEMM kernel (BM x BN output tile per 256-thread workgroup) */

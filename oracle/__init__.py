@@ -9,7 +9,8 @@ loudly when its HIP library is missing.
 Pinning status
   * scheduler / w-embedding / RNG contract: PINNED — checked against tests/golden/lcm_scheduler.json,
     which was produced by executing the reference's own in-tree code (tests/golden/make_golden.py).
-  * CLIP text encoder: PINNED against `transformers.CLIPTextModel` (installed here) on random weights.
+  * CLIP text encoder: PINNED against `transformers.CLIPTextModel` (installed here) on random weights; the SDXL pair
+    (text_encoders.py: penultimate states of both towers, `CLIPTextModelWithProjection.text_embeds`) likewise.
   * UNet / ControlNet / TAESD network forward passes: PARITY UNPINNED.  Their arithmetic lives in the
     unvendored, unpinned third-party dependency `diffusers` (reference requirements.txt:1, bracketed to
     0.23-0.25 by its API use) which is not installable here; the restatement follows that library's

@@ -26,6 +26,9 @@ class FakeOps:
     def to_device(self, t):
         return t.clone()
 
+    def to_device_pack(self, p):
+        return p
+
     def synchronize(self):
         pass
 
@@ -127,6 +130,8 @@ class FakeOps:
                 return F.silu(v)
             if a == L.ACT_QUICKGELU:
                 return v * torch.sigmoid(1.702 * v)
+            if a == L.ACT_GELU:
+                return F.gelu(v)
             return v
 
         if not post:

@@ -98,6 +98,10 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   if (p.out_t && p.batch > 1 && (p.t_img < p.hw_out || (int64_t)p.batch * p.t_img > p.ldt))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: transposed output needs hw <= t_img and batch * t_img <= ldt");
   if (p.out2 && !p.add2) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: out2 without add2");
+  if ((p.act & 0xff) > VSD_ACT_GELU) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: activation %d", p.act & 0xff);
+  if ((p.act & 0xff) == VSD_ACT_GELU && (p.out_t || p.rowstat_out || p.ln_part || (p.act & VSD_ACT_POST)))
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: erf GELU exists in the general epilogue walk only (no transposed output, row statistics, "
+                    "fused LayerNorm or post-residual form)");
   if (p.rowstat_out && (p.N % 64 || p.out_t || (p.split_k > 1 && !d->counters)))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: rowstat_out needs N %% 64 == 0, no transposed output and the in-kernel split-K form");
   if (p.chanstat_out && (!p.chanstat_part || !p.chan_counters || p.N % 8 || p.out_t || (p.act & 0xff) == VSD_ACT_GEGLU ||
@@ -121,7 +125,8 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   }
   if (halo) {
     const bool simple_epi = !p.out2 && !p.residual2 && !p.out_t && !p.rowstat_out && !p.chanstat_out && !p.ln_part &&
-                            p.out_scale == 1.0f && !p.out_scale_dev && (p.act & 0xff) != VSD_ACT_GEGLU && (p.act & 0xff) != VSD_ACT_QUICKGELU &&
+                            p.out_scale == 1.0f && !p.out_scale_dev &&
+                            ((p.act & 0xff) == VSD_ACT_NONE || (p.act & 0xff) == VSD_ACT_RELU || (p.act & 0xff) == VSD_ACT_SILU) &&
                             !((p.act & VSD_ACT_POST) && (p.act & 0xff) != VSD_ACT_RELU);
     if (!p.halo_ok || p.ksize != 3 || p.stride != 1 || p.pad != 1 || BM < 128 || p.N % 8 || p.c0 % 64 || p.c1 % 64 || !simple_epi)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the halo-patch form (pipeline 7) needs a 3x3 stride-1 conv, Cin %% 64 == 0 per "

@@ -171,6 +171,7 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
     if (act == VSD_ACT_RELU) return fmaxf(x, 0.0f);
     if (act == VSD_ACT_SILU) return silu_f(x);
     if (act == VSD_ACT_QUICKGELU) return quick_gelu_f(x);
+    if (act == VSD_ACT_GELU) return gelu_erf_f(x);
     return x;
   };
   if (act != VSD_ACT_NONE && !post) {

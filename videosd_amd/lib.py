@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VSD_LIB") or os.path.join(HERE, "libvsd.so")
 
 VERSION = 4  # include/vsd.h VSD_VERSION
-ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_QUICKGELU, ACT_SOFTMAX = range(6)
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_QUICKGELU, ACT_SOFTMAX, ACT_GELU = range(7)
 ACT_POST = 256
 SPLITK_MAX_TILES = 16384
 POOL_STREAMS = 4  # include/vsd.h VSD_POOL_STREAMS

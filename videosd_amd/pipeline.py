@@ -136,7 +136,31 @@ class VideoSDPipeline:
             wv, self.weight_sources["vae"] = load_or_synthesize(W.taesd_spec(C.TAESD), "vae.", "taesdxl.safetensors", dev,
                                                                 CK.checkpoint_file(vdir))
             self.model = Engine(ops, C.SDXL_UNET, None, C.TAESD, wu, None, wv)
-            self.text_encoder = None
+            # the two text towers of an SDXL snapshot (<model>/text_encoder, <model>/text_encoder_2, tokenizer, tokenizer_2;
+            # flat: $VSD_WEIGHTS/text_encoder.safetensors + text_encoder_2.safetensors, vocabulary files in $VSD_WEIGHTS[/tokenizer_2])
+            self.text_encoder, self._xl_prompts = None, {}
+            d = _weights_dir()
+
+            def flat(name):
+                return os.path.join(d, name) if d and os.path.exists(os.path.join(d, name)) else None
+
+            def sub(name):
+                return os.path.join(mdir, name) if mdir and os.path.isdir(os.path.join(mdir, name)) else None
+
+            f1 = CK.checkpoint_file(mdir, "text_encoder", stems=("model",)) or flat("text_encoder.safetensors")
+            f2 = CK.checkpoint_file(mdir, "text_encoder_2", stems=("model",)) or flat("text_encoder_2.safetensors")
+            self.weight_sources["text_encoder"] = f1 or "stand-in embeddings seeded by the prompt text"
+            self.weight_sources["text_encoder_2"] = f2 or "stand-in embeddings seeded by the prompt text"
+            if f1 is not None and f2 is not None:
+                from . import clip as K
+
+                towers = []
+                for f, cfg, tok in ((f1, K.SDXL_CLIP_L, sub("tokenizer") or d),
+                                    (f2, K.SDXL_CLIP_G, sub("tokenizer_2") or (flat("tokenizer_2") or d))):
+                    wt = CK.load_safetensors(f, device=dev)
+                    CK.check_against_spec(wt, K.text_tower_spec(cfg), f)
+                    towers.append(K.ClipTextEncoder(ops, cfg, wt, tokenizer_dir=tok))
+                self.text_encoder = K.SdxlTextEncoders(*towers)
             return self.model
         cdir = CK.find_snapshot(controlnet_model)
         wu, self.weight_sources["unet"] = load_or_synthesize(W.unet_spec(C.SD15_UNET), "unet.", "unet.safetensors", dev,
@@ -171,14 +195,26 @@ class VideoSDPipeline:
         runs; otherwise (no vocabulary offline) a deterministic stand-in seeded by the prompt text is used."""
         text = prompt if isinstance(prompt, str) else " ".join(prompt)
         if self.text_encoder is not None and self.text_encoder.has_tokenizer:
-            return self.text_encoder.encode(text)
+            return self._xl_encode(text)[0] if self.is_xl else self.text_encoder.encode(text)
         g = torch.Generator().manual_seed(zlib.crc32(text.encode()))
         return (torch.randn(77, self.unet_cfg.cross_dim, generator=g) * 0.5).half()
 
+    def _xl_encode(self, text: str):
+        """SDXL: (prompt_embeds [77, 2048], pooled_prompt_embeds [1280]) of both text towers, once per prompt text (the pooled
+        vector is asked for separately, per engine: keep the last few pairs)."""
+        hit = self._xl_prompts.get(text)
+        if hit is None:
+            hit = self._xl_prompts[text] = self.text_encoder.encode(text)
+            while len(self._xl_prompts) > 8:
+                self._xl_prompts.pop(next(iter(self._xl_prompts)))
+        return hit
+
     def encode_pooled(self, prompt: Union[str, List[str]]) -> torch.Tensor:
-        """SDXL only: the pooled text embedding [1280] (stand-in seeded by the prompt text; the two SDXL text encoders
-        are outside this path)."""
+        """SDXL only: the pooled text embedding [1280] = the second tower's `text_embeds` (with both towers' checkpoints and
+        tokenizer files present; otherwise a stand-in seeded by the prompt text, like `encode_prompt`)."""
         text = prompt if isinstance(prompt, str) else " ".join(prompt)
+        if self.text_encoder is not None and self.text_encoder.has_tokenizer:
+            return self._xl_encode(text)[1]
         g = torch.Generator().manual_seed(zlib.crc32(("pooled:" + text).encode()))
         return (torch.randn(self.unet_cfg.add_pooled_dim, generator=g) * 0.5).half()
 
