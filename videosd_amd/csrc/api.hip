@@ -156,8 +156,21 @@ extern "C" int vsd_stream_pool(vsd_ctx* ctx, void** streams_out) {
     std::vector<uint32_t> all;
     int rc = full_cu_mask(ctx, all);
     if (rc != VSD_OK) return rc;
-    for (int i = 0; i < VSD_POOL_STREAMS; ++i)
-      VSD_HIP(ctx, hipExtStreamCreateWithCUMask(&g_pool[ctx->device][i], (uint32_t)all.size(), all.data()));
+    // VSD_POOL_MASK (experiments, scripts/mask_probe.cpp): "xcd" = stream i gets the mask bits b with b % 8 in {2i, 2i+1},
+    // "blk" = the i-th quarter of the bits; default: every stream may use every CU
+    const char* mode = getenv("VSD_POOL_MASK");
+    const int ncu = ctx->num_cus > 0 ? ctx->num_cus : (int)all.size() * 32;
+    for (int i = 0; i < VSD_POOL_STREAMS; ++i) {
+      std::vector<uint32_t> m = all;
+      if (mode && (mode[0] == 'x' || mode[0] == 'b')) {
+        std::fill(m.begin(), m.end(), 0u);
+        for (int b = 0; b < ncu; ++b) {
+          const bool on = mode[0] == 'x' ? (b % 8) / 2 == i : b * VSD_POOL_STREAMS / ncu == i;
+          if (on) m[(size_t)b / 32] |= 1u << (b % 32);
+        }
+      }
+      VSD_HIP(ctx, hipExtStreamCreateWithCUMask(&g_pool[ctx->device][i], (uint32_t)m.size(), m.data()));
+    }
     g_pool_made[ctx->device] = true;
     static bool registered = false;
     if (!registered) {
