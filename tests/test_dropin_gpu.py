@@ -64,6 +64,22 @@ def test_infer_batch_gives_every_frame_its_single_frame_result(pipe):
     assert len(pipe._engines) == 2  # (program, 1, lane 0) and (program, 3, lane 0)
 
 
+def test_a_size_that_is_not_a_multiple_of_8_is_rounded_down_like_the_image_processor(pipe):
+    """VaeImageProcessor.preprocess (lcm_controlnet.py:457) rounds the frame down to a multiple of the VAE stride with a Lanczos
+    resize and the pipeline returns that size: `infer(height=100, width=150)` gives a 144x96 picture, the one the rounded call
+    gives for the frame resized that way."""
+    from videosd_amd.pipeline import center_crop_resize
+
+    img = _photo(400, 300, 17)
+    opts = dict(prompt="pixar, cg", strength=0.6, steps=2)
+    got = pipe.infer(img, height=100, width=150, **opts)
+    assert got.size == (144, 96)
+    pre = center_crop_resize(img, 150, 100).resize((144, 96), resample=Image.Resampling.LANCZOS)
+    assert np.array_equal(np.asarray(got), np.asarray(pipe.infer(pre, height=96, width=144, **opts)))
+    with pytest.raises(ValueError):
+        pipe.infer(img, height=7, width=64, **opts)
+
+
 def test_slider_options_do_not_rebuild_the_plan(pipe):
     """The client patches `strength` (step 0.02) and `controlnet_scale` (0.05 - 3) live (server.py:163-197): through the
     drop-in class a new value must keep the prepared engines (no `prepare`, no re-capture) and still give the frame a

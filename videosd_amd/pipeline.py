@@ -357,6 +357,15 @@ class VideoSDPipeline:
             raise ValueError(f"lane {lane}: this pipeline was built for {self.max_lanes} launch lane(s) (kwarg `lanes`)")
         t0 = time.perf_counter()
         imgs = [center_crop_resize(im, width, height) for im in imgs]
+        # A size that is not a multiple of the VAE stride: `VaeImageProcessor.preprocess` (lcm_controlnet.py:457, 230) rounds it
+        # DOWN to a multiple of 8 with a Lanczos resize and the pipeline returns that size.  (There the control image is the
+        # Sobel map of the unrounded frame, resized; here it is the Sobel map of the rounded frame -- sizes the client offers
+        # are multiples of 8.)
+        if height % 8 or width % 8:
+            height, width = height - height % 8, width - width % 8
+            if height <= 0 or width <= 0:
+                raise ValueError("height and width must be at least 8")
+            imgs = [im.resize((width, height), resample=Image.Resampling.LANCZOS) for im in imgs]
         self._note("crop_resize", t0)
         pkey = prompt if isinstance(prompt, str) else tuple(prompt)
         pblock = self._cache_prompt(pkey, prompt=prompt)  # cached: nothing to do; new: ~1 ms on the GPU, nobody waits
@@ -443,7 +452,7 @@ class VideoSDPipeline:
             use_ref = bool(o["ref"]) and self.honor_ref_flag and not self.is_xl
             if use_ref:
                 return bool(self._outstanding)  # (reference image upload + one frame per launch: keep it simple)
-            pk = (o["height"], o["width"], int(o["steps"]), n_eff, use_cn and not use_ref, use_ref)
+            pk = (o["height"] - o["height"] % 8, o["width"] - o["width"] % 8, int(o["steps"]), n_eff, use_cn and not use_ref, use_ref)
             if self.is_xl:
                 pk += (o["prompt"] if isinstance(o["prompt"], str) else tuple(o["prompt"]),)
             plan = self._plans.get(pk)
