@@ -60,12 +60,22 @@ long long* g_probe = nullptr;
 
 constexpr float NEG_BIG = -1.0e30f;
 
+#ifndef VSD_ATTN_WEAVE
+#define VSD_ATTN_WEAVE 0
+#endif
+#ifndef VSD_ATTN_PV_PRIO
+#define VSD_ATTN_PV_PRIO 3
+#endif
+
 __device__ __forceinline__ float xhalf_max(float x) {  // max over the two half-waves (lanes l and l ^ 32)
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 template <int NQK, int NPV, int NW, int QB, int KSP>
+#if VSD_ATTN_WEAVE
+__attribute__((amdgpu_waves_per_eu(NQK <= 3 && KSP == 1 ? 3 : 1, 8)))  // (keep the third wave per SIMD the shipped d = 40 kernel has)
+#endif
 __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnParams pp) {
   constexpr int NTG = 64 * NW;       // threads of one key-split group (they stage that group's tiles)
   constexpr int KS = NQK * 16 + 8;   // K tile row pitch (halfs): 4 * odd dwords -> conflict-free ds_read_b128
@@ -282,6 +292,7 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
         grew_any = grew_any || (m_new > m_run[qb]);
         alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
         m_run[qb] = m_new;
+        if constexpr (VSD_ATTN_WEAVE) continue;  // (the exponentials are woven into the PV product below)
         if (ones_row) {
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb)
@@ -312,7 +323,66 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
       }
 
       PROBE(2)
-      __builtin_amdgcn_s_setprio(3);
+      __builtin_amdgcn_s_setprio(VSD_ATTN_PV_PRIO);
+#if VSD_ATTN_WEAVE
+      // ---- woven form: the tile's 64 keys in four 16-key chunks c = kb * 2 + st; the exponentials + fp16 conversion of chunk
+      // c + 1 sit BETWEEN the PV MFMAs of chunk c (an MFMA occupies the matrix pipe for 32 cycles; the ~10 VALU instructions
+      // behind it are independent of it), pinned with sched_barrier so the scheduler keeps the alternation
+      {
+        float psum[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) psum[qb] = 0.f;
+        auto exp_part = [&](const int c, const int part) __attribute__((always_inline)) {
+          const int kb = c >> 1, st = c & 1, lo = 8 * part / NPV, hi = 8 * (part + 1) / NPV;
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int j = lo; j < hi; ++j) {
+              const float e = __builtin_amdgcn_exp2f(s[qb][kb][8 * st + j] - m_run[qb]);
+              s[qb][kb][8 * st + j] = e;
+              if (!ones_row) psum[qb] += e;
+            }
+        };
+        auto cvt_chunk = [&](const int c, half8 (&pf)[QB]) __attribute__((always_inline)) {
+          const int kb = c >> 1, st = c & 1;
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[qb][j] = (half_t)s[qb][kb][8 * st + j];
+        };
+        auto vread = [&](const int c, half8 (&vf)[NPV]) __attribute__((always_inline)) {
+          const int kb = c >> 1, st = c & 1;
+#pragma unroll
+          for (int db = 0; db < NPV; ++db) vf[db] = *reinterpret_cast<const half8*>(Vb + (db * 32 + lr) * VS + kb * 32 + 16 * st + 8 * lh);
+        };
+        // (V^T fragments single-buffered: the next chunk's reads go into the registers the last MFMA of this chunk has just
+        //  consumed -- with a second set the kernel needs 172 registers and loses its third wave per SIMD)
+        half8 pf[2][QB], vf[NPV];
+        vread(0, vf);
+#pragma unroll
+        for (int part = 0; part < NPV; ++part) exp_part(0, part);
+        cvt_chunk(0, pf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int db = 0; db < NPV; ++db) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[db], pf[c & 1][qb], o[qb][db], 0, 0, 0);
+            if (c + 1 < 4) {
+              if (db == NPV - 1) vread(c + 1, vf);
+              exp_part(c + 1, db);
+              if (db == NPV - 1) cvt_chunk(c + 1, pf[(c + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (!ones_row) {
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) l_run[qb] = l_run[qb] * alpha[qb] + psum[qb];
+        }
+      }
+#else
       // ---- O^T += V^T P^T (each V^T fragment feeds all QB query blocks)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -331,6 +401,7 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
           }
         }
       }
+#endif
       PROBE(3)
   };
   // two copies of the softmax body: the masked one only runs for a ragged last tile (or causal attention) -- as ONE
