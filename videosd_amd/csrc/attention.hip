@@ -75,6 +75,8 @@ __device__ __forceinline__ float xhalf_max(float x) {  // max over the two half-
 template <int NQK, int NPV, int NW, int QB, int KSP>
 #if VSD_ATTN_WEAVE
 __attribute__((amdgpu_waves_per_eu(NQK <= 3 && KSP == 1 ? 3 : 1, 8)))  // (keep the third wave per SIMD the shipped d = 40 kernel has)
+#elif defined(VSD_ATTN_WAVES)
+__attribute__((amdgpu_waves_per_eu(NQK <= 3 && KSP == 1 ? VSD_ATTN_WAVES : 1, 8)))  // (experiments: occupancy of the d <= 48 kernels)
 #endif
 __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnParams pp) {
   constexpr int NTG = 64 * NW;       // threads of one key-split group (they stage that group's tiles)
