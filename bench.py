@@ -474,9 +474,9 @@ def run_rank(args):
         sync_all()
     eng.overlap_launch = True
     eng.tune_for_lanes = False
-    eng.use_side_stream = True  # one frame in flight: the second stream also takes the ControlNet merges (engine.py)
+    # (the launch sequence the drop-in class uses for a lone frame: ControlNet encoder on the lane's side stream, nothing else
+    #  there -- `use_side_stream` measures level since the launch streams own their pipes: 47.8 vs 47.6 launches/s)
     plan1 = eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
-    eng.use_side_stream = False
     lat = []
     got0 = None
     for i in range(min(30, max(5, args.steps))):

@@ -429,8 +429,9 @@ class Engine:
         # ... and, optionally, while that stream is otherwise idle: the ControlNet skip merges beside the mid block / decoder
         # start and Sobel + conditioning embedding beside the TAESD encoder (`use_side_stream`).  Measured on MI355X (512x512,
         # 4 steps): one frame alone 23.8 -> 23.2 ms, but with two launches in flight 97 -> 81 frames/s -- four busy hardware
-        # queues instead of two cost more than the filled gaps give.  So: off by default, switched on where a single frame is
-        # in flight (bench.py's latency leg).  (Round 2 also moved the decoder's 1x1 shortcut convs there: 23.6 ms, removed.)
+        # queues instead of two cost more than the filled gaps give.  Round 4, launch streams on their own pipes: level either
+        # way (one frame 47.8 vs 47.6 launches/s, 5 x 2 128.0 vs 128.4).  Off; `VSD_SIDE=1` switches it on.  (Round 2 also
+        # moved the decoder's 1x1 shortcut convs there: 23.6 ms, removed.)
         self.use_side_stream = False
         import os as _os
         if _os.environ.get("VSD_SIDE") is not None:  # A/B switch
