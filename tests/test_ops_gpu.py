@@ -86,6 +86,8 @@ def run_conv(ops, x_list, h, w, weight, bias, *, ksize, stride=1, up_to=None, ti
         ref = F.silu(ref)
     elif act == 4:
         ref = ref * torch.sigmoid(1.702 * ref)
+    elif act == 6:
+        ref = F.gelu(ref)
     ref = ref * out_scale
     if residual is not None:
         ref = ref + from_nhwc(residual.float(), g.ho, g.wo)
@@ -284,7 +286,7 @@ def test_conv_small_channels_generic_path(ops, cin, cout, pad):
         check(got, ref, f"generic conv {cin}->{cout} pipeline={pl}")
 
 
-@pytest.mark.parametrize("act", [0, 1, 2, 4])
+@pytest.mark.parametrize("act", [0, 1, 2, 4, 6])  # none, ReLU, SiLU, quick-GELU (CLIP-L), erf GELU (SDXL's second text tower)
 def test_linear_epilogues(ops, act):
     m, k, n = 77, 768, 320
     x = rnd(1, k, 1, m, seed=1)
@@ -293,6 +295,12 @@ def test_linear_epilogues(ops, act):
     got, ref = run_conv(ops, [x], 1, m, wt, rnd(n, seed=5, scale=0.1), ksize=1, act=act, residual=res, residual2=res2,
                         out_scale=0.37)
     check(got, ref, f"linear act={act}")
+    if act == 6:  # ... and behind the split-K reducer / the in-launch reduction
+        for inkernel in (False, True):
+            ops.inkernel_splitk = inkernel
+            got, ref = run_conv(ops, [x], 1, m, wt, rnd(n, seed=5, scale=0.1), ksize=1, act=act, residual=res, split_k=3, tile=2)
+            check(got, ref, f"linear act=6 split-K inkernel={inkernel}")
+        ops.inkernel_splitk = True
 
 
 @pytest.mark.parametrize("tile", [0, 3])
@@ -859,6 +867,14 @@ def test_errors_are_reported_not_fatal(ops):
         ops.conv(x, x, Geom.conv(4, 4), pw, out, c0=40, c1=24)
     with pytest.raises(RuntimeError, match="head_dim"):
         ops.attention(x, 64, x, 64, x, 64, out, 64, 16, 16, 1, 12, 1.0)
+    # erf GELU lives in the general epilogue walk only; an activation the enum does not know is refused
+    lin = pack_conv(rnd(64, 64, 1, 1), None)
+    lin.weight = lin.weight.cuda()
+    vt = torch.zeros(64, 64, dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError, match="GELU"):
+        ops.conv(x, None, Geom.linear(16), lin, out, act=6, out_t=vt, ldt=64)
+    with pytest.raises(RuntimeError, match="activation"):
+        ops.conv(x, None, Geom.linear(16), lin, out, act=9)
 
 
 # ---------------------------------------------------------------------------------------------- batched launches
