@@ -4,7 +4,8 @@ rebuilt all the time).  Checks, per phase: every frame comes back; a frame seen 
 same picture again (mean |diff| < 0.5 LSB: the worker coalesces a varying number of frames per launch, whose kernels differ in
 rounding, so not bit-equal); no picture is flat; device memory does not drift; throughput does not decay.  Exit code 1 on any.
 
-usage (GPU box): python scripts/api_soak.py [seconds=120] [lanes=4] [batch=5]"""
+usage (GPU box): python scripts/api_soak.py [seconds=120] [lanes=4] [batch=5] [memory_budget=0.6]
+(a small memory_budget, e.g. 0.15, makes the plan cache evict engines for memory all the time)"""
 import asyncio, json, os, sys, time
 import numpy as np
 from PIL import Image
@@ -22,10 +23,10 @@ SESSIONS = [
 PROMPTS = ["pixar, cg", "an oil painting of a harbour at dusk", "lego bricks", "watercolour, autumn", "neon city at night", "charcoal sketch"]
 
 
-def main(seconds=120.0, lanes=4, batch=5):
+def main(seconds=120.0, lanes=4, batch=5, memory_budget=0.6):
     frames = [Image.fromarray(f, "RGB") for f in bench.synthetic_frames(8, 512, 512)]
     w = VideoSDPipeline.remote(model="SimianLuo/LCM_Dreamshaper_v7", controlnet="lllyasviel/control_v11p_sd15_canny", device=0,
-                               batch=batch, lanes=lanes, shm_slots=(lanes + 1) * batch + 4, call_timeout=600.0)
+                               batch=batch, lanes=lanes, shm_slots=(lanes + 1) * batch + 4, call_timeout=600.0, memory_budget=memory_budget)
     seen, bad, log = {}, [], []
     rng = np.random.default_rng(5)
 
@@ -93,7 +94,10 @@ def main(seconds=120.0, lanes=4, batch=5):
                       "fps_first_last_by_session": decay, "worker": {k: met.get(k) for k in ("launches", "frames", "frames_per_launch")},
                       "stage_ms_p50": met.get("pipeline", {}).get("stage_ms_p50")}))
     leak = early is not None and late > 1.05 * early + 1024
-    slow = any(b < 0.8 * a for a, b in decay.values())
+    evicted = (met.get("pipeline", {}).get("stage_ms_p50") or {}).get("engines_evicted_for_memory", 0)
+    # (with a budget small enough to evict all the time a phase's rate is set by how many engines it has to prepare again: no
+    #  decay criterion then -- results and the memory bound are what that run checks)
+    slow = not evicted and any(b < 0.8 * a for a, b in decay.values())
     if bad or leak or slow:
         print("FAILED:", "results" if bad else "", "memory" if leak else "", "throughput decay" if slow else "")
         return 1
@@ -103,4 +107,4 @@ def main(seconds=120.0, lanes=4, batch=5):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    sys.exit(main(float(a[0]) if a else 120.0, int(a[1]) if len(a) > 1 else 4, int(a[2]) if len(a) > 2 else 5))
+    sys.exit(main(float(a[0]) if a else 120.0, int(a[1]) if len(a) > 1 else 4, int(a[2]) if len(a) > 2 else 5, float(a[3]) if len(a) > 3 else 0.6))
