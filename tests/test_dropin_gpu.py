@@ -80,6 +80,24 @@ def test_a_size_that_is_not_a_multiple_of_8_is_rounded_down_like_the_image_proce
         pipe.infer(img, height=7, width=64, **opts)
 
 
+def test_a_tiny_frame_after_other_programs_does_not_read_past_its_split_k_slabs():
+    """An 8 x 8 frame (a 1 x 1 latent: every GEMM has ONE row) prepared while other programs are cached.  Round 4 found a GPU
+    memory fault here: the tile-softmax epilogue of the absorbed cross-attention read the split-K slabs for all 64 rows of its
+    tile, the workspace holds M rows -- harmless or fatal depending on what the allocator had placed behind it (a fresh
+    process ran it fine).  The sequence below is the one that faulted."""
+    from videosd_amd.pipeline import VideoSDPipeline
+
+    p = VideoSDPipeline(max_plans=9, **CFG)
+    opts = dict(prompt="pixar, cg", strength=0.6, steps=2)
+    for w, h in ((256, 256), (320, 192), (192, 320), (8, 8)):
+        img = _photo(w, h, 5)
+        a = np.asarray(p.infer(img, height=h, width=w, **opts))
+        assert a.shape == (h, w, 3) and np.array_equal(np.asarray(p.infer(img, height=h, width=w, **opts)), a)
+        two = p.infer_batch([img, img], height=h, width=w, **opts)
+        assert np.abs(np.asarray(two[0]).astype(int) - a.astype(int)).mean() < 0.5
+    assert len(p._plans) == 4
+
+
 def test_slider_options_do_not_rebuild_the_plan(pipe):
     """The client patches `strength` (step 0.02) and `controlnet_scale` (0.05 - 3) live (server.py:163-197): through the
     drop-in class a new value must keep the prepared engines (no `prepare`, no re-capture) and still give the frame a

@@ -553,7 +553,7 @@ def test_attention_with_peaked_softmax_rows(ops, sq, sk, heads, d):
     check(out, attention_ref(q, k, v, heads, scale), f"peaked attention {sq}x{sk} d{d}", rel=4e-3)
 
 
-@pytest.mark.parametrize("m,c,heads", [(768, 1280, 8), (3072, 640, 8), (200, 640, 8)])
+@pytest.mark.parametrize("m,c,heads", [(768, 1280, 8), (3072, 640, 8), (200, 640, 8), (1, 1280, 8)])  # (1 row: an 8 x 8 frame's latent)
 def test_absorbed_cross_attention_matches_explicit_attention(ops, m, c, heads):
     """Cross-attention over the 77 text tokens as two GEMMs (packing.pack_cross_attention: K folded into the query
     weights, V into the output weights, per-head tile softmax in the first GEMM's epilogue) against the explicit

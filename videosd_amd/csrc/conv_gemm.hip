@@ -24,8 +24,13 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.hs = d->hs; p.ws = d->ws; p.hi = d->hi; p.wi = d->wi; p.ho = d->ho; p.wo = d->wo;
   p.ksize = d->ksize; p.stride = d->stride; p.pad = d->pad;
   p.resize = (d->hi != d->hs) || (d->wi != d->ws);
-  if (d->hi <= 0 || d->wi <= 0 || d->hs > d->hi || d->ws > d->wi || (p.resize && (d->hi > 1024 || d->wi > 1024)))
-    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: input size %dx%d (stored %dx%d) unsupported", d->hi, d->wi, d->hs, d->ws);
+  // nearest resize = a 32-bit fixed-point multiply in the loaders: source row = (iy * ceil(hs * 2^22 / hi)) >> 22, exactly
+  // floor(iy * hs / hi) while iy * hi < 2^22 (hi <= 2048) and without overflow while hs * 2^22 + hi < 2^32 (hs <= 1023): frames
+  // up to 2046 pixels a side through the TAESD decoder's 2x upsamples (1920 x 1080 included)
+  if (d->hi <= 0 || d->wi <= 0 || d->hs > d->hi || d->ws > d->wi ||
+      (p.resize && (d->hi > 2048 || d->wi > 2048 || d->hs > 1023 || d->ws > 1023)))
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: input size %dx%d (stored %dx%d) unsupported (a resized input may be at most 2048 a side, "
+                    "its stored form 1023)", d->hi, d->wi, d->hs, d->ws);
   if (p.resize) {
     p.rshift = 22;
     p.rmul_y = (unsigned)((((unsigned long long)d->hs << 22) + d->hi - 1) / d->hi);

@@ -472,6 +472,7 @@ class HipOps:
             best = table[0]
             self.tile_override[key] = (best[1], best[2], best[3], best[4])
             return best, table
+        last_error = None
         for (t, sp, ink, pl) in cands:
             self.inkernel_splitk = ink
             try:
@@ -487,9 +488,12 @@ class HipOps:
                     e1.synchronize()
                     best_us = min(best_us, e0.elapsed_time(e1) / reps * 1e3)
                 table.append((best_us, t, sp, ink, pl))
-            except RuntimeError:
+            except RuntimeError as e:
+                last_error = e
                 continue
         self.inkernel_splitk = True
+        if not table:  # (every candidate was refused: say for which layer and why instead of an IndexError)
+            raise RuntimeError(f"tune_conv: no candidate ran for M={g.m} N={w.n} K={w.k} ksize={g.ksize}: {last_error}")
         table.sort()
         best = table[0]
         if best[2] > 1 and not best[3] and self.one_launch_bias_us > 0:
