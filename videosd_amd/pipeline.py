@@ -325,7 +325,7 @@ class VideoSDPipeline:
     def infer_batch(self, imgs, prompt=["pixar, cg"], height=360, width=640, strength=0.4, steps=20, guidance_scale=7.5,
                     ref=False, style_fidelity=0.0, controlnet=False, seed=42, controlnet_scale=1):
         """Several frames (of different sessions, or consecutive frames of one stream) with the SAME options through
-        one batched launch: same result per frame as `infer` (frames are denoised independently), one pass over the
+        one batched launch: the result `infer` gives each frame, up to kernel rounding (frames are denoised independently), one pass over the
         weights for all of them.  Extension of the reference surface; `RemotePipeline(batch=B)` coalesces queued
         `infer` calls into this."""
         return self.collect_batch(self.submit_batch(imgs, prompt=prompt, height=height, width=width, strength=strength,
