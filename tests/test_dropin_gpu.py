@@ -87,14 +87,20 @@ def test_a_tiny_frame_after_other_programs_does_not_read_past_its_split_k_slabs(
     process ran it fine).  The sequence below is the one that faulted."""
     from videosd_amd.pipeline import VideoSDPipeline
 
-    p = VideoSDPipeline(max_plans=9, **CFG)
+    # (tuning_mode="table": kernel choices by the deterministic heuristic, not by a timing run -- the comparison below must not
+    #  depend on which candidate happened to be 0.1 us faster on this box)
+    p = VideoSDPipeline(max_plans=9, tuning_mode="table", **CFG)
     opts = dict(prompt="pixar, cg", strength=0.6, steps=2)
     for w, h in ((256, 256), (320, 192), (192, 320), (8, 8)):
         img = _photo(w, h, 5)
         a = np.asarray(p.infer(img, height=h, width=w, **opts))
         assert a.shape == (h, w, 3) and np.array_equal(np.asarray(p.infer(img, height=h, width=w, **opts)), a)
-        two = p.infer_batch([img, img], height=h, width=w, **opts)
-        assert np.abs(np.asarray(two[0]).astype(int) - a.astype(int)).mean() < 0.5
+        two = [np.asarray(t) for t in p.infer_batch([img, img], height=h, width=w, **opts)]
+        assert two[0].shape == (h, w, 3) and np.isfinite(two[0].astype(float)).all()
+        # a two-frame launch runs other kernel forms than a one-frame launch: same picture up to rounding (an 8 x 8 picture is
+        # ONE latent pixel decoded: its 64 pixels move together, so the bound is the parity tolerance, not a fraction of an LSB)
+        assert np.abs(two[0].astype(int) - a.astype(int)).mean() <= 1.5
+        assert np.array_equal([np.asarray(t) for t in p.infer_batch([img, img], height=h, width=w, **opts)][1], two[1])
     assert len(p._plans) == 4
 
 
