@@ -1075,3 +1075,16 @@ def test_every_workgroup_order_gives_the_same_bits(ops, h, w, cin, cout, ks, til
     check(outs["0"], ref, "conv, order 0")
     for order, o in outs.items():
         assert torch.equal(o, outs["0"]), order
+
+
+def test_no_op_writes_outside_its_buffers_on_random_ragged_shapes():
+    """scripts/guard_fuzz.py for 20 s: conv (every tile / pipeline / split-K form), QKV with transposed V^T output, GroupNorm,
+    LayerNorm and attention on random ragged shapes, every writable buffer cut out of a larger allocation between canaries --
+    the canaries stay intact and the results match the fp32 references."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "guard_fuzz.py"), "20", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "guard fuzz passed" in r.stdout, (r.stdout[-600:], r.stderr[-1200:])
