@@ -1088,3 +1088,17 @@ def test_no_op_writes_outside_its_buffers_on_random_ragged_shapes():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "guard_fuzz.py"), "20", "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "guard fuzz passed" in r.stdout, (r.stdout[-600:], r.stderr[-1200:])
+
+
+def test_no_op_touches_a_byte_past_its_operands_on_random_ragged_shapes():
+    """scripts/guard_page_fuzz.py for 25 s: the same random ragged shapes with EVERY operand (inputs, weights, bias, residual,
+    statistics, split-K workspace, outputs) in a buffer that ends at -- or starts right after -- an unmapped page (HIP's
+    virtual-memory API): an out-of-bounds READ takes a GPU memory fault there and then.  Round 4's fault (the tile-softmax epilogue
+    behind split-K reading slab rows past M) depended on what the allocator had placed behind the workspace; this does not."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "guard_page_fuzz.py"), "25", "7"], capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0 and "guard page fuzz passed" in r.stdout, (r.stdout[-800:], r.stderr[-1200:])
