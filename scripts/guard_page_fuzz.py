@@ -230,6 +230,51 @@ def one_layernorm():
     return "ok"
 
 
+_TAIL = {}
+
+
+def one_tail():
+    """the fused transformer tails (csrc/fused_tail.hip, C = 320) at ragged token counts"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_ops_gpu import _tail_weights
+
+    m = int(rng.choice([1, 7, 64, 65, 200, 1000, 3600, 4097, 8000]))
+    print(f"tails m{m}", flush=True)
+    c = 320
+    if not _TAIL:
+        w, packs = _tail_weights(c)
+        _TAIL["w"], _TAIL["pk"] = w, {k: gpack(v) for k, v in packs.items()}
+        _TAIL["keep"] = list(live)
+    w, pk = _TAIL["w"], _TAIL["pk"]
+    att, h, x, att2 = rnd(m, c), (rnd(m, c).float() * 2 + 0.5).half(), rnd(m, c), rnd(m, c)
+    h1, q, out = guarded(shape=(m, c)), guarded(shape=(m, c)), guarded(shape=(m, c))
+    ops.tail_a(guarded(att), guarded(h), m, pk["out1"], pk["q2"], h1, q)
+    ops.tail_b(guarded(att2), h1, guarded(x), m, pk["out2"], pk["ff1"], pk["ff2"], pk["proj"], out)
+    ops.synchronize()
+    h1_ref = F.linear(att.float(), w["wo1"].float(), w["bo1"].float()) + h.float()
+    close(h1, h1_ref, f"tail_a h1 m{m}")
+    h2 = F.linear(att2.float(), w["wo2"].float(), w["bo2"].float()) + h1.float().cpu()
+    ln = F.layer_norm(h2.half().float(), (c,), w["g3"].float(), w["be3"].float(), 1e-5)
+    hid, gate = F.linear(ln, w["wf1"].float(), w["bf1"].float()).chunk(2, dim=-1)
+    h3 = F.linear(hid * F.gelu(gate), w["wf2"].float(), w["bf2"].float()) + h2
+    close(out, F.linear(h3, w["wp"].float().reshape(c, c), w["bp"].float()) + x.float(), f"tail_b m{m}")
+    return "ok"
+
+
+def one_geglu():
+    from videosd_amd.packing import pack_geglu
+
+    m, c, tile = int(rng.choice([1, 63, 200, 500])), int(rng.choice([320, 640])), int(rng.choice([0, 3]))
+    print(f"geglu m{m} c{c} tile {tile}", flush=True)
+    x, wt, b = rnd(m, c), rnd(8 * c, c, scale=c ** -0.5), rnd(8 * c, scale=0.1)
+    out = guarded(shape=(m, 4 * c))
+    ops.conv(guarded(x), None, Geom.linear(m), gpack(pack_geglu(wt, b)), out, tile=tile)
+    ops.synchronize()
+    hid, gate = F.linear(x.float(), wt.float(), b.float()).chunk(2, dim=-1)
+    close(out, hid * F.gelu(gate), f"geglu m{m} c{c}")
+    return "ok"
+
+
 def one_pixels():
     """u8 frame -> fp16 rows, Sobel control map, fp16 rows -> u8 frame at ragged sizes"""
     h, w = int(rng.integers(1, 70)) * 8, int(rng.integers(1, 70)) * 8
@@ -256,7 +301,7 @@ if "selftest" in sys.argv:
     print(float(big.sum()), "NO FAULT: the guard pages do not work here", flush=True)
     sys.exit(3)
 
-kinds = [one_conv, one_conv, one_conv, one_qkv, one_xattn, one_groupnorm, one_attention, one_layernorm, one_pixels]
+kinds = [one_conv, one_conv, one_conv, one_qkv, one_xattn, one_groupnorm, one_attention, one_layernorm, one_pixels, one_tail, one_geglu]
 count = {}
 t_end = time.time() + seconds
 while time.time() < t_end:
