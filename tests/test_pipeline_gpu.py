@@ -490,3 +490,19 @@ def test_no_kernel_reads_uninitialised_memory():
     diffs = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert set(diffs) == {"live", "reference_only", "reference_only_64"}
     assert all(v < 1.5 for v in diffs.values()), diffs
+
+
+@pytest.mark.gpu
+def test_whole_program_with_every_buffer_between_unmapped_pages():
+    """scripts/guard_page_engine.py: SD1.5 + ControlNet and the mini SDXL topology at ragged / degenerate frame sizes, 1 and 3
+    frames per launch, with every device buffer of the engine (packed weights, each activation tensor, workspaces, I/O) ending
+    at or starting after an unmapped page (`HipOps.allocator` hook + HIP's virtual-memory API): an out-of-bounds access anywhere
+    in the recorded program faults; every frame equals the ordinary engine's bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "guard_page_engine.py"), "8x8", "24x40", "104x88", "200x136"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "guard page engine run passed" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])

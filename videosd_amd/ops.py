@@ -196,7 +196,27 @@ class HipOps:
             self._lanes[0] = max(self._lanes[0], int(lane) + 1)
         return HipOps(self.device_id, make_current=False, tile_override=self.tile_override, lane=lane, _lanes=self._lanes)
 
+    # Debugging hook (scripts/guard_page_engine.py): a callable(nbytes) -> uint8 device tensor.  When set, EVERY buffer this object
+    # hands out -- activations (the engine's arena then allocates tensor by tensor), packed weights, uploads, workspaces -- comes
+    # from it, e.g. from an allocator that ends each buffer at an unmapped page so that an out-of-bounds access faults.
+    allocator = None
+
+    def _alloc(self, shape, dtype):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        raw = self.allocator(max(nbytes, 16))
+        return raw[:nbytes].view(dtype).view(*shape)
+
     def empty(self, *shape, dtype=torch.float16):
+        if self.allocator is not None:
+            with torch.cuda.stream(self.stream):
+                t = self._alloc(shape, dtype)
+                t.view(torch.uint8).fill_(255 if POISON else 0)
+                return t
         with torch.cuda.stream(self.stream):
             t = torch.empty(*shape, dtype=dtype, device=self.device)
             if POISON:  # VSD_POISON=1 (tests): every "uninitialised" byte is 0xFF (fp16 / fp32 NaN), so that a kernel
@@ -205,10 +225,18 @@ class HipOps:
 
     def zeros(self, *shape, dtype=torch.float16):
         with torch.cuda.stream(self.stream):
+            if self.allocator is not None:
+                t = self._alloc(shape, dtype)
+                t.view(torch.uint8).zero_()
+                return t
             return torch.zeros(*shape, dtype=dtype, device=self.device)
 
     def to_device(self, t: torch.Tensor):
         with torch.cuda.stream(self.stream):
+            if self.allocator is not None:
+                d = self._alloc(tuple(t.shape), t.dtype)
+                d.copy_(t.contiguous())
+                return d
             return t.to(self.device)
 
     def zero_(self, t: torch.Tensor):
@@ -224,7 +252,7 @@ class HipOps:
         for f in ("weight", "bias", "ln_s", "ln_t", "weight_frag"):
             v = getattr(p, f)
             if v is not None:
-                setattr(p, f, v.to(self.device).contiguous())
+                setattr(p, f, self.to_device(v) if self.allocator is not None else v.to(self.device).contiguous())
         return p
 
     def workspace(self, key: str, nbytes: int) -> torch.Tensor:
@@ -232,10 +260,16 @@ class HipOps:
         cur = self._ws.get(key)
         if cur is None or cur.numel() < nbytes:
             with torch.cuda.stream(self.stream):
-                cur = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+                if self.allocator is not None:
+                    cur = self.allocator(max(nbytes, 256))
+                else:
+                    cur = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
                 if POISON:
                     cur.fill_(255)
             self._ws[key] = cur
+        if self.allocator is not None and cur.numel() != max(nbytes, 256):  # (hook mode: exactly the size asked for, every time)
+            with torch.cuda.stream(self.stream):
+                cur = self._ws[key] = self.allocator(max(nbytes, 256))
         return cur
 
     def synchronize(self):
