@@ -3,7 +3,8 @@ tensor), workspaces, frame / output buffers -- ending at (or starting after) an 
 `HipOps.allocator` hook): an out-of-bounds access anywhere in the recorded program takes a GPU memory fault.  Ragged and
 degenerate frame sizes, 1-3 frames per launch, SD1.5 + ControlNet and the mini SDXL topology; every result must equal the
 ordinary engine's bit for bit.
-usage (GPU box): python scripts/guard_page_engine.py [sizes like 8x8 24x40 ...]"""
+usage (GPU box): python scripts/guard_page_engine.py [table] [lanes] [b=1,3] [sizes like 8x8 24x40 ...]
+(table: the shipped tuning table's kernel forms instead of the heuristic's; lanes: its throughput-mode entries)"""
 import ctypes as C
 import os, subprocess, sys
 import numpy as np
@@ -49,19 +50,23 @@ def engines(kind):
     for hook in (None, guard_allocator):
         ops = plain if hook is None else HipOps(0, make_current=False)
         ops.allocator = hook
+        if "table" in sys.argv:
+            ops.load_tuning(os.path.join(ROOT, "profiles", "tuning_mi355x.json"))
         e = Engine(ops, ucfg, ccfg, Cfg.TAESD, wu, wc, wv)
         e.set_text_embeds((torch.randn(77, ucfg.cross_dim, generator=torch.Generator().manual_seed(7)) * 0.5).half())
         e.overlap_controlnet = False
+        e.tune_for_lanes = "lanes" in sys.argv
         out.append(e)
     return out, ccfg is not None
 
 
+BATCHES = [int(x) for a in sys.argv[1:] if a.startswith("b=") for x in a[2:].split(",")] or [1, 3]
 sizes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:] if "x" in a] or [(8, 8), (16, 8), (24, 40), (72, 40), (104, 88), (200, 136), (360, 640)]
 for kind in ("sd15", "mini"):
     (ref, grd), cn = engines(kind)
     for (h, w) in sizes:
-        for b in (1, 3):
-            if h * w * b > 360 * 640 * 2:
+        for b in BATCHES:
+            if h * w * b > 512 * 512 * 5:
                 continue
             f = rng.integers(0, 256, (h, w, 3) if b == 1 else (b, h, w, 3), dtype=np.uint8)
             print(f"{kind} {h}x{w} x{b}", flush=True)
@@ -73,4 +78,24 @@ for kind in ("sd15", "mini"):
                 outs.append(e.infer_u8(f).copy())
             assert np.array_equal(outs[0], outs[1]), f"{kind} {h}x{w} x{b}: guarded run differs from the ordinary one"
     print(f"{kind}: ok ({mapped[0] / 2**30:.1f} GB mapped so far)", flush=True)
+# the text towers (once per prompt: CLIP-L, and the SDXL pair with the erf-GELU tower and its pooled row)
+from videosd_amd import clip as K
+for c1, c2 in ((Cfg.MINI_CLIP, K.MINI_CLIP_G), (Cfg.CLIP_L, None)):
+    got = []
+    for hook in (None, guard_allocator):
+        ops = plain if hook is None else HipOps(0, make_current=False)
+        ops.allocator = hook
+        t1 = K.ClipTextEncoder(ops, c1, W.synthesize(K.text_tower_spec(c1), "t1.", device="cuda"))
+        ids = torch.randint(1, c1.vocab - 1, (77,), generator=torch.Generator().manual_seed(3))
+        ids[9:] = c1.vocab - 1
+        r = [t1.encode_ids(ids).float().cpu()]
+        if c2 is not None:
+            t2 = K.ClipTextEncoder(ops, c2, W.synthesize(K.text_tower_spec(c2), "t2.", device="cuda"))
+            ids2 = ids.clone()
+            ids2[10:] = 0
+            e, pooled = K.SdxlTextEncoders(t1, t2).encode_ids(ids, ids2)
+            r += [e.float().cpu(), pooled.float().cpu()]
+        got.append(r)
+    assert all(torch.equal(a, b) for a, b in zip(*got)), "text towers: guarded run differs"
+    print(f"text towers width {c1.width}{' + ' + str(c2.width) if c2 else ''}: ok", flush=True)
 print("guard page engine run passed")
