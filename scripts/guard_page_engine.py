@@ -77,6 +77,16 @@ for kind in ("sd15", "mini"):
                 e.prepare(h, w, 2, 0.6, use_controlnet=cn, use_graph=False, batch=b, autotune=False)
                 outs.append(e.infer_u8(f).copy())
             assert np.array_equal(outs[0], outs[1]), f"{kind} {h}x{w} x{b}: guarded run differs from the ordinary one"
+    if kind == "sd15":  # the reference-only program (banked self-attention keys / values + AdaIN): kernels nothing else runs
+        for (h, w) in ((64, 64), (128, 192)):
+            f, rf = (rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(2))
+            print(f"{kind} reference-only {h}x{w}", flush=True)
+            outs = []
+            for e in (ref, grd):
+                e.prepare(h, w, 2, 0.6, use_controlnet=False, use_graph=False, batch=1, ref_mode=True, autotune=False)
+                e.ops.upload(e.ref_u8, torch.from_numpy(rf))
+                outs.append(e.infer_u8(f).copy())
+            assert np.array_equal(outs[0], outs[1]), f"reference-only {h}x{w}: guarded run differs from the ordinary one"
     print(f"{kind}: ok ({mapped[0] / 2**30:.1f} GB mapped so far)", flush=True)
 # the text towers (once per prompt: CLIP-L, and the SDXL pair with the erf-GELU tower and its pooled row)
 from videosd_amd import clip as K
