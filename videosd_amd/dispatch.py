@@ -147,12 +147,18 @@ class _ShmRing:
         return self.shm.buf[o:o + nbytes]
 
     def close(self):
+        # (two steps: `close` raises BufferError while a frame's memoryview is still alive -- a worker that died with frames in
+        #  flight -- and the segment must lose its NAME anyway, or every respawn leaves one behind in /dev/shm until exit)
         try:
             self.shm.close()
-            if self.owner:
-                self.shm.unlink()
         except Exception:
             pass
+        if self.owner:
+            try:
+                self.shm.unlink()
+            except Exception:
+                pass
+            self.owner = False
 
 
 def _image_from_slot(ring: _ShmRing, slot: int, w: int, h: int, copy: bool):
