@@ -3,7 +3,7 @@ tensor), workspaces, frame / output buffers -- ending at (or starting after) an 
 `HipOps.allocator` hook): an out-of-bounds access anywhere in the recorded program takes a GPU memory fault.  Ragged and
 degenerate frame sizes, 1-3 frames per launch, SD1.5 + ControlNet and the mini SDXL topology; every result must equal the
 ordinary engine's bit for bit.
-usage (GPU box): python scripts/guard_page_engine.py [table] [lanes] [b=1,3] [sizes like 8x8 24x40 ...]
+usage (GPU box): python scripts/guard_page_engine.py [table] [lanes] [sdxl] [b=1,3] [sizes like 8x8 24x40 ...]
 (table: the shipped tuning table's kernel forms instead of the heuristic's; lanes: its throughput-mode entries)"""
 import ctypes as C
 import os, subprocess, sys
@@ -41,6 +41,8 @@ def guard_allocator(nbytes):
 def engines(kind):
     if kind == "sd15":
         ucfg, ccfg = Cfg.SD15_UNET, Cfg.SD15_CONTROLNET
+    elif kind == "sdxl":
+        ucfg, ccfg = Cfg.SDXL_UNET, None
     else:
         ucfg, ccfg = Cfg.MINI_SDXL_UNET, None
     wu = W.synthesize(W.unet_spec(ucfg), "unet.", device="cuda")
@@ -61,18 +63,18 @@ def engines(kind):
 
 
 BATCHES = [int(x) for a in sys.argv[1:] if a.startswith("b=") for x in a[2:].split(",")] or [1, 3]
-sizes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:] if "x" in a] or [(8, 8), (16, 8), (24, 40), (72, 40), (104, 88), (200, 136), (360, 640)]
-for kind in ("sd15", "mini"):
+sizes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:] if "x" in a and a[0].isdigit()] or [(8, 8), (16, 8), (24, 40), (72, 40), (104, 88), (200, 136), (360, 640)]
+for kind in (("sdxl",) if "sdxl" in sys.argv else ("sd15", "mini")):
     (ref, grd), cn = engines(kind)
     for (h, w) in sizes:
         for b in BATCHES:
-            if h * w * b > 512 * 512 * 5:
+            if h * w * b > 512 * 512 * 5 and kind != "sdxl":
                 continue
             f = rng.integers(0, 256, (h, w, 3) if b == 1 else (b, h, w, 3), dtype=np.uint8)
             print(f"{kind} {h}x{w} x{b}", flush=True)
             outs = []
             for e in (ref, grd):
-                if kind == "mini":
+                if kind in ("mini", "sdxl"):
                     e.set_added_cond(torch.full((e.ucfg.add_pooled_dim,), 0.25).half(), (h, w, 0, 0, h, w))
                 e.prepare(h, w, 2, 0.6, use_controlnet=cn, use_graph=False, batch=b, autotune=False)
                 outs.append(e.infer_u8(f).copy())
