@@ -92,7 +92,7 @@ for kind in (("sdxl",) if "sdxl" in sys.argv else ("sd15", "mini")):
     print(f"{kind}: ok ({mapped[0] / 2**30:.1f} GB mapped so far)", flush=True)
 # the text towers (once per prompt: CLIP-L, and the SDXL pair with the erf-GELU tower and its pooled row)
 from videosd_amd import clip as K
-for c1, c2 in ((Cfg.MINI_CLIP, K.MINI_CLIP_G), (Cfg.CLIP_L, None)):
+for c1, c2 in ((Cfg.MINI_CLIP, K.MINI_CLIP_G), (Cfg.CLIP_L, None)) + (((K.SDXL_CLIP_L, K.SDXL_CLIP_G),) if "sdxl" in sys.argv else ()):
     got = []
     for hook in (None, guard_allocator):
         ops = plain if hook is None else HipOps(0, make_current=False)
