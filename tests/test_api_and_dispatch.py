@@ -368,3 +368,44 @@ def test_side_stream_policy_is_a_function_of_the_launches_in_flight():
     assert not p._overlap_now(0) and not p._overlap_now(2)   # a third launch: three lanes busy
     p._lanes_busy = [2]
     assert not p._overlap_now(0)                             # lane 0's side stream IS lane 2's stream
+
+
+def test_remote_without_device_takes_the_next_gpu_like_a_ray_actor():
+    """server.py:320-321 writes `VideoSDPipeline.remote(**config)` with no device: Ray's num_gpus=1 (videopipeline.py:11) gives
+    every actor its own GPU.  Here the k-th worker created without `device` gets GPU k (mod the GPU count, resolved in the
+    worker); a respawn keeps the dead worker's GPU; an explicit `device` does not consume an ordinal."""
+    from videosd_amd import dispatch as D
+
+    with RemotePipeline._auto_lock:
+        RemotePipeline._auto_next = 0
+    ws = [RemotePipeline(factory=FAKE, model="m", controlnet="c", wait=False) for _ in range(4)]
+    fixed = RemotePipeline(factory=FAKE, model="m", controlnet="c", device=7, wait=False)
+    late = RemotePipeline(factory=FAKE, model="m", controlnet="c", wait=False)
+    try:
+        tags = [int(np.asarray(w.infer(_img(10), height=12, width=16))[0, 0, 0]) for w in ws + [fixed, late]]
+        assert tags == [0, 1, 2, 3, 7, 4]
+        assert [w.device for w in ws] == ["auto:0", "auto:1", "auto:2", "auto:3"]
+        ws[2] = ws[2].respawn()
+        assert int(np.asarray(ws[2].infer(_img(10), height=12, width=16))[0, 0, 0]) == 2
+        assert asyncio.run(_metrics_of(ws[1]))["device"] == 1
+    finally:
+        for w in ws + [fixed, late]:
+            w.close()
+    # the worker-side rule: ordinal modulo the GPUs the worker sees (this box: none -> a stand-in keeps its ordinal)
+    n = torch.cuda.device_count()
+    assert D.resolve_auto_device({"device": "auto:9"})["device"] == (9 % n if n else 9)
+    assert D.resolve_auto_device({"device": 3})["device"] == 3 and "device" not in D.resolve_auto_device({})
+
+
+async def _metrics_of(w):
+    return await w.metrics.remote()
+
+
+def test_a_prompt_list_is_one_prompt_or_refused():
+    """lcm_controlnet.py:433-438 makes a list a BATCH of prompts; the per-frame path returns one image (videopipeline.py:126-128):
+    a string and the one-element default are the same prompt, anything longer is refused by name (it used to be joined)."""
+    one = VideoSDPipeline._one_prompt
+    assert one("pixar, cg") == one(["pixar, cg"]) == one(("pixar, cg",)) == "pixar, cg"
+    for bad in (["a", "b"], [], [3]):
+        with pytest.raises(ValueError, match="lcm_controlnet.py:433-438"):
+            one(bad)

@@ -429,14 +429,25 @@ __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p
           lo = hi = (f32x4){0.f, 0.f, 0.f, 0.f};
           const float* sp = p.ws_partial + (size_t)row_m(r) * p.N + n;
           const size_t slab_sz = (size_t)p.M * p.N;
-          for (int k = 0; k < p.split_k; ++k) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(sp + k * slab_sz);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(sp + k * slab_sz + 4);
+          // eight slabs per round trip (see load_chunk8 in conv_kernels.h); the additions run in slab order: same bits
+          constexpr int NB = 8;
+          for (int k0 = 0; k0 < p.split_k; k0 += NB) {
+            f32x4 a[NB], b[NB];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              lo[i] += a[i];
-              hi[i] += b[i];
+            for (int k = 0; k < NB; ++k) {
+              const int kk = k0 + k < p.split_k ? k0 + k : 0;
+              a[k] = *reinterpret_cast<const f32x4*>(sp + kk * slab_sz);
+              b[k] = *reinterpret_cast<const f32x4*>(sp + kk * slab_sz + 4);
             }
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+              if (k0 + k < p.split_k) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  lo[i] += a[k][i];
+                  hi[i] += b[k][i];
+                }
+              }
           }
         } else {
           lo = *reinterpret_cast<const f32x4*>(Cs + r * BNP + c8);

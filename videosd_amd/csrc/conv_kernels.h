@@ -322,14 +322,27 @@ __device__ __forceinline__ void load_chunk8(const ConvParams& p, const float* Cs
   const size_t slab = (size_t)p.M * p.N;
   const float* s = p.ws_partial + (size_t)m * p.N + n;
   if (n + 8 <= p.N) {
-    for (int k = 0; k < nparts; ++k) {
-      f32x4 lo = *reinterpret_cast<const f32x4*>(s + k * slab);
-      f32x4 hi = *reinterpret_cast<const f32x4*>(s + k * slab + 4);
+    // Up to 8 slabs per round trip (as splitk_reduce_kernel): the first form's runtime-bounded loop was a chain of `nparts`
+    // dependent memory round trips in the LAST workgroup of every tile -- a 12-way split paid ~12 fabric latencies behind its
+    // ticket, which is why the tuner kept the two-launch form at the deep levels.  Same order of additions: same bits.
+    constexpr int NB = 8;
+    for (int k0 = 0; k0 < nparts; k0 += NB) {
+      f32x4 lo[NB], hi[NB];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        v[i] += lo[i];
-        v[4 + i] += hi[i];
+      for (int k = 0; k < NB; ++k) {
+        const int kk = k0 + k < nparts ? k0 + k : 0;  // (clamped: surplus loads hit slab 0's line again)
+        lo[k] = *reinterpret_cast<const f32x4*>(s + kk * slab);
+        hi[k] = *reinterpret_cast<const f32x4*>(s + kk * slab + 4);
       }
+#pragma unroll
+      for (int k = 0; k < NB; ++k)
+        if (k0 + k < nparts) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] += lo[k][i];
+            v[4 + i] += hi[k][i];
+          }
+        }
     }
   } else {
     for (int k = 0; k < nparts; ++k) {

@@ -214,6 +214,22 @@ class _Stats:
                 "frames_per_launch": round(self.frames / self.launches, 3) if self.launches else None}
 
 
+AUTO_DEVICE = "auto:"
+
+
+def resolve_auto_device(config: Dict[str, Any]) -> Dict[str, Any]:
+    """IN THE WORKER: `device="auto:k"` (what `RemotePipeline` writes when the caller named no device: this is the k-th such
+    worker of its parent) -> GPU k mod the number of GPUs this process sees.  The reference gets the same from Ray:
+    `@ray.remote(num_gpus=1)` (videopipeline.py:11) hands every actor a GPU of its own and the class's `device` default 0
+    (:20) names it INSIDE the actor.  Counting devices does not initialise HIP; the parent never looks at the GPUs at all."""
+    d = config.get("device")
+    if isinstance(d, str) and d.startswith(AUTO_DEVICE):
+        k = int(d[len(AUTO_DEVICE):])
+        n = torch.cuda.device_count()
+        config = dict(config, device=k % n if n > 0 else k)  # (no GPU: a CPU stand-in worker keeps its ordinal)
+    return config
+
+
 def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1, group: Optional[Dict[str, Any]] = None,
                  shm: Optional[Dict[str, Any]] = None, lanes: int = 2):
     """Serve calls in order, like a Ray actor.  With max_batch > 1, `infer` calls that are ALREADY queued behind the one
@@ -227,6 +243,7 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
     rank, world = 0, 1
     dev = torch.device("cpu")
     try:
+        config = resolve_auto_device(config)
         if group is not None:  # join the workers' process group (RCCL on the GPU box, gloo in CPU tests)
             import datetime
 
@@ -491,6 +508,9 @@ class RemotePipeline:
     fails with WorkerDied / CallTimeout, later calls raise at once, and `respawn()` gives a FRESH worker with the same
     configuration (the old process is never re-executed)."""
 
+    _auto_next = 0                 # workers of this process created without `device` so far
+    _auto_lock = threading.Lock()
+
     def __init__(self, factory: str = "videosd_amd.pipeline:VideoSDPipeline", start_timeout: float = 600.0, batch: int = 1,
                  call_timeout: Optional[float] = None, group: Optional[Dict[str, Any]] = None, shm_slots: int = 16,
                  shm_slot_bytes: int = 1024 * 1024 * 3, wait: bool = True, lanes: int = 2, **config):
@@ -500,8 +520,16 @@ class RemotePipeline:
         shm_slots: frames in flight through shared memory (0: always pickle).
         lanes: launches the worker keeps on the GPU at once (engines with their own buffers / graph; default 2: one running,
         one queued behind it while the host prepares the next; 3 also covers the host's own time per launch)."""
+        if "device" not in config:
+            # `VideoSDPipeline.remote(**config)` as server.py:320-321 writes it, no `device`: the next GPU, as Ray's num_gpus=1
+            # gives every actor its own (videopipeline.py:11).  The ordinal is resolved modulo the GPU count IN THE WORKER
+            # (`resolve_auto_device`); a respawn keeps it (`_ctor`), so the replacement takes the dead worker's GPU.
+            with RemotePipeline._auto_lock:
+                config["device"] = f"{AUTO_DEVICE}{RemotePipeline._auto_next}"
+                RemotePipeline._auto_next += 1
         self._ctor = dict(factory=factory, start_timeout=start_timeout, batch=batch, call_timeout=call_timeout,
                           shm_slots=shm_slots, shm_slot_bytes=shm_slot_bytes, lanes=lanes, **config)
+        self.device = config["device"]
         self.lanes = max(1, int(lanes))
         self.group = group
         self.call_timeout = call_timeout

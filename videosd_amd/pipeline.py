@@ -193,11 +193,28 @@ class VideoSDPipeline:
     def encode_prompt(self, prompt: Union[str, List[str]]) -> torch.Tensor:
         """[77, 768] fp16 embeddings.  With CLIP weights + tokenizer files under $VSD_WEIGHTS the HIP CLIP encoder
         runs; otherwise (no vocabulary offline) a deterministic stand-in seeded by the prompt text is used."""
-        text = prompt if isinstance(prompt, str) else " ".join(prompt)
+        text = self._one_prompt(prompt)
         if self.text_encoder is not None and self.text_encoder.has_tokenizer:
             return self._xl_encode(text)[0] if self.is_xl else self.text_encoder.encode(text)
         g = torch.Generator().manual_seed(zlib.crc32(text.encode()))
         return (torch.randn(77, self.unet_cfg.cross_dim, generator=g) * 0.5).half()
+
+    @staticmethod
+    def _one_prompt(prompt: Union[str, List[str]]) -> str:
+        """The ONE prompt of a frame.  The reference hands a list to the tokenizer as a BATCH: `batch_size = len(prompt)`
+        (lcm_controlnet.py:433-438), i.e. a two-element list asks for two images from one input frame -- which its own
+        `infer` cannot return (videopipeline.py:126-128 takes `.images[0]`) and `prepare_latents` cannot build from a single
+        encoded frame without duplicating it.  Every call site of the reference passes a string or the one-element default
+        `["pixar, cg"]` (videopipeline.py:77; server.py:166-171 sets a string): that is what is supported here, and anything
+        else is refused instead of silently meaning something different (rounds 1-4 joined the elements with spaces)."""
+        if isinstance(prompt, str):
+            return prompt
+        items = list(prompt)
+        if len(items) != 1 or not isinstance(items[0], str):
+            raise ValueError(f"prompt must be a string or a one-element list of strings, got {len(items)} element(s): the reference treats "
+                             "a list as a batch of prompts (batch_size = len(prompt), lcm_controlnet.py:433-438), which this per-frame "
+                             "path (one image in, one image out, videopipeline.py:126-128) does not have")
+        return items[0]
 
     def _xl_encode(self, text: str):
         """SDXL: (prompt_embeds [77, 2048], pooled_prompt_embeds [1280]) of both text towers, once per prompt text (the pooled
@@ -212,7 +229,7 @@ class VideoSDPipeline:
     def encode_pooled(self, prompt: Union[str, List[str]]) -> torch.Tensor:
         """SDXL only: the pooled text embedding [1280] = the second tower's `text_embeds` (with both towers' checkpoints and
         tokenizer files present; otherwise a stand-in seeded by the prompt text, like `encode_prompt`)."""
-        text = prompt if isinstance(prompt, str) else " ".join(prompt)
+        text = self._one_prompt(prompt)
         if self.text_encoder is not None and self.text_encoder.has_tokenizer:
             return self._xl_encode(text)[1]
         g = torch.Generator().manual_seed(zlib.crc32(("pooled:" + text).encode()))
