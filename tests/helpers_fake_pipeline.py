@@ -178,3 +178,35 @@ class SessionFakePipeline(FakePipeline):
     def warm_up(self, batches=(1,), lanes=1, **options):
         self.tuning.setdefault(("warmed", tuple(batches), lanes), ("by", self.device))  # a shape this rank "measures" if it has no entry yet
         return len(tuple(batches)) * lanes
+
+
+class NullPipeline(FakePipeline):
+    """A zero-cost 'GPU': every frame's result is one cached image of the asked size (no per-frame pixel work in the worker), so
+    that what remains is the transport -- shared-memory slots, the request / reply pipes, the parent's threads and event loop
+    (scripts/dispatch_ceiling.py: the host-side ceiling of the N-worker product path)."""
+
+    def __init__(self, **config):
+        super().__init__(**config)
+        self._out = {}
+
+    def _image(self, opts):
+        key = (opts.get("width", 640), opts.get("height", 360))
+        img = self._out.get(key)
+        if img is None:
+            a = np.zeros((key[1], key[0], 3), dtype=np.uint8)
+            a[0, 0, 0] = self.device if isinstance(self.device, int) else 0
+            img = self._out[key] = Image.fromarray(a, "RGB")
+        return img
+
+    def infer(self, img, **opts):
+        return self._image(opts)
+
+    def infer_batch(self, imgs, **opts):
+        return [self._image(opts)] * len(imgs)
+
+    def submit_batch(self, imgs, lane=0, **opts):
+        return (len(imgs), opts)
+
+    def collect_batch(self, handle):
+        n, opts = handle
+        return [self._image(opts)] * n

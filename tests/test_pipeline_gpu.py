@@ -333,6 +333,52 @@ def test_side_stream_and_single_stream_sequences_give_the_same_bits(mini_setup):
     assert eng.ops.pool_check() < 1.5  # the four launch streams sit on four different command-processor pipes
 
 
+def test_weight_prefetcher_sequence_gives_the_same_bits_and_always_leaves(mini_setup):
+    """The lone frame's third launch sequence (Engine.launch(prefetch=True); csrc/prefetch.hip): the same kernels and buffers plus
+    ONE read-only kernel on the lane's third stream that walks the frame's weight table behind the conv launches' progress word.
+    Same bits as the other two sequences; the prefetcher touches every entry and says so; a launch on another lane raises its
+    stop word, after which it leaves early (reason 2) -- or had already finished -- and the frames are still the same."""
+    eng, orc, text = mini_setup
+    eng.overlap_controlnet = True
+    eng.prepare(128, 128, 4, 0.6, controlnet_scale=1.5, use_controlnet=True, use_graph=True)
+    assert eng.graph_pf is not None and eng._pf["n"] > 100
+    f = _frame(128, 128, seed=9)
+    a = eng.infer_u8(f)
+    eng.submit_u8(f, overlap=True, prefetch=True)
+    b = eng.collect_u8()
+    rec = eng._pf["words"].cpu().tolist()
+    assert np.array_equal(a, b)
+    assert rec[4] == eng._pf["n"] and rec[5] == 0, rec  # walked the whole table, left because it was done
+    assert 0 < rec[0] < eng._pf["n"]  # the conv launches published their place (the last one's index stays)
+    # the weight table is in program order and covers every conv launch of the frame once
+    idx = [k["progress_idx"] for fn, a_, k in eng.program.calls if fn.__name__ == "conv"]
+    assert sorted(idx) == list(range(eng._pf["n"]))
+    # another lane starts while the prefetching frame runs: stop word, both frames right
+    other = eng.make_slot()
+    other.prepare(128, 128, 4, 0.6, controlnet_scale=1.5, use_controlnet=True)
+    g = _frame(128, 128, seed=10)
+    ref_other = other.infer_u8(g)
+    for _ in range(3):
+        eng.submit_u8(f, overlap=True, prefetch=True)
+        other.submit_u8(g, overlap=False)
+        assert np.array_equal(eng.collect_u8(), a)
+        assert np.array_equal(other.collect_u8(), ref_other)
+        assert eng._pf["words"].cpu().tolist()[5] in (0, 2)
+    # a consumer that never moves (the prefetcher alone, nothing published): it gives up by itself (reason 1), bounded
+    ops = eng.ops
+    pf = eng._pf
+    ops.fill32(pf["words"], 0, 8)
+    ops.fill32(pf["stop"], 0, 1)
+    os.environ["VSD_PF_MIN_ENTRY_KB"] = "0"  # (the mini networks' layers are all below the default threshold)
+    try:
+        ops.prefetch_weights(pf["table"], pf["n"], pf["words"], pf["stop"], 64, 4, stall_ms=2.0, limit_ms=50.0, exit_record=pf["words"][4:])
+        ops.synchronize()
+    finally:
+        del os.environ["VSD_PF_MIN_ENTRY_KB"]
+    rec = pf["words"].cpu().tolist()
+    assert rec[5] == 1 and rec[4] < pf["n"] and rec[6] < 50 * 100000, rec
+
+
 def test_stored_and_live_oracle_comparisons_agree():
     """The full-size cases are compared with the oracle's STORED output (`_compare_golden`), everything else with the live
     oracle (`_compare`).  One small case goes through both in the same test -- same engine, same frame -- so that the two code

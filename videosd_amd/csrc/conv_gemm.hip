@@ -86,10 +86,11 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.ln_eps = d->ln_eps;
   p.ln_s = (const float*)d->ln_s;
   p.ln_t = (const float*)d->ln_t;
+  p.progress = (int*)d->progress;
+  p.progress_idx = d->progress_idx;
   const int stages = d->pipeline;
-  if (stages != 0 && (stages < 3 || stages > 8)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..8)", stages);
+  if (stages != 0 && (stages < 3 || stages > 7)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..7)", stages);
   const bool halo = stages == 7;
-  const bool streamk = stages == 8;
 
   if (!p.src0 || !p.w || !p.out) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: null src/weight/out");
   if (p.M <= 0 || p.N <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: empty problem M=%d N=%d", p.M, p.N);
@@ -116,8 +117,6 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   if (p.ln_part && (p.ksize != 1 || !p.ln_s || !p.ln_t || p.ln_groups <= 0 || p.bias))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: fused LayerNorm needs a 1x1 layer, ln_s/ln_t and no separate bias");
   if (p.split_k > 1 && !p.ws_partial) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: split_k needs a workspace");
-  if (streamk && p.split_k > 1 && !d->counters)
-    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the stream-K form (pipeline 8) shares tiles through slabs + arrival tickets: counters needed");
   int BM, BN;
   switch (d->tile) {
     case VSD_TILE_128x128: BM = 128; BN = 128; break;
@@ -151,48 +150,16 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
                       "1 <= softmax_cols <= 128");
   }
   if (p.out_t && (p.t_col0 % BN)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: t_col0 must be a multiple of BN");
-  if (streamk && (!p.fast || BM > 128))
-    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the stream-K form (pipeline 8) exists for the buffer-load path (Cin %% 64 == 0 per source, "
-                    "no resize) with 64- / 128-row tiles");
   p.tiles_m = halo ? p.batch * cdiv(p.ho, BM / 16) * cdiv(p.wo, 16) : cdiv(p.M, BM);  // halo: 8x16 / 16x16 pixel patches
   p.tiles_n = cdiv(p.N, BN);
   const int KT = halo ? p.cin / BK : p.Kp / BK;  // the halo form splits over channel blocks (each = 9 K tiles)
-  p.sk_units = p.sk_q = 0;
-  p.fd_kt = p.fd_q = fast_div(1u);
-  int sk_grid = 0;
-  if (streamk) {
-    // split_k here = the most parts a tile may be shared among (what the workspace holds slabs for); 1 = whole tiles only.
-    // Grid: as many workgroups as the chip holds at once (LDS-limited), never more than the parts bound allows.
-    int pmax = p.split_k;
-    if ((p.act & 0xff) == VSD_ACT_GEGLU) pmax = 1;  // (its epilogue reads the accumulator tile itself, not slabs)
-    const int tiles = p.tiles_m * p.tiles_n;
-    const long long units = (long long)tiles * KT;
-    if (units >= (1ll << 30)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: stream-K unit count overflow");
-    const int per_cu = 163840 / vsd_streamk_lds_bytes(BM, BN);
-    const int slots = ctx->num_cus * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
-    int q;
-    if (pmax <= 1) {
-      q = KT * cdiv(tiles, slots < tiles ? slots : tiles);
-    } else {
-      const int q_min = pmax == 2 ? KT : cdiv(KT, pmax - 1);
-      q = cdiv((int)units, slots);
-      if (q < q_min) q = q_min;
-    }
-    sk_grid = cdiv((int)units, q);
-    p.sk_units = (int)units;
-    p.sk_q = q;
-    p.fd_kt = fast_div((unsigned)KT);
-    p.fd_q = fast_div((unsigned)q);
-    p.split_k = 1;  // (block_to_tile: tile index -> (tile_m, tile_n))
-    if (pmax <= 1) p.counters = nullptr;
-  }
   if (p.split_k > KT) p.split_k = KT;
   p.kt_per_split = cdiv(KT, p.split_k);
   p.split_k = cdiv(KT, p.kt_per_split);
-  if (p.split_k == 1 && !streamk) p.counters = nullptr;
+  if (p.split_k == 1) p.counters = nullptr;
   if (p.counters && p.tiles_m * p.tiles_n > VSD_SPLITK_MAX_TILES)
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: %d tiles exceed the split-K counter buffer", p.tiles_m * p.tiles_n);
-  const int grid = streamk ? sk_grid : p.tiles_m * p.tiles_n * p.split_k;
+  const int grid = p.tiles_m * p.tiles_n * p.split_k;
   {
     // fabric bytes of the two workgroup orders (see block_to_tile): an operand shared inside an XCD crosses once, the
     // other one once per XCD that needs it
@@ -233,7 +200,6 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   {
     LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
     if (halo) vsd_launch_conv_halo(p, BM, BN, grid, s);
-    else if (streamk) vsd_launch_conv_streamk(p, BM, BN, grid, s);
     else if (BM == 256) vsd_launch_conv_256x128(p, grid, stages, s);
     else if (BM == 128 && BN == 128) vsd_launch_conv_128x128(p, grid, stages, s);
     else if (BM == 128 && BN == 64) vsd_launch_conv_128x64(p, grid, stages, s);

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
 template <int BN, int WMN, int NSB>
 __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p) {
   prefetch_kernargs();
+  publish_progress(p);
   WGTL_START()
   constexpr int NW = 2 * WMN, NT = 64 * NW;
   constexpr int BM = 64 * WMN, PW = 16, PH = 4 * WMN, HW_ = PW + 2;  // halo row length 18

@@ -85,10 +85,17 @@ struct ConvParams {
   // launch constants as multipliers (common.h fdiv): block -> tile (span = 8 S, S, tiles_n: see block_to_tile), output row ->
   // (image, y, x) (hw_out, wo), halo patch -> (image, patch row / column) (tiles per image, patches per row)
   FastDiv fd_span, fd_s, fd_tiles_n, fd_hw_out, fd_wo, fd_tpi, fd_ppr, fd_gx;
-  // persistent stream-K form (conv_streamk.hip): units = tiles * KT in tile-major order, workgroup g owns units [g q, (g + 1) q)
-  int sk_units, sk_q;
-  FastDiv fd_kt, fd_q;
+  // the frame's weight prefetcher (prefetch.hip) stays a bounded distance ahead of the consumer: every launch says where it is
+  int* progress;     // device word (or null)
+  int progress_idx;  // this launch's index in the frame's weight table
 };
+
+// workgroup 0 publishes the launch's place in the frame's weight table as soon as it starts (one relaxed agent-scope store;
+// the prefetcher polls the word, nothing in this launch depends on it)
+__device__ __forceinline__ void publish_progress(const ConvParams& p) {
+  if (p.progress && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(p.progress, p.progress_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 #ifdef VSD_CONV_PROBE
 inline long long* g_conv_probe = nullptr;
@@ -118,8 +125,6 @@ void vsd_launch_conv_64x128(const ConvParams& p, int grid, int stages, hipStream
 void vsd_launch_conv_256x128(const ConvParams& p, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_halo(const ConvParams& p, int bm, int bn, int grid, hipStream_t s);
 void vsd_launch_splitk_reduce(const ConvParams& p, int grid, hipStream_t s);
-void vsd_launch_conv_streamk(const ConvParams& p, int bm, int bn, int grid, hipStream_t s);
-int vsd_streamk_lds_bytes(int bm, int bn);
 
 namespace {
 
@@ -427,6 +432,7 @@ __device__ __forceinline__ void block_to_tile(const ConvParams& p, int bid, int&
 template <int BM, int BN, bool GENERIC, int STAGES, bool ILV, bool FAST>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   prefetch_kernargs();
+  publish_progress(p);
   WGTL_START()
   constexpr int WM = 2, WN = 2;             // 2x2 waves
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile

@@ -165,9 +165,10 @@ def _image_from_slot(ring: _ShmRing, slot: int, w: int, h: int, copy: bool):
     from PIL import Image
 
     mv = ring.view(slot, w * h * 3)
-    if copy:
-        return Image.frombytes("RGB", (w, h), bytes(mv))
-    return Image.frombuffer("RGB", (w, h), mv, "raw", "RGB", 0, 1)  # zero-copy, read-only use
+    # (packed RGB is not Pillow's storage layout -- it keeps 4 bytes per pixel -- so `frombuffer` DECODES the slot into storage of
+    #  the image's own: one pass, with the GIL released, and the slot may be reused as soon as this returns.  `frombytes(bytes(mv))`
+    #  -- the first form -- copied the slot once more in front of the same decode: 0.05 ms of the parent's 0.9 ms per frame.)
+    return Image.frombuffer("RGB", (w, h), mv, "raw", "RGB", 0, 1)
 
 
 def _image_to_slot(ring: _ShmRing, slot: int, img) -> Optional[tuple]:
@@ -177,7 +178,16 @@ def _image_to_slot(ring: _ShmRing, slot: int, img) -> Optional[tuple]:
     n = w * h * 3
     if n > ring.slot_bytes:
         return None
-    ring.view(slot, n)[:] = img.tobytes()
+    # np.asarray(img) packs the pixels in one call (0.26 ms for 512x512 on the build box; `img.tobytes()` goes through the raw
+    # encoder in 64 KB pieces and a join: 0.9 ms -- the largest single item of the parent's per-frame cost in
+    # scripts/dispatch_ceiling.py); the copy into the slot is a numpy memcpy, which runs with the GIL released
+    import numpy as np
+
+    a = np.asarray(img)
+    if a.dtype != np.uint8 or a.shape != (h, w, 3):  # (never for an RGB image; stay correct anyway)
+        ring.view(slot, n)[:] = img.tobytes()
+        return (slot, w, h)
+    np.frombuffer(ring.view(slot, n), dtype=np.uint8)[:] = a.reshape(-1)
     return (slot, w, h)
 
 
@@ -487,6 +497,93 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
             pass
 
 
+class _ReplyHub:
+    """ONE thread reads the reply pipes of every RemotePipeline of the process (multiprocessing.connection.wait over all of
+    them) and hands a whole batch of finished calls to their event loop in ONE wake-up.  Rounds 2-4 gave every worker a reader
+    thread of its own: with 8 workers that is 8 threads + the loop thread taking turns on the interpreter lock around every
+    frame's decode, and one self-pipe write per frame to wake the loop -- scripts/dispatch_ceiling.py measured the parent at 2.6-5
+    ms of CPU per frame with 8 workers where one worker cost it 1.2 (budget at 8 x 137 frames/s: 0.91 ms)."""
+
+    _inst = None
+    _inst_lock = threading.Lock()
+
+    @classmethod
+    def get(cls) -> "_ReplyHub":
+        with cls._inst_lock:
+            if cls._inst is None or not cls._inst._thread.is_alive():
+                cls._inst = _ReplyHub()
+            return cls._inst
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._conns: Dict[Any, "RemotePipeline"] = {}
+        self._wake_r, self._wake_w = mp.Pipe(duplex=False)
+        self._thread = threading.Thread(target=self._loop, daemon=True, name="vsd-reply-hub")
+        self._thread.start()
+
+    def _wake(self):
+        try:
+            self._wake_w.send_bytes(b"x")
+        except (OSError, ValueError):
+            pass
+
+    def add(self, p: "RemotePipeline"):
+        with self._lock:
+            self._conns[p._conn] = p
+        self._wake()
+
+    def remove(self, p: "RemotePipeline"):
+        with self._lock:
+            self._conns.pop(p._conn, None)
+        self._wake()
+
+    def _loop(self):
+        from multiprocessing.connection import wait
+
+        while True:
+            with self._lock:
+                conns = list(self._conns)
+            try:
+                ready = wait(conns + [self._wake_r])
+            except (OSError, ValueError):  # a pipe was closed under the wait: its owner has been removed (or is about to be)
+                time.sleep(0.001)
+                continue
+            batch: Dict[Any, list] = {}
+            for c in ready:
+                if c is self._wake_r:
+                    try:
+                        while self._wake_r.poll(0):
+                            self._wake_r.recv_bytes()
+                    except (EOFError, OSError):
+                        return
+                    continue
+                with self._lock:
+                    p = self._conns.get(c)
+                if p is None:
+                    continue
+                try:
+                    while c.poll(0):
+                        rid, ok, payload = c.recv()
+                        with p._lock:
+                            entry = p._pending.pop(rid, None)
+                        if entry is not None:
+                            p._complete(entry, ok, payload, batch)
+                except (EOFError, OSError, ValueError):
+                    with self._lock:
+                        self._conns.pop(c, None)
+                    p._on_eof()
+            for loop, setters in batch.items():
+                try:
+                    loop.call_soon_threadsafe(_run_setters, setters)  # one wake-up of the loop for the whole batch
+                except RuntimeError:  # the caller's loop is gone
+                    pass
+
+
+def _run_setters(setters):
+    for f in setters:
+        f()
+
+
 class _RemoteMethod:
     def __init__(self, owner: "RemotePipeline", name: str):
         self._owner, self._name = owner, name
@@ -549,10 +646,16 @@ class RemotePipeline:
         self._proc.start()
         child.close()
         self._lock = threading.Lock()
+        self._send_lock = threading.Lock()  # the request pipe has two writers: the writer thread and `_send`'s direct path
+        self._q_lock = threading.Lock()
+        self._queued = 0                    # messages handed to the writer thread and not yet in the pipe
         self._proc_lock = threading.Lock()
         self._next = 0
         self._pending: Dict[int, Any] = {}
         self._ready = False
+        # the PARENT's own seconds per stage of a frame's round trip (scripts/dispatch_ceiling.py; two clock reads per stage):
+        # frame -> request slot, request header -> pipe (writer thread), reply slot -> PIL image, future hand-over to the loop
+        self.host_s = {"slot_write": 0.0, "send": 0.0, "slot_read": 0.0, "complete": 0.0, "frames": 0}
         self.infer = _RemoteMethod(self, "infer")
         self.compile_model = _RemoteMethod(self, "compile_model")
         self.set_prompt_embeds = _RemoteMethod(self, "set_prompt_embeds")
@@ -583,8 +686,7 @@ class RemotePipeline:
         self._outbox: "queue.Queue" = queue.Queue()
         self._writer = threading.Thread(target=self._write_loop, daemon=True)
         self._writer.start()
-        self._reader = threading.Thread(target=self._read_loop, daemon=True)
-        self._reader.start()
+        _ReplyHub.get().add(self)  # replies of every worker of the process are read by one thread
         if self.call_timeout:
             self._watch = threading.Thread(target=self._watch_loop, daemon=True)
             self._watch.start()
@@ -595,18 +697,29 @@ class RemotePipeline:
     def _write_loop(self):
         while True:
             msg = self._outbox.get()
+            t0 = time.perf_counter()
             try:
-                self._conn.send(msg)
+                with self._send_lock:
+                    self._conn.send(msg)
             except (OSError, ValueError, BrokenPipeError):
                 return
+            finally:
+                with self._q_lock:
+                    self._queued -= 1
+            self.host_s["send"] += time.perf_counter() - t0
             if msg is None:
                 return
 
-    def _complete(self, entry, ok, payload):
+    def _complete(self, entry, ok, payload, batch: Optional[Dict[Any, list]] = None):
+        """batch (the reply hub): completions for an event loop are collected per loop and handed over in one wake-up"""
         target, loop, slot, _deadline = entry
+        t0 = time.perf_counter()
         if ok and isinstance(payload, tuple) and payload and payload[0] == "__shm__":
             _, s, w, h = payload
             payload = _image_from_slot(self._rings[1], s, w, h, copy=True)
+            self.host_s["frames"] += 1
+        t1 = time.perf_counter()
+        self.host_s["slot_read"] += t1 - t0
         if slot is not None:
             with self._lock:
                 self._free_slots.append(slot)
@@ -615,13 +728,16 @@ class RemotePipeline:
         else:
             exc = payload if isinstance(payload, BaseException) else _remote_exception(payload[0], payload[1])
             setter = lambda t=target, e=exc: (not t.done()) and t.set_exception(e)  # noqa: E731
-        if loop is not None:
+        if loop is not None and batch is not None:
+            batch.setdefault(loop, []).append(setter)
+        elif loop is not None:
             try:
                 loop.call_soon_threadsafe(setter)
             except RuntimeError:  # the caller's loop is gone
                 pass
         else:
             setter()
+        self.host_s["complete"] += time.perf_counter() - t1
 
     def _fail_all(self, exc: BaseException):
         """The worker is gone: nobody will ever answer the pending calls (callers hung forever)."""
@@ -632,23 +748,15 @@ class RemotePipeline:
         for entry in pending.values():
             self._complete(entry, False, self.death)
 
-    def _read_loop(self):
-        while True:
+    def _on_eof(self):
+        """the reply pipe ended: the worker is gone (called by the reply hub's thread)"""
+        with self._proc_lock:  # (one thread at a time reaps: a concurrent waitpid leaves `exitcode` unset)
             try:
-                rid, ok, payload = self._conn.recv()
-            except (EOFError, OSError, ValueError):
-                with self._proc_lock:  # (one thread at a time reaps: a concurrent waitpid leaves `exitcode` unset)
-                    try:
-                        self._proc.join(timeout=5)  # `exitcode` / `is_alive` are settled when the callers wake up
-                    except Exception:
-                        pass
-                    code = self._proc.exitcode
-                self._fail_all(WorkerDied(f"pipeline worker (pid {self._proc.pid}) died (exit code {code})"))
-                return
-            with self._lock:
-                entry = self._pending.pop(rid, None)
-            if entry is not None:
-                self._complete(entry, ok, payload)
+                self._proc.join(timeout=5)  # `exitcode` / `is_alive` are settled when the callers wake up
+            except Exception:
+                pass
+            code = self._proc.exitcode
+        self._fail_all(WorkerDied(f"pipeline worker (pid {self._proc.pid}) died (exit code {code})"))
 
     def _watch_loop(self):
         """Per-call timeout: a call past its deadline means a hung GPU / worker.  Kill the process (its pending calls
@@ -675,7 +783,9 @@ class RemotePipeline:
             with self._lock:
                 slot = self._free_slots.pop() if self._free_slots else None
             if slot is not None:
+                t0 = time.perf_counter()
                 where = _image_to_slot(self._rings[0], slot, args[0])
+                self.host_s["slot_write"] += time.perf_counter() - t0
                 if where is None:
                     with self._lock:
                         self._free_slots.append(slot)
@@ -693,6 +803,23 @@ class RemotePipeline:
             rid = self._next
             self._next += 1
             self._pending[rid] = (target, loop, slot, deadline)
+        with self._q_lock:
+            direct = slot is not None and self._queued == 0
+            if not direct:
+                self._queued += 1
+        if direct:
+            # a frame that travels through shared memory is a ~200-byte header: far below the pipe's buffer, it cannot block the
+            # caller the way a pickled 0.8 MB frame can (why the writer thread exists) -- written here, the frame costs one thread
+            # hand-over less (scripts/dispatch_ceiling.py).  Only while nothing is queued or being written by the writer thread:
+            # a caller's messages reach the worker in the order it sent them.
+            t0 = time.perf_counter()
+            try:
+                with self._send_lock:
+                    self._conn.send((rid, name, args, kwargs))
+            except (OSError, ValueError, BrokenPipeError):
+                pass  # the reader's EOF path reports the dead worker
+            self.host_s["send"] += time.perf_counter() - t0
+            return
         self._outbox.put((rid, name, args, kwargs))
 
     def _submit(self, name, args, kwargs):
@@ -738,6 +865,8 @@ class RemotePipeline:
     def close(self):
         try:
             if hasattr(self, "_outbox") and not self.dead:
+                with self._q_lock:
+                    self._queued += 1
                 self._outbox.put(None)
                 self._writer.join(timeout=2)
             elif not self.dead:
@@ -754,6 +883,9 @@ class RemotePipeline:
             pass
         self.dead = True
         self.death = self.death or WorkerDied("pipeline worker was closed")
+        hub = _ReplyHub._inst  # (never MAKE a hub here: `close` also runs from __del__ while the interpreter shuts down)
+        if self._ready and hub is not None and hub._thread.is_alive():
+            hub.remove(self)
         if self._rings is not None:
             for r in self._rings:
                 r.close()

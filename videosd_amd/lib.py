@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # VSD_LIB: another build of the same sources (development: the instrumented libvsd_tl.so of build.build_timeline)
 LIB_PATH = os.environ.get("VSD_LIB") or os.path.join(HERE, "libvsd.so")
 
-VERSION = 4  # include/vsd.h VSD_VERSION
+VERSION = 5  # include/vsd.h VSD_VERSION
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_QUICKGELU, ACT_SOFTMAX, ACT_GELU = range(7)
 ACT_POST = 256
 SPLITK_MAX_TILES = 16384
@@ -45,6 +45,7 @@ class ConvDesc(C.Structure):
         ("batch", C.c_int32), ("t_img", C.c_int32),
         ("out_scale_dev", C.c_void_p),
         ("softmax_cols", C.c_int32),
+        ("progress", C.c_void_p), ("progress_idx", C.c_int32),
     ]
 
 
@@ -87,6 +88,9 @@ SIGNATURES = {
     "vsd_embed_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vsd_postprocess_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vsd_axpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]),
+    "vsd_prefetch_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                      C.c_void_p, C.c_void_p]),
+    "vsd_fill32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vsd_graph_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vsd_graph_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "vsd_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -78,11 +78,41 @@ def choose_tile(m: int, n: int, kp: int, geglu: bool = False, t_col0: int = 0):
     return best[1], best[2]
 
 
+class LaneBook:
+    """What the HipOps objects of one process and device share about launch lanes: which lanes have a live object (weak
+    references: a dropped slot gives its lane back), and the helper objects the throughput-mode tuner times candidates with."""
+
+    def __init__(self):
+        import weakref
+
+        self._weakref = weakref
+        self.users = {}          # lane -> WeakSet of HipOps
+        self.tune_helpers = {}   # lane -> HipOps kept for HipOps._time_candidates_on_lanes (made once per process)
+        self.warned = False
+
+    def register(self, ops: "HipOps"):
+        self.users.setdefault(ops.lane, self._weakref.WeakSet()).add(ops)
+
+    def next_free(self) -> int:
+        """the lowest lane no live object runs on; when all four launch streams have one, lanes are shared round-robin (their
+        objects then take turns on a stream: said once, since engines meant to run side by side would not)"""
+        for lane in range(L.POOL_STREAMS):
+            if not len(self.users.get(lane, ())):
+                return lane
+        if not self.warned:
+            self.warned = True
+            import warnings
+
+            warnings.warn(f"HipOps.clone(): all {L.POOL_STREAMS} launch lanes have a live object; further auto-numbered clones share a lane's "
+                          "streams with an existing one and take turns with it (pass lane= to choose)")
+        return min(range(L.POOL_STREAMS), key=lambda l: len(self.users.get(l, ())))
+
+
 class HipOps:
     name = "hip"
 
     def __init__(self, device_id: int = 0, stream: Optional[torch.cuda.Stream] = None, make_current: bool = True,
-                 tile_override: Optional[dict] = None, lane: int = 0, _lanes: Optional[list] = None):
+                 tile_override: Optional[dict] = None, lane: int = 0, _lanes: Optional[LaneBook] = None, _register: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("HipOps needs a ROCm GPU; there is no CPU fallback in the product path")
         self.device = torch.device("cuda", device_id)
@@ -95,16 +125,27 @@ class HipOps:
         # encoder) on stream (l + 2) mod 4: two lanes with side branches, or four lanes without, never share a pipe.
         # VSD_STREAMS=plain takes torch's pool streams instead (A/B measurements only).
         self.lane = int(lane)
-        self._lanes = _lanes if _lanes is not None else [1]  # shared with every clone: the next free lane number
+        self._lanes = _lanes if _lanes is not None else LaneBook()  # shared with every clone
         self._plain = _os.environ.get("VSD_STREAMS") == "plain"
+        # streams[2]: where a LONE frame's weight prefetcher runs (csrc/prefetch.hip) -- the pool stream that neither this lane nor
+        # its side branch uses; it belongs to another lane, so the prefetching launch sequence is only taken while no other
+        # launch is in flight, and any other launch raises the prefetcher's stop word (Engine.launch)
         if stream is not None:
-            self.streams = [stream, torch.cuda.Stream(device=self.device)]
+            self.streams = [stream, torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
         elif self._plain:
-            self.streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         else:
             pool = self.pool_streams()
-            self.streams = [pool[self.lane % L.POOL_STREAMS], pool[(self.lane + 2) % L.POOL_STREAMS]]
+            self.streams = [pool[self.lane % L.POOL_STREAMS], pool[(self.lane + 2) % L.POOL_STREAMS], pool[(self.lane + 3) % L.POOL_STREAMS]]
+            pm = _os.environ.get("VSD_POOL_MASK", "")
+            if pm.startswith("p") and pm[1:].isdigit() and int(pm[1:]) > 0:
+                # experiment (round 5): the prefetcher on compute units of its own -- the launch streams were made without the last
+                # k CUs of every XCD (vsd_stream_pool), this stream has only those; it is the 6th CU-masked stream of the process
+                # (a dummy 5th in front of it), i.e. on command-processor pipe 1, not on lane 0's
+                self.streams[2] = self._pf_stream(int(pm[1:]))
         self.stream = self.streams[0]
+        if _register:  # (the tuner's helper objects do not occupy a lane)
+            self._lanes.register(self)
         # torch-side plumbing (allocation fills, H2D/D2H copies) must be ordered with the kernels: make the
         # kernel stream this thread's current torch stream.
         if make_current:
@@ -117,7 +158,6 @@ class HipOps:
         # 0: kernel choices timed alone (latency), 1: timed with four lanes busy (throughput).  Set by Engine.prepare for the plan
         # it records / captures; part of the tuning key.
         self.tune_mode = 0
-        self._tune_lanes = None
         # timing with four lanes busy takes ~80 s per plan: done offline (scripts/retune_all.py sets this) or on request
         # (VSD_TUNE_LANES=1); a live worker that meets a shape the table has no throughput-mode entry for takes the alone-timed
         # choice (a second or two per plan, as before) instead of stalling a stream for minutes
@@ -126,6 +166,7 @@ class HipOps:
         self.one_launch_bias_us = float(_os.environ.get("VSD_ONE_LAUNCH_BIAS_US", "0.5"))  # tune_conv: see there
         self.no_halo = bool(__import__("os").environ.get("VSD_NO_HALO"))  # debugging: run halo-tuned shapes on the generic ring
         self.default_pipeline = 3
+        self.progress = None  # int32 device word the conv launches publish their weight-table index to (Engine sets it)
         with torch.cuda.stream(self.stream):
             self._counters = [torch.zeros(L.SPLITK_MAX_TILES, dtype=torch.int32, device=self.device) for _ in range(2)]
         with torch.cuda.stream(self.stream):
@@ -138,6 +179,25 @@ class HipOps:
         h = (C.c_void_p * L.POOL_STREAMS)()
         self.ctx.call("vsd_stream_pool", h)
         return [torch.cuda.ExternalStream(int(h[i]), device=self.device) for i in range(L.POOL_STREAMS)]
+
+    _PF_STREAMS = {}
+
+    def _pf_stream(self, k: int):
+        key = (self.device_id, k)
+        st = HipOps._PF_STREAMS.get(key)
+        if st is None:
+            ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            words = (ncu + 31) // 32
+            dummy = C.c_void_p()
+            self.ctx.call("vsd_stream_create", None, 0, C.byref(dummy))  # (all CUs; never used: it takes the queue on pipe 0)
+            mask = (C.c_uint32 * words)()
+            for b in range(ncu):
+                if b // 8 >= ncu // 8 - k:
+                    mask[b // 32] |= 1 << (b % 32)
+            h = C.c_void_p()
+            self.ctx.call("vsd_stream_create", mask, words, C.byref(h))
+            st = HipOps._PF_STREAMS[key] = torch.cuda.ExternalStream(int(h.value), device=self.device)
+        return st
 
     def pool_check(self, chain: int = 100) -> float:
         """time of four frame-like kernel chains on the four launch streams at once / one chain alone: ~1.0 when they run side
@@ -185,16 +245,14 @@ class HipOps:
     def _p(t):
         return None if t is None else C.c_void_p(t.data_ptr())
 
-    def clone(self, lane: Optional[int] = None) -> "HipOps":
+    def clone(self, lane: Optional[int] = None, _register: bool = True) -> "HipOps":
         """Same GPU, own context / scratch, shared tuning table, the streams of launch lane `lane` (default: the next unused
         one): a further frame in flight.  Objects of ONE lane share its streams -- they are meant to take turns (the engines of a
         lane's several plans / batch sizes); objects of different lanes run side by side."""
         if lane is None:
-            lane = self._lanes[0]
-            self._lanes[0] += 1
-        else:
-            self._lanes[0] = max(self._lanes[0], int(lane) + 1)
-        return HipOps(self.device_id, make_current=False, tile_override=self.tile_override, lane=lane, _lanes=self._lanes)
+            lane = self._lanes.next_free()
+        return HipOps(self.device_id, make_current=False, tile_override=self.tile_override, lane=int(lane), _lanes=self._lanes,
+                      _register=_register)
 
     # Debugging hook (scripts/guard_page_engine.py): a callable(nbytes) -> uint8 device tensor.  When set, EVERY buffer this object
     # hands out -- activations (the engine's arena then allocates tensor by tensor), packed weights, uploads, workspaces -- comes
@@ -299,7 +357,7 @@ class HipOps:
     def conv(self, src0, src1, g: Geom, w: PackedConv, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None,
              residual2=None, ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0,
              t_col0=0, tile=None, split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None,
-             ln_eps=1e-5, chanstat_out=None, t_img=0, out_scale_dev=None, softmax_cols=0):
+             ln_eps=1e-5, chanstat_out=None, t_img=0, out_scale_dev=None, softmax_cols=0, progress_idx=None):
         """t_img: with g.batch > 1, columns of out_t per image (image b's pixels start at column b * t_img).
         out_scale_dev: one fp32 in device memory that replaces out_scale at run time (changeable under a captured graph)."""
         m = g.m
@@ -360,12 +418,8 @@ class HipOps:
         d.batch, d.t_img = g.batch, t_img
         d.tile, d.split_k = tile, split_k
         d.pipeline = self.default_pipeline if pipeline is None else pipeline
-        if d.pipeline == 8:
-            # persistent stream-K form (csrc/conv_streamk.hip): split_k = the most parts one tile's K range may be shared among
-            # (the workspace holds that many fp32 slabs); parts meet through arrival tickets, never through the reducer kernel
-            inkernel = True
-            if w.geglu:
-                split_k = d.split_k = 1  # (the GEGLU epilogue reads the accumulator tile itself: whole tiles only)
+        if progress_idx is not None and self.progress is not None:
+            d.progress, d.progress_idx = self._p(self.progress), int(progress_idx)
         if split_k > 1:
             ws = workspace if workspace is not None else self.workspace("splitk", split_k * m * w.n * 4)
             d.workspace = self._p(ws)
@@ -456,26 +510,6 @@ class HipOps:
                     if kwargs.get("rowstat_out") is None and kwargs.get("chanstat_out") is None and not w.tile128:
                         cands.append((t, sp, False, pl))
                     cands.append((t, sp, True, pl))
-        # persistent stream-K form (pipeline 8; buffer-load operand path: Cin % 64 == 0 per source, no resize): the launch's
-        # (tile, K step) units spread evenly over as many workgroups as the chip holds; `sp` = the most parts a tile may be
-        # shared among (1 = whole tiles only: a persistent data-parallel walk)
-        c1_ = kwargs.get("c1", 0) or 0
-        # Measured on MI355X (scripts/streamk_bench.py, 24 layer shapes at 1 and 5 frames per launch): 8-25 % SLOWER than the best
-        # tiled form on every one of them -- these layers run at the LDS-capacity x latency bound of the L2 -> LDS fill, which a
-        # better spread of the same tiles does not move.  So: a parity-tested form, a tuner candidate only
-        # on request (VSD_TUNE_STREAMK=1).
-        sk_ok = (w.cin % 64 == 0 and c1_ % 64 == 0 and (g.hi, g.wi) == (g.hs, g.ws) and bool(_os.environ.get("VSD_TUNE_STREAMK")) and
-                 (kwargs.get("rowstat_out") is None or w.n % 64 == 0))
-        if sk_ok:
-            for t in tiles:
-                if t == L.TILE_256x128:
-                    continue
-                if kwargs.get("out_t") is not None and t_col0 % L.TILE_DIMS[t][1]:
-                    continue
-                for sp in ((1,) if w.geglu else (1, 2, 3, 4, 6)):
-                    if sp > 1 and sp - 1 > kt:
-                        break
-                    cands.append((t, sp, True, 8))
         if halo_ok:  # 16x16 patches (8 waves): half the weight traffic of the 8x16 patch
             for t in (L.TILE_256x128, L.TILE_256x64):
                 bn = L.TILE_DIMS[t][1]
@@ -486,7 +520,7 @@ class HipOps:
                     cands.append((t, sp, False, 7))
                     if sp > 1 and hblocks <= L.SPLITK_MAX_TILES:
                         cands.append((t, sp, True, 7))
-        kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline")}
+        kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline", "progress_idx")}
         table = []
         saved = self.tile_override.pop(key, None)
         if self.tune_mode == 1:
@@ -566,25 +600,38 @@ class HipOps:
     def _time_candidates_on_lanes(self, args, kw, cands, reps, n_lanes: int = 4):
         """us per launch with `n_lanes` copies of the candidate in flight, one per launch lane (captured graphs of `reps`
         launches each, so that the host is out of the picture); every lane has its own input / output / scratch"""
-        if self._tune_lanes is None:
-            self._tune_lanes = [self] + [self.clone(lane=l) for l in range(1, n_lanes)]
-        lanes = self._tune_lanes[:n_lanes]
+        # this object on ITS lane, helpers on the other lanes (one set per process, kept on the shared lane book; an engine on
+        # lane 1-3 that tunes online must not put two copies on its own stream: ADVICE r4)
+        others = [l for l in range(L.POOL_STREAMS) if l != self.lane % L.POOL_STREAMS][:max(0, n_lanes - 1)]
+        for l in others:
+            if l not in self._lanes.tune_helpers:
+                self._lanes.tune_helpers[l] = self.clone(lane=l, _register=False)
+        lanes = [self] + [self._lanes.tune_helpers[l] for l in others]
         for o in lanes:
             o.tune_mode = self.tune_mode
         src0, src1, g, w, out = args[:5]
-        per_lane = [(src0, src1, out)] + [(src0.clone(), None if src1 is None else src1.clone(), out.clone()) for _ in lanes[1:]]
+        # every lane writes its OWN buffers: the output and every other tensor the launch writes (transposed output, second
+        # output, statistics) -- four launches at once into one buffer would time a write conflict, not the candidate
+        writes = ("out2", "out_t", "rowstat_out", "chanstat_out")
+        per_lane = [(src0, src1, out, kw)]
+        for _ in lanes[1:]:
+            kwl = dict(kw)
+            for name in writes:
+                if kwl.get(name) is not None:
+                    kwl[name] = kwl[name].clone()
+            per_lane.append((src0.clone(), None if src1 is None else src1.clone(), out.clone(), kwl))
         table = []
         for (t, sp, ink, pl) in cands:
             graphs = []
             try:
-                for o, (a0, a1, oo) in zip(lanes, per_lane):
+                for o, (a0, a1, oo, kwl) in zip(lanes, per_lane):
                     o.inkernel_splitk = ink
-                    o.conv(a0, a1, g, w, oo, *args[5:], tile=t, split_k=sp, pipeline=pl, **kw)
+                    o.conv(a0, a1, g, w, oo, *args[5:], tile=t, split_k=sp, pipeline=pl, **kwl)
                     o.synchronize()
                     o.graph_begin()
                     try:
                         for _ in range(reps):
-                            o.conv(a0, a1, g, w, oo, *args[5:], tile=t, split_k=sp, pipeline=pl, **kw)
+                            o.conv(a0, a1, g, w, oo, *args[5:], tile=t, split_k=sp, pipeline=pl, **kwl)
                     finally:
                         graphs.append((o, o.graph_end()))
                 best = 1e30
@@ -724,6 +771,33 @@ class HipOps:
 
     def postprocess_rgb(self, img, ld, hw, rgb_u8):
         self.ctx.call("vsd_postprocess_rgb", self._p(img), ld, hw, self._p(rgb_u8), self.s)
+
+    def fill32(self, dst, value: int, count: int = 1):
+        """32-bit fill on the current stream (a memset node under capture)"""
+        self.ctx.call("vsd_fill32", self._p(dst), int(value), int(count), self.s)
+
+    def prefetch_weights(self, table, n, progress, stop, lookahead_kb, workgroups, stall_ms, limit_ms, exit_record=None):
+        """the lone frame's weight prefetcher on the current stream (include/vsd.h vsd_prefetch_weights)"""
+        self.ctx.call("vsd_prefetch_weights", self._p(table), int(n), self._p(progress), self._p(stop), int(lookahead_kb), int(workgroups),
+                      float(stall_ms), float(limit_ms), self._p(exit_record), self.s)
+
+    # ---- the lone frame's weight prefetcher as recorded by the engine (markers `pf_*`: Engine._capture(prefetch=True) only)
+    def pf_reset(self, pf: dict):
+        self.fill32(pf["words"], 0, 8)   # progress word + exit record
+        self.fill32(pf["stop"], 0, 1)
+
+    def pf_launch(self, pf: dict):
+        self.prefetch_weights(pf["table"], pf["n"], pf["words"], pf["stop"], pf["lookahead_kb"], pf["workgroups"], stall_ms=5.0,
+                              limit_ms=200.0, exit_record=pf["words"][4:])
+
+    def pf_signal(self, name: str):
+        self.signal(name)
+
+    def pf_wait(self, name: str):
+        self.wait(name)
+
+    def pf_use_stream(self, idx: int):
+        self.use_stream(idx)
 
     def axpy(self, a, b, scale, n, out):
         self.ctx.call("vsd_axpy", self._p(a), self._p(b), scale, n, self._p(out), self.s)
