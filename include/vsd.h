@@ -50,7 +50,7 @@ enum vsd_family {
   VSD_FAM_ATTENTION = 4, VSD_FAM_ELEMENTWISE = 5, VSD_FAM_COUNT = 6
 };
 
-/* Version of this interface (bumped whenever a struct grows or an entry point is added; round 3 = 3, round 4 = 4, round 5 = 5) and the size in
+/* Version of this interface (bumped whenever a struct grows or an entry point is added; round 3 = 3, round 4 = 4, round 5 = 5: pipeline 8 -- the stream-K form -- left the library) and the size in
  * bytes of vsd_conv_desc as the LIBRARY was built: a caller compares both with its own header before the first call
  * (videosd_amd/lib.py does) instead of passing a short struct to a stale libvsd.so. */
 #define VSD_VERSION 5
@@ -144,10 +144,6 @@ typedef struct vsd_conv_desc {
                              (scores_h = LN(x) (scale K_h Wq_h)^T, one 128-column group per head), the GEMM tile IS the score
                              block of one head and this epilogue turns it into probabilities: cross-attention over the 77
                              text tokens (Attention.forward of attn2 under lcm_controlnet.py:568) as two plain GEMMs. */
-  void* progress;         /* optional: ONE int32 in device memory.  Workgroup 0 of the launch stores progress_idx there when it
-                             starts (relaxed, agent scope): the frame's weight prefetcher (vsd_prefetch_weights) reads it to
-                             stay a bounded distance ahead of the consumer.  Nothing in the launch depends on it. */
-  int32_t progress_idx;
 } vsd_conv_desc;
 #define VSD_SPLITK_MAX_TILES 16384
 
@@ -266,21 +262,6 @@ int vsd_postprocess_rgb(vsd_ctx* ctx, const void* img, int ld, int hw, void* rgb
 
 /* out = a + b * scale   (fp16, n elements, n % 8 == 0) */
 int vsd_axpy(vsd_ctx* ctx, const void* a, const void* b, float scale, int64_t n, void* out, void* stream);
-
-/* ---- a lone frame's weights run ahead of the dependency (csrc/prefetch.hip) -----------------------------------------------
- * The reference's per-layer cuDNN / cuBLAS launches under lcm_controlnet.py:558-577 each start on weights no cache holds (a
- * denoising step streams 2.45 GB of them, ten times the memory-side cache).  ONE kernel per frame, on a launch stream of its
- * own, walks `table` -- n entries {const void* ptr; uint32 bytes; uint32 cum_kb (KiB of all entries before this one)} in the
- * order the frame's conv launches use their weights -- and touches one dword of every 128-byte line, staying at most
- * lookahead_kb ahead of the consumer: `progress` is the device word the conv launches publish their table index to
- * (vsd_conv_desc.progress / progress_idx).  It reads only (exit_record, int32[4], optional: entries touched, exit reason 0 done /
- * 1 consumer stalled / 2 stop / 3 time limit, 10 ns ticks) and every wait is bounded: it leaves when the consumer has not
- * moved for stall_ms, when the word at `stop` (device-readable, e.g. raised by another launch that wants the stream) is
- * non-zero, and after limit_ms (<= 2000) in any case -- a frame never depends on it.                                        */
-int vsd_prefetch_weights(vsd_ctx* ctx, const void* table, int n, const void* progress, const void* stop, int lookahead_kb,
-                         int workgroups, float stall_ms, float limit_ms, void* exit_record, void* stream);
-/* 32-bit fill of `count` words on `stream` (a memset node under capture): the prefetcher's progress / stop words */
-int vsd_fill32(vsd_ctx* ctx, void* dst, int value, int count, void* stream);
 
 /* ---- hipGraph capture / replay (reference intent: compile_model, videopipeline.py:35-47) ----------- */
 int vsd_graph_begin(vsd_ctx* ctx, void* stream);

@@ -16,22 +16,34 @@ def _f(w, name):
     return w[name].float()
 
 
+# fp16-STORAGE emulation (off by default: the oracle is fp32).  When set, the output of every conv / linear / norm layer and the
+# attention probabilities are rounded to fp16 and back -- what ANY fp16 implementation of the path does to its activations (the
+# reference's own fp16 diffusers pipeline included) while accumulating in fp32.  Used to separate "the HIP path differs from the
+# algorithm" from "fp16 storage moves this network's output by that much" on weight sets where the latter is large (the
+# range-stress set: tests/test_pipeline_gpu.py::test_baseline_config2_on_range_stress_weights_matches_oracle).
+EMULATE_FP16 = False
+
+
+def _r(x):
+    return x.half().float() if EMULATE_FP16 else x
+
+
 def conv(w, name, x, stride=1, padding=1):
     b = w.get(name + ".bias")
-    return F.conv2d(x, _f(w, name + ".weight"), None if b is None else b.float(), stride=stride, padding=padding)
+    return _r(F.conv2d(x, _f(w, name + ".weight"), None if b is None else b.float(), stride=stride, padding=padding))
 
 
 def linear(w, name, x):
     b = w.get(name + ".bias")
-    return F.linear(x, _f(w, name + ".weight"), None if b is None else b.float())
+    return _r(F.linear(x, _f(w, name + ".weight"), None if b is None else b.float()))
 
 
 def group_norm(w, name, x, groups, eps):
-    return F.group_norm(x, groups, _f(w, name + ".weight"), _f(w, name + ".bias"), eps)
+    return _r(F.group_norm(x, groups, _f(w, name + ".weight"), _f(w, name + ".bias"), eps))
 
 
 def layer_norm(w, name, x, eps=1e-5):
-    return F.layer_norm(x, (x.shape[-1],), _f(w, name + ".weight"), _f(w, name + ".bias"), eps)
+    return _r(F.layer_norm(x, (x.shape[-1],), _f(w, name + ".weight"), _f(w, name + ".bias"), eps))
 
 
 def timestep_sinusoid(t, dim):
@@ -81,7 +93,7 @@ def attention(w, p, x, ctx, heads):
         return t.view(b, -1, heads, d).transpose(1, 2)
 
     q, k, v = split(q), split(k), split(v)
-    att = torch.softmax(q @ k.transpose(-1, -2) * (d ** -0.5), dim=-1)
+    att = _r(torch.softmax(q @ k.transpose(-1, -2) * (d ** -0.5), dim=-1))
     o = (att @ v).transpose(1, 2).reshape(b, s, c)
     return linear(w, p + ".to_out.0", o)
 

@@ -85,13 +85,21 @@ class OraclePipeline:
     @torch.no_grad()
     def infer(self, img: Image.Image, prompt_embeds: torch.Tensor, height=360, width=640, strength=0.4, steps=20,
               seed=42, controlnet_scale=1.0, use_controlnet=True, keep_trace=False, pooled=None,
-              time_ids=None, ref_image: Image.Image = None) -> Image.Image:
+              time_ids=None, ref_image: Image.Image = None, emulate_fp16: bool = False) -> Image.Image:
         """ref_image: run the reference-only mode of lcm_reference_pipeline.py:855-890 -- no ControlNet (that pipeline
         has none); per step a fresh noise draw for the reference latents (:861-871, taken from the same per-frame-reset
         CPU stream as every other draw of the frame, in call order), a WRITE pass WITHOUT the guidance embedding
         (:875-881 passes no timestep_cond) and the READ pass (:884-891).  The reference latents are the TAESD encoding of
         the reference image (`prepare_ref_latents` :161-209 calls `.latent_dist.sample`, which AutoencoderTiny does not
         have -- one reason this path is dead at v2; the live path's `retrieve_latents` behaviour is used)."""
+        if emulate_fp16:  # (nets.EMULATE_FP16: every layer output rounded to fp16 -- how far fp16 STORAGE alone moves the result)
+            nets.EMULATE_FP16 = True
+            try:
+                return self.infer(img, prompt_embeds, height=height, width=width, strength=strength, steps=steps, seed=seed,
+                                  controlnet_scale=controlnet_scale, use_controlnet=use_controlnet, keep_trace=keep_trace, pooled=pooled,
+                                  time_ids=time_ids, ref_image=ref_image)
+            finally:
+                nets.EMULATE_FP16 = False
         img = center_crop_resize(img, width, height)
         canny = sobel_edges(img, 0.11, 0.8)
         reset_rng(seed)

@@ -38,7 +38,6 @@ eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
 eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half())
 eng.overlap_launch = True
 eng.tune_for_lanes = False
-eng.prefetch_launch = "--no-prefetch" not in argv
 if retune:
     # record the one-frame program once without tuning to learn its conv keys, drop them from the table, prepare again
     eng.prepare(512, 512, 4, 0.6, use_controlnet=use_cn, batch=1, autotune=False, use_graph=False)
@@ -80,13 +79,7 @@ for i in range(40):
     eng.infer_u8(frames[i % 12])
     lat.append((time.perf_counter() - t1) * 1e3)
     gpu.append(getattr(eng, "last_gpu_ms", 0.0))
-pf = getattr(eng, "_pf", None)
-pf_info = None
-if pf is not None and eng.prefetch_launch:
-    rec = pf["words"].cpu().tolist()
-    pf_info = {"entries": pf["n"], "mb": round(pf["bytes"] / 2 ** 20, 1), "walked": rec[4], "touched": rec[7], "exit_reason": rec[5], "ms": round(rec[6] / 1e5, 3),
-               "lookahead_mb": eng.pf_lookahead_mb, "workgroups": eng.pf_workgroups}
-out = {"tag": tag, "prefetch": pf_info, "controlnet": use_cn, "retune": retune, "table_entries_loaded": n_loaded, "prepare_s": round(prepare_s, 2),
+out = {"tag": tag, "controlnet": use_cn, "retune": retune, "table_entries_loaded": n_loaded, "prepare_s": round(prepare_s, 2),
        "p50_ms": round(statistics.median(lat), 3), "min_ms": round(min(lat), 3), "gpu_p50_ms": round(statistics.median(gpu), 3),
        "n_ops": plan["n_ops"], "launches_by_kind": kinds, "graphs": plan.get("graphs"), "edges": plan.get("edges")}
 

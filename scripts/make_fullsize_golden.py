@@ -72,6 +72,43 @@ if only == "mini64":
     sys.exit(0)
 del orc, wu, wc
 
+
+def stress512(case="stress512"):
+    """BASELINE configs[1] on the range-stress weight sets (tests/golden_guard.py CASES["stress512"] / ["stress512m"])"""
+    c = G.CASES[case]
+    t0 = time.time()
+    wu = _cpu(W.synthesize(W.unet_spec(C.SD15_UNET), "unet.", device="cuda", stress=c["stress"]))
+    wc = _cpu(W.synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", device="cuda", stress=c["stress"]))
+    wv = _cpu(W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda"))
+    text = (torch.randn(77, C.SD15_UNET.cross_dim, generator=torch.Generator().manual_seed(c["text_seed"])) * 0.5).half()
+    orc = OraclePipeline(C.SD15_UNET, C.SD15_CONTROLNET, wu, wc, wv)
+    img = np.asarray(orc.infer(Image.fromarray(_frame(c["H"], c["W"], seed=c["frame_seed"]), "RGB"), text[None].float(), height=c["H"],
+                               width=c["W"], strength=c["strength"], steps=c["steps"], seed=23, controlnet_scale=c["cn_scale"],
+                               use_controlnet=True, keep_trace=True))
+    res[case + "_image_half"] = img[::2, ::2].copy()
+    res[case + "_denoised"] = orc.trace["denoised"][-1][0].half().numpy()
+    res[case + "_init_latents"] = orc.trace["init_latents"][0].half().numpy()
+    den = orc.trace["denoised"][-1][0]
+    # ... and the same frame with every layer output rounded to fp16 (oracle.nets.EMULATE_FP16): how far fp16 STORAGE alone moves
+    # this network's output on these weights -- the yardstick the HIP path is held against on this set
+    img16 = np.asarray(orc.infer(Image.fromarray(_frame(c["H"], c["W"], seed=c["frame_seed"]), "RGB"), text[None].float(), height=c["H"],
+                                 width=c["W"], strength=c["strength"], steps=c["steps"], seed=23, controlnet_scale=c["cn_scale"],
+                                 use_controlnet=True, keep_trace=True, emulate_fp16=True))
+    den16 = orc.trace["denoised"][-1][0]
+    res[case + "_fp16emu_denoised"] = den16.half().numpy()
+    res[case + "_fp16emu_image_half"] = img16[::2, ::2].copy()
+    d16 = np.abs(img16.astype(int) - img.astype(int))
+    print(f"{case} fp16-storage emulation vs fp32: denoised rel-L2 {float((den16 - den).norm() / den.norm()):.3e}, image mean |diff| {d16.mean():.2f} LSB", flush=True)
+    print(f"{case}: {time.time() - t0:.0f} s; denoised latents mean {float(den.mean()):.3f} std {float(den.std()):.3f} max |x| {float(den.abs().max()):.2f}; "
+          f"image mean {img.mean():.1f} std {img.std():.1f}", flush=True)
+
+
+if only in ("stress512", "stress512m", "stress"):
+    for case in (("stress512", "stress512m") if only == "stress" else (only,)):
+        stress512(case)
+    save()
+    sys.exit(0)
+
 wv = _cpu(W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda"))
 
 t0 = time.time()
@@ -109,4 +146,6 @@ img = np.asarray(orc.infer(Image.fromarray(_frame(H, W_, seed=2), "RGB"), text[N
 res["sdxl1024_image_half"] = img[::2, ::2].copy()
 res["sdxl1024_denoised"] = orc.trace["denoised"][-1][0].half().numpy()
 print(f"SDXL 1024x1024 4-step: {time.time() - t0:.0f} s", flush=True)
+stress512("stress512")
+stress512("stress512m")
 save()

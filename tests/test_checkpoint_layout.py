@@ -25,7 +25,18 @@ def test_find_snapshot_takes_a_directory_or_the_newest_revision_in_the_hf_cache(
     new.mkdir(parents=True)
     os.utime(old, (1, 1))
     monkeypatch.setenv("HF_HUB_CACHE", str(cache))
+    assert CK.find_snapshot("SimianLuo/LCM_Dreamshaper_v7") == str(new)  # no refs/: the newest snapshot
+    # ... but `from_pretrained` resolves refs/main: with a ref the OLDER revision it names wins over the newest directory
+    refs = cache / "models--SimianLuo--LCM_Dreamshaper_v7" / "refs"
+    refs.mkdir()
+    (refs / "main").write_text("aaaa\n")
+    assert CK.find_snapshot("SimianLuo/LCM_Dreamshaper_v7") == str(old)
+    (refs / "main").write_text("cccc")  # a ref to a revision that is not cached: back to the newest
     assert CK.find_snapshot("SimianLuo/LCM_Dreamshaper_v7") == str(new)
+    (refs / "pinned").write_text("aaaa")
+    monkeypatch.setenv("VSD_HF_REVISION", "pinned")
+    assert CK.find_snapshot("SimianLuo/LCM_Dreamshaper_v7") == str(old)
+    monkeypatch.delenv("VSD_HF_REVISION")
     assert CK.find_snapshot("lllyasviel/control_v11p_sd15_canny") is None  # not cached: never downloaded, the caller falls back
     assert CK.find_snapshot(None) is None and CK.find_snapshot("") is None
 

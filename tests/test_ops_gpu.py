@@ -111,32 +111,12 @@ def test_conv3x3_all_tiles_splitk(ops, tile, split_k, pipeline):
     check(got, ref, f"conv3x3 tile={tile} split={split_k} pipeline={pipeline}")
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
-@pytest.mark.parametrize("parts", [1, 2, 3, 5])
-@pytest.mark.parametrize("ksize,h,w,cin,cout", [(1, 40, 37, 320, 200), (3, 18, 14, 128, 192), (1, 9, 7, 1280, 136)])
-def test_streamk_persistent_form_matches_the_tiled_kernel_bit_for_bit(ops, tile, parts, ksize, h, w, cin, cout):
-    """Pipeline 8 (csrc/conv_streamk.hip): the launch's (tile, K step) units spread over a fixed grid of workgroups, tiles
-    whose K range is shared finished through fp32 slabs + arrival tickets in part order.  Ragged M and N, 1x1 and 3x3, short
-    and long K, whole tiles only (parts = 1) and shared tiles.  Against the fp32 reference, and -- for unshared tiles -- bit
-    for bit against the one-tile-per-workgroup kernel (same MFMA order over K)."""
-    x = rnd(1, cin, h, w, seed=1)
-    wt = rnd(cout, cin, ksize, ksize, seed=2, scale=(cin * ksize * ksize) ** -0.5)
-    b = rnd(cout, seed=3, scale=0.1)
-    rv = rnd(cout, seed=4, scale=0.1)
-    res = rnd(h * w, cout, seed=5)
-    got, ref = run_conv(ops, [x], h, w, wt, b, ksize=ksize, tile=tile, split_k=parts, rowvec=rv, residual=res, act=2, pipeline=8)
-    check(got, ref, f"stream-K tile={tile} parts={parts} k={ksize}")
-    again, _ = run_conv(ops, [x], h, w, wt, b, ksize=ksize, tile=tile, split_k=parts, rowvec=rv, residual=res, act=2, pipeline=8)
-    assert torch.equal(got, again)  # deterministic whatever the arrival order
-    if parts == 1:
-        base, _ = run_conv(ops, [x], h, w, wt, b, ksize=ksize, tile=tile, split_k=1, rowvec=rv, residual=res, act=2, pipeline=3)
-        assert torch.equal(got, base)
-    assert int(ops._counters[0].abs().sum()) == 0  # every shared tile's arrival counter is back at zero
-
-
-def test_streamk_on_a_launch_larger_than_the_chip(ops):
-    """More tiles than resident workgroup slots: every workgroup walks several tiles (the persistent loop: next segment's
-    first K tile in flight under the current epilogue), concat sources, batch of images, LayerNorm-consuming + row statistics."""
+def test_splitk_in_the_launch_on_a_grid_larger_than_the_chip(ops):
+    """More workgroups than resident slots (20 480 rows): the in-launch split-K hand-over (slabs + arrival tickets, the last
+    arriver sums eight slabs per round trip and runs the straight-line epilogue walk) with row statistics on the producer and a
+    LayerNorm-consuming qkv projection with a transposed V^T on the consumer; the interleaved pipeline gives the same bits as the
+    plain ring, the split forms agree with the fp32 reference.  (Round 4's persistent stream-K form had this test; the form left
+    the library in round 5.)"""
     from videosd_amd.ops import Geom
     from videosd_amd.packing import pack_linear, pack_linear_ln
 
@@ -146,7 +126,7 @@ def test_streamk_on_a_launch_larger_than_the_chip(ops):
     w0, b0 = rnd(c, c, seed=3, scale=c ** -0.5), rnd(c, seed=4, scale=0.1)
     p0 = ops.to_device_pack(pack_linear(w0, b0))
     outs = []
-    for pl, sp in ((3, 1), (8, 1), (8, 3)):
+    for pl, sp in ((3, 1), (5, 1), (3, 3)):
         h = torch.zeros(m, c, dtype=torch.float16, device="cuda")
         rs = torch.zeros(m, c // 64, 2, dtype=torch.float32, device="cuda")
         ops.conv(x.cuda(), None, Geom.linear(m), p0, h, residual=res.cuda(), rowstat_out=rs, split_k=sp, tile=3, pipeline=pl)
@@ -154,8 +134,8 @@ def test_streamk_on_a_launch_larger_than_the_chip(ops):
         check(h, F.linear(x.float(), w0.float(), b0.float()) + res.float(), f"producer pipeline={pl} parts={sp}")
         outs.append((h.cpu(), rs.cpu()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    # (parts = 3: tiles at the workgroup boundaries are shared -- their fp32 partial sums are grouped differently from the
-    #  one-pass accumulation, so those rows agree to rounding, not bit for bit; checked against the reference above)
+    # (split 3: the fp32 partial sums are grouped differently from the one-pass accumulation, so the rows agree to rounding, not
+    #  bit for bit; checked against the reference above)
     hq = outs[0][0].float()
     gamma, beta = (1 + 0.1 * rnd(c, seed=5).float()).half(), rnd(c, seed=6, scale=0.1)
     ln = F.layer_norm(hq, (c,), gamma.float(), beta.float(), 1e-5)
@@ -163,7 +143,7 @@ def test_streamk_on_a_launch_larger_than_the_chip(ops):
     pq = ops.to_device_pack(pack_linear_ln([wq, wk, wv], None, gamma, beta))
     ldt = m
     got = []
-    for pl, sp in ((3, 1), (8, 1), (8, 2)):
+    for pl, sp in ((3, 1), (5, 1), (3, 2)):
         qk = torch.zeros(m, 2 * c, dtype=torch.float16, device="cuda")
         vt = torch.zeros(c, ldt, dtype=torch.float16, device="cuda")
         ops.conv(outs[0][0].cuda(), None, Geom.linear(m), pq, qk, ldo=2 * c, out_t=vt, ldt=ldt, t_col0=2 * c, ln_part=outs[0][1].cuda(),

@@ -307,6 +307,53 @@ def test_baseline_config2_512_four_step_matches_oracle(sd15_setup):
     eng.prepare(H, W, 4, 0.6, controlnet_scale=1.0, use_controlnet=True, batch=1)
 
 
+@pytest.mark.parametrize("case", ["stress512m", "stress512"])
+def test_baseline_config2_on_range_stress_weights_matches_oracle(case):
+    """BASELINE configs[1] (512x512, 4 steps, ControlNet) on the RANGE-STRESS weight sets (weights.synthesize(stress=1 / 2)): what
+    trained SD1.5 tensors look like and N(0, 1/fan_in) does not -- per-output-channel scales over one / two decades, 0.5 % outlier
+    channels 8 x / 30 x larger, GroupNorm / LayerNorm gamma away from 1 with beta ~ 0.3 N, and (level 2) attention logits pushed to
+    +-30.  Every parity number of this suite used to be on the plain set.
+    The yardstick: on these weights fp16 STORAGE alone moves the network's output (the oracle with every layer output rounded to
+    fp16, oracle.nets.EMULATE_FP16, against the fp32 oracle: stored beside the fp32 answer) -- by 27 % of the denoised latents on the
+    level-2 set, where peaked softmax rows turn rounding differences into different attention; any fp16 pipeline, the reference's own
+    included, moves that much there.  The HIP path must be finite and at most 1.5 x that far from the fp32 oracle (and, where the
+    yardstick is below the plain set's tolerance, within the plain tolerance)."""
+    from videosd_amd import config as C
+    from videosd_amd import weights as W
+    from videosd_amd.engine import Engine
+    from videosd_amd.ops import HipOps
+
+    c = GOLDEN_CASES[case]
+    wu = W.synthesize(W.unet_spec(C.SD15_UNET), "unet.", device="cuda", stress=c["stress"])
+    wc = W.synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", device="cuda", stress=c["stress"])
+    wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda")
+    text = (torch.randn(77, C.SD15_UNET.cross_dim, generator=torch.Generator().manual_seed(c["text_seed"])) * 0.5).half()
+    ops = HipOps(0)
+    ops.load_tuning(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tuning_mi355x.json"))
+    eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
+    eng.set_text_embeds(text)
+    H, W_ = c["H"], c["W"]
+    eng.prepare(H, W_, c["steps"], c["strength"], controlnet_scale=c["cn_scale"], use_controlnet=True)
+    frame = _frame(H, W_, seed=c["frame_seed"])
+    r0, r1, mad, psnr, got = _compare_golden(eng, frame, H, W_, case)
+    with np.load(GOLDEN_FULLSIZE) as z:
+        ref = torch.from_numpy(z[case + "_denoised"]).float()
+        emu = torch.from_numpy(z[case + "_fp16emu_denoised"]).float()
+        mad_emu = float(np.abs(z[case + "_fp16emu_image_half"].astype(int) - z[case + "_image_half"].astype(int)).mean())
+    r1_emu = float((emu - ref).norm() / ref.norm())
+    den = eng.buffers["denoised"][:, :4].float()
+    assert bool(torch.isfinite(den).all()), "non-finite latents on the stress weights"
+    assert r0 <= 5e-3, r0
+    assert r1 <= max(2e-2, 1.5 * r1_emu) and mad <= max(1.5, 1.5 * mad_emu), (case, r1, r1_emu, mad, mad_emu, psnr)
+    # five frames per launch (the bench's plan, throughput-mode kernels): frame 0 is the same frame, as close to the one-frame
+    # result as fp16 storage allows on this set
+    eng.tune_for_lanes = True
+    eng.prepare(H, W_, c["steps"], c["strength"], controlnet_scale=c["cn_scale"], use_controlnet=True, batch=5)
+    out = eng.infer_u8(np.stack([frame] + [_frame(H, W_, seed=s) for s in (72, 73, 74, 75)]))
+    d = np.abs(out[0].astype(int) - got.astype(int))
+    assert d.mean() <= max(0.5, 1.5 * mad_emu), (case, d.mean(), mad_emu)
+
+
 def test_side_stream_and_single_stream_sequences_give_the_same_bits(mini_setup):
     """Every engine is captured twice (Engine._capture): the ControlNet encoder on the lane's side stream (graphs + event
     edges) and everything on the lane's own stream (one graph).  Same kernels, same buffers: the frame must not depend on
@@ -331,52 +378,6 @@ def test_side_stream_and_single_stream_sequences_give_the_same_bits(mini_setup):
         other.collect_u8()
     eng.overlap_launch = True
     assert eng.ops.pool_check() < 1.5  # the four launch streams sit on four different command-processor pipes
-
-
-def test_weight_prefetcher_sequence_gives_the_same_bits_and_always_leaves(mini_setup):
-    """The lone frame's third launch sequence (Engine.launch(prefetch=True); csrc/prefetch.hip): the same kernels and buffers plus
-    ONE read-only kernel on the lane's third stream that walks the frame's weight table behind the conv launches' progress word.
-    Same bits as the other two sequences; the prefetcher touches every entry and says so; a launch on another lane raises its
-    stop word, after which it leaves early (reason 2) -- or had already finished -- and the frames are still the same."""
-    eng, orc, text = mini_setup
-    eng.overlap_controlnet = True
-    eng.prepare(128, 128, 4, 0.6, controlnet_scale=1.5, use_controlnet=True, use_graph=True)
-    assert eng.graph_pf is not None and eng._pf["n"] > 100
-    f = _frame(128, 128, seed=9)
-    a = eng.infer_u8(f)
-    eng.submit_u8(f, overlap=True, prefetch=True)
-    b = eng.collect_u8()
-    rec = eng._pf["words"].cpu().tolist()
-    assert np.array_equal(a, b)
-    assert rec[4] == eng._pf["n"] and rec[5] == 0, rec  # walked the whole table, left because it was done
-    assert 0 < rec[0] < eng._pf["n"]  # the conv launches published their place (the last one's index stays)
-    # the weight table is in program order and covers every conv launch of the frame once
-    idx = [k["progress_idx"] for fn, a_, k in eng.program.calls if fn.__name__ == "conv"]
-    assert sorted(idx) == list(range(eng._pf["n"]))
-    # another lane starts while the prefetching frame runs: stop word, both frames right
-    other = eng.make_slot()
-    other.prepare(128, 128, 4, 0.6, controlnet_scale=1.5, use_controlnet=True)
-    g = _frame(128, 128, seed=10)
-    ref_other = other.infer_u8(g)
-    for _ in range(3):
-        eng.submit_u8(f, overlap=True, prefetch=True)
-        other.submit_u8(g, overlap=False)
-        assert np.array_equal(eng.collect_u8(), a)
-        assert np.array_equal(other.collect_u8(), ref_other)
-        assert eng._pf["words"].cpu().tolist()[5] in (0, 2)
-    # a consumer that never moves (the prefetcher alone, nothing published): it gives up by itself (reason 1), bounded
-    ops = eng.ops
-    pf = eng._pf
-    ops.fill32(pf["words"], 0, 8)
-    ops.fill32(pf["stop"], 0, 1)
-    os.environ["VSD_PF_MIN_ENTRY_KB"] = "0"  # (the mini networks' layers are all below the default threshold)
-    try:
-        ops.prefetch_weights(pf["table"], pf["n"], pf["words"], pf["stop"], 64, 4, stall_ms=2.0, limit_ms=50.0, exit_record=pf["words"][4:])
-        ops.synchronize()
-    finally:
-        del os.environ["VSD_PF_MIN_ENTRY_KB"]
-    rec = pf["words"].cpu().tolist()
-    assert rec[5] == 1 and rec[4] < pf["n"] and rec[6] < 50 * 100000, rec
 
 
 def test_stored_and_live_oracle_comparisons_agree():

@@ -296,3 +296,35 @@ def test_rank0_tuning_choices_reach_every_rank():
     finally:
         for w in ws:
             w.close()
+
+
+@pytest.mark.gpu
+def test_rccl_member_killed_mid_sync_leaves_the_survivor_serving_past_the_group_timeout():
+    """the RCCL path of `abandon_group` (communicator abort through torch's process-group backend) had only ever run on
+    gloo.  Two workers on two GPUs in one RCCL group; rank 1 dies; a prompt sync is then posted to rank 0 ANYWAY (the race the
+    dispatcher's liveness check cannot close): its broadcast has no peer, ends at `sync_timeout`, the communicator is aborted (or,
+    if this torch cannot, the watchdog is told to stand down and the worker says so), the prompt is encoded locally -- and the
+    survivor still serves frames after the group timeout has passed.  Needs two GPUs: skipped on the one-GPU box."""
+    import time
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL group of two workers)")
+    ws = spawn_workers(2, factory=SESSION, backend="nccl", model="m", controlnet="c", delay=0.01, call_timeout=60.0, sync_timeout=3.0,
+                       group_timeout=12.0, crash_on=66)
+    try:
+        r = [w.sync_prompt.remote("a red fox", {"height": 12}) for w in ws]
+        assert all(f.result(timeout=60)["via"] == "nccl" for f in r)
+        with pytest.raises(WorkerDied):
+            ws[1].infer(_img(66), **OPTS)
+        t0 = time.time()
+        rep = ws[0].sync_prompt.remote("a blue whale", {"height": 12}).result(timeout=40)
+        assert rep["via"] == "local-after-failed-sync" and time.time() - t0 < 15.0, rep
+        assert "abandon" in rep and (rep["abandon"].get("aborted") or rep["abandon"].get("why")), rep
+        time.sleep(14.0)  # past the group timeout: a watchdog that still saw the abandoned collective would have killed rank 0
+        out = ws[0].infer(_img(20), prompt="a blue whale", **OPTS)
+        assert out.size == (16, 12) and not ws[0].dead
+    finally:
+        for w in ws:
+            w.close()

@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libvsd.so")
 # the implicit-GEMM conv kernel is a template with ~60 instantiations: one translation unit per tile family, so that
 # the families compile in parallel (as one file the library took 4.5 minutes to build)
 SOURCES = ["api.hip", "conv_gemm.hip", "conv_t128x128.hip", "conv_t128x64.hip", "conv_t64x64.hip", "conv_t64x128.hip",
-           "conv_t256x128.hip", "conv_halo.hip", "prefetch.hip", "fused_tail.hip", "norm.hip", "attention.hip", "elementwise.hip", "prompt_fold.hip"]
+           "conv_t256x128.hip", "conv_halo.hip", "fused_tail.hip", "norm.hip", "attention.hip", "elementwise.hip", "prompt_fold.hip"]
 HEADERS = ["common.h", "conv_kernels.h", "conv_epilogue.inc", os.path.join("..", "..", "include", "vsd.h")]
 # attention keeps its O / S accumulators live across the key loop and touches them with VALU every tile (online-softmax
 # rescale, exp): with the default AGPR placement the compiler moves them through v_accvgpr_read/write every tile
@@ -101,6 +101,9 @@ def build_timeline(verbose: bool = False) -> str:
     for f in SOURCES:
         o = os.path.join(HERE, "build", "tl_" + f.replace(".hip", ".o"))
         objs.append(o)
+        deps = [os.path.join(CSRC, f)] + [os.path.join(CSRC, h) for h in HEADERS]
+        if os.path.exists(o) and all(os.path.getmtime(d) <= os.path.getmtime(o) for d in deps):
+            continue  # (up to date)
         procs.append((subprocess.Popen([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-DVSD_WG_TIMELINE", "-w"] +
                                        EXTRA_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", o]), f))
     for p, f in procs:

@@ -22,7 +22,7 @@ def load_safetensors(path: str, device="cpu", dtype=torch.float16) -> Dict[str, 
 # ------------------------------------------------------------------------------------------ `from_pretrained` layouts
 def find_snapshot(name) -> Optional[str]:
     """The directory a `from_pretrained(name)` call of the reference would read (videopipeline.py:51-69), offline: `name` itself
-    when it is a directory, else the newest snapshot of that hub id in the local Hugging Face cache
+    when it is a directory, else the snapshot `refs/main` names (the newest one when there is no ref) of that hub id in the local Hugging Face cache
     (`$HF_HUB_CACHE`, `$HF_HOME/hub`, `~/.cache/huggingface/hub`: `models--<org>--<repo>/snapshots/<rev>/`), else None
     (there is no network here: nothing is ever downloaded)."""
     if not name:
@@ -36,12 +36,23 @@ def find_snapshot(name) -> Optional[str]:
     for root in roots:
         if not root:
             continue
-        snaps = os.path.join(root, "models--" + name.replace("/", "--"), "snapshots")
+        repo = os.path.join(root, "models--" + name.replace("/", "--"))
+        snaps = os.path.join(repo, "snapshots")
         if os.path.isdir(snaps):
+            # what `from_pretrained` resolves: the commit `refs/<revision>` names (main unless $VSD_HF_REVISION says otherwise) --
+            # with several cached revisions the newest directory is not necessarily the one the reference would load
+            ref = os.path.join(repo, "refs", os.environ.get("VSD_HF_REVISION", "main"))
+            if os.path.isfile(ref):
+                try:
+                    rev = open(ref).read().strip()
+                except OSError:
+                    rev = ""
+                if rev and os.path.isdir(os.path.join(snaps, rev)):
+                    return os.path.join(snaps, rev)
             revs = [os.path.join(snaps, r) for r in os.listdir(snaps)]
             revs = [r for r in revs if os.path.isdir(r)]
             if revs:
-                return max(revs, key=os.path.getmtime)
+                return max(revs, key=os.path.getmtime)  # (no usable ref: the newest snapshot)
     return None
 
 

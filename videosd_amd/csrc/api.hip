@@ -168,12 +168,6 @@ extern "C" int vsd_stream_pool(vsd_ctx* ctx, void** streams_out) {
           const bool on = mode[0] == 'x' ? (b % 8) / 2 == i : b * VSD_POOL_STREAMS / ncu == i;
           if (on) m[(size_t)b / 32] |= 1u << (b % 32);
         }
-      } else if (mode && mode[0] == 'p') {
-        // "p<k>" (round 5, the weight prefetcher's experiment): every launch stream gives up the LAST k compute units of every
-        // XCD (mask bit b = CU b / 8 of XCD b % 8); a stream made with exactly those bits has them to itself
-        const int k = atoi(mode + 1);
-        for (int b = 0; b < ncu; ++b)
-          if (b / 8 >= ncu / 8 - k) m[(size_t)b / 32] &= ~(1u << (b % 32));
       }
       VSD_HIP(ctx, hipExtStreamCreateWithCUMask(&g_pool[ctx->device][i], (uint32_t)m.size(), m.data()));
     }

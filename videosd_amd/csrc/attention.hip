@@ -41,6 +41,7 @@ struct AttnParams {
   float scale_log2;  // scale * log2(e)
   int causal;
   int k_brows, vt_bcols;  // batch (blockIdx.z): image b reads K rows from b*k_brows and V^T columns from b*vt_bcols
+  VSD_CUT_FIELD
 #ifdef VSD_ATTN_PROBE
   long long* probe;  // scripts/attn_probe.cpp: per-section shader-clock totals of wave 0 of workgroup 0
 #endif
@@ -60,9 +61,6 @@ long long* g_probe = nullptr;
 
 constexpr float NEG_BIG = -1.0e30f;
 
-#ifndef VSD_ATTN_WEAVE
-#define VSD_ATTN_WEAVE 0
-#endif
 #ifndef VSD_ATTN_PV_PRIO
 #define VSD_ATTN_PV_PRIO 3
 #endif
@@ -72,13 +70,16 @@ __device__ __forceinline__ float xhalf_max(float x) {  // max over the two half-
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// (Round 4's two experiment bodies -- the PV MFMAs woven into the exponentials, -DVSD_ATTN_WEAVE, and a forced fourth wave per SIMD,
+//  -DVSD_ATTN_WAVES -- measured -2 ... -5 % / +60 % and left this file in round 5: scripts/attic/attention_weave.inc keeps the woven
+//  body, profiles/round4_attention_weave.txt the ISA listing and the numbers.  Round 5 looked at the VALU stream itself
+//  (profiles/round5_attention_valu.txt): per 64-key tile a wave issues 33 v_sub + 33 v_exp + 17 v_max3 + 16 v_cvt_pk; the scale is
+//  already folded into Q, the row sums already come out of the PV MFMA (the ones row below), O is already rescaled only when a
+//  maximum moved; the max-subtract as 16 v_pk_add_f32 measured 9-34 % SLOWER (the compiler no longer shares the two row-sum
+//  branches' code, 174 registers) and was not kept.)
 template <int NQK, int NPV, int NW, int QB, int KSP>
-#if VSD_ATTN_WEAVE
-__attribute__((amdgpu_waves_per_eu(NQK <= 3 && KSP == 1 ? 3 : 1, 8)))  // (keep the third wave per SIMD the shipped d = 40 kernel has)
-#elif defined(VSD_ATTN_WAVES)
-__attribute__((amdgpu_waves_per_eu(NQK <= 3 && KSP == 1 ? VSD_ATTN_WAVES : 1, 8)))  // (experiments: occupancy of the d <= 48 kernels)
-#endif
 __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnParams pp) {
+  VSD_CUT(VSD_CUT_ATTENTION, pp.cut)
   constexpr int NTG = 64 * NW;       // threads of one key-split group (they stage that group's tiles)
   constexpr int KS = NQK * 16 + 8;   // K tile row pitch (halfs): 4 * odd dwords -> conflict-free ds_read_b128
   constexpr int VS = 64 + 8;         // V^T tile row pitch (halfs): 36 dwords, same property
@@ -294,7 +295,6 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
         grew_any = grew_any || (m_new > m_run[qb]);
         alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
         m_run[qb] = m_new;
-        if constexpr (VSD_ATTN_WEAVE) continue;  // (the exponentials are woven into the PV product below)
         if (ones_row) {
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb)
@@ -326,65 +326,6 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
 
       PROBE(2)
       __builtin_amdgcn_s_setprio(VSD_ATTN_PV_PRIO);
-#if VSD_ATTN_WEAVE
-      // ---- woven form: the tile's 64 keys in four 16-key chunks c = kb * 2 + st; the exponentials + fp16 conversion of chunk
-      // c + 1 sit BETWEEN the PV MFMAs of chunk c (an MFMA occupies the matrix pipe for 32 cycles; the ~10 VALU instructions
-      // behind it are independent of it), pinned with sched_barrier so the scheduler keeps the alternation
-      {
-        float psum[QB];
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) psum[qb] = 0.f;
-        auto exp_part = [&](const int c, const int part) __attribute__((always_inline)) {
-          const int kb = c >> 1, st = c & 1, lo = 8 * part / NPV, hi = 8 * (part + 1) / NPV;
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int j = lo; j < hi; ++j) {
-              const float e = __builtin_amdgcn_exp2f(s[qb][kb][8 * st + j] - m_run[qb]);
-              s[qb][kb][8 * st + j] = e;
-              if (!ones_row) psum[qb] += e;
-            }
-        };
-        auto cvt_chunk = [&](const int c, half8 (&pf)[QB]) __attribute__((always_inline)) {
-          const int kb = c >> 1, st = c & 1;
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pf[qb][j] = (half_t)s[qb][kb][8 * st + j];
-        };
-        auto vread = [&](const int c, half8 (&vf)[NPV]) __attribute__((always_inline)) {
-          const int kb = c >> 1, st = c & 1;
-#pragma unroll
-          for (int db = 0; db < NPV; ++db) vf[db] = *reinterpret_cast<const half8*>(Vb + (db * 32 + lr) * VS + kb * 32 + 16 * st + 8 * lh);
-        };
-        // (V^T fragments single-buffered: the next chunk's reads go into the registers the last MFMA of this chunk has just
-        //  consumed -- with a second set the kernel needs 172 registers and loses its third wave per SIMD)
-        half8 pf[2][QB], vf[NPV];
-        vread(0, vf);
-#pragma unroll
-        for (int part = 0; part < NPV; ++part) exp_part(0, part);
-        cvt_chunk(0, pf[0]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-          for (int db = 0; db < NPV; ++db) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[db], pf[c & 1][qb], o[qb][db], 0, 0, 0);
-            if (c + 1 < 4) {
-              if (db == NPV - 1) vread(c + 1, vf);
-              exp_part(c + 1, db);
-              if (db == NPV - 1) cvt_chunk(c + 1, pf[(c + 1) & 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        if (!ones_row) {
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) l_run[qb] = l_run[qb] * alpha[qb] + psum[qb];
-        }
-      }
-#else
       // ---- O^T += V^T P^T (each V^T fragment feeds all QB query blocks)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -403,7 +344,6 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
           }
         }
       }
-#endif
       PROBE(3)
   };
   // two copies of the softmax body: the masked one only runs for a ragged last tile (or causal attention) -- as ONE
@@ -571,6 +511,7 @@ extern "C" int vsd_attention_batched(vsd_ctx* ctx, const void* q, int ldq, const
   p.scale_log2 = scale * 1.4426950408889634f;
   p.causal = causal;
   p.k_brows = k_batch_rows; p.vt_bcols = vt_batch_cols;
+  VSD_CUT_SET(p)
 #ifdef VSD_ATTN_PROBE
   p.probe = g_probe;
 #endif

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -141,7 +142,36 @@ static inline unsigned long long* wgtl_claim(int grid) {  // host: the next laun
             ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);                       \
     if (blockIdx.x == 0) { p.wgtl[-2] = gridDim.x; p.wgtl[-1] = (KIND_); }                                \
   }
+// Workgroup-seconds per kernel family under ANY load (round 5; scripts/wg_cu_time.py): every workgroup of the conv / reducer /
+// GroupNorm / attention / fused-tail kernels adds its life (first instruction -> thread 0's exit, 10 ns ticks), a count and
+// life x waves to per-family counters in a device buffer the host hands over (vsd_cut_set; the launchers copy the pointer into
+// the kernel's argument block).  Unlike the per-launch log above this works under graph replay with several launch lanes busy: what
+// a kernel family OCCUPIES of the chip while the timed 5 x 4 program runs, not what a launch takes alone.
+enum { VSD_CUT_CONV_GEMM = 0, VSD_CUT_CONV_HALO = 1, VSD_CUT_REDUCE = 2, VSD_CUT_GROUPNORM = 3, VSD_CUT_ATTENTION = 4, VSD_CUT_TAIL = 5,
+       VSD_CUT_FAMS = 8 };
+inline unsigned long long* g_cut = nullptr;  // [3 * VSD_CUT_FAMS]: per family ticks, workgroups, ticks x waves (device memory)
+struct CuTimer {
+  unsigned long long t0;
+  unsigned long long* buf;
+  int fam;
+  __device__ __forceinline__ CuTimer(int f, unsigned long long* b) : t0(__builtin_amdgcn_s_memrealtime()), buf(b), fam(f) {}
+  __device__ __forceinline__ ~CuTimer() {
+    if (buf && threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+      const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+      const unsigned long long waves = (blockDim.x * blockDim.y * blockDim.z + 63) / 64;
+      atomicAdd(buf + 3 * fam, dt);
+      atomicAdd(buf + 3 * fam + 1, 1ull);
+      atomicAdd(buf + 3 * fam + 2, dt * waves);
+    }
+  }
+};
+#define VSD_CUT(FAM_, PTR_) CuTimer cut_timer_(FAM_, PTR_);
+#define VSD_CUT_FIELD unsigned long long* cut;
+#define VSD_CUT_SET(P_) (P_).cut = g_cut;
 #else
+#define VSD_CUT(FAM_, PTR_)
+#define VSD_CUT_FIELD
+#define VSD_CUT_SET(P_)
 #define WGTL_START()
 #define WGTL_LOOP()
 #define WGTL_MARK(W_)

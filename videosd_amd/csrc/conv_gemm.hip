@@ -10,6 +10,9 @@ extern "C" void vsd_conv_set_probe(void* buf) { g_conv_probe = (long long*)buf; 
 // appends [grid, kind, 4 words per workgroup]; returns the words used so far
 extern "C" void vsd_wgtl_set(void* buf, int64_t words) { g_wgtl = (unsigned long long*)buf; g_wgtl_cap = (size_t)words; g_wgtl_off = 0; }
 extern "C" int64_t vsd_wgtl_used(void) { return (int64_t)g_wgtl_off; }
+// buf: device memory of 3 * VSD_CUT_FAMS 8-byte words, zeroed by the caller (per kernel family, common.h VSD_CUT_*: workgroup ticks
+// of 10 ns, workgroups, ticks x waves); null switches the accounting off
+extern "C" void vsd_cut_set(void* buf) { g_cut = (unsigned long long*)buf; }
 #endif
 
 extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream) {
@@ -86,8 +89,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   p.ln_eps = d->ln_eps;
   p.ln_s = (const float*)d->ln_s;
   p.ln_t = (const float*)d->ln_t;
-  p.progress = (int*)d->progress;
-  p.progress_idx = d->progress_idx;
+  VSD_CUT_SET(p)
   const int stages = d->pipeline;
   if (stages != 0 && (stages < 3 || stages > 7)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..7)", stages);
   const bool halo = stages == 7;

@@ -10,6 +10,7 @@ namespace {
 // thread pays one memory round trip instead of one per slab (the first form's runtime-bounded loop: a dependent chain of
 // split_k round trips, then the epilogue's own loads).  The additions run in the same order: same bits.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
+  VSD_CUT(VSD_CUT_REDUCE, p.cut)
   const int nch = (p.N + 7) / 8;
   const size_t total = (size_t)p.M * nch;
   const size_t slab = (size_t)p.M * p.N;
@@ -104,8 +105,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
 // NSB = slots of the weight-tile ring (lead = NSB - 1 tiles).
 template <int BN, int WMN, int NSB>
 __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p) {
+  VSD_CUT(VSD_CUT_CONV_HALO, p.cut)
   prefetch_kernargs();
-  publish_progress(p);
   WGTL_START()
   constexpr int NW = 2 * WMN, NT = 64 * NW;
   constexpr int BM = 64 * WMN, PW = 16, PH = 4 * WMN, HW_ = PW + 2;  // halo row length 18

@@ -68,6 +68,7 @@ struct ConvParams {
   const half_t* zeros;  // >= 16 zero bytes: source of out-of-bounds chunks for the direct-to-LDS loader
   int* counters;  // per-tile arrival tickets for the in-kernel split-K reduction (all zero between launches)
   int tiles_m, tiles_n;
+  VSD_CUT_FIELD
   int order;    // block_to_tile: 0 = workgroups sharing a weight tile share an XCD, 1 = workgroups sharing input rows do,
                 // 2 / 3 = the XCDs as a 2 x 4 / 4 x 2 grid over (M tiles, weight-tile groups)
   int gx;       // orders 2 / 3: weight-tile groups per XCD
@@ -85,17 +86,7 @@ struct ConvParams {
   // launch constants as multipliers (common.h fdiv): block -> tile (span = 8 S, S, tiles_n: see block_to_tile), output row ->
   // (image, y, x) (hw_out, wo), halo patch -> (image, patch row / column) (tiles per image, patches per row)
   FastDiv fd_span, fd_s, fd_tiles_n, fd_hw_out, fd_wo, fd_tpi, fd_ppr, fd_gx;
-  // the frame's weight prefetcher (prefetch.hip) stays a bounded distance ahead of the consumer: every launch says where it is
-  int* progress;     // device word (or null)
-  int progress_idx;  // this launch's index in the frame's weight table
 };
-
-// workgroup 0 publishes the launch's place in the frame's weight table as soon as it starts (one relaxed agent-scope store;
-// the prefetcher polls the word, nothing in this launch depends on it)
-__device__ __forceinline__ void publish_progress(const ConvParams& p) {
-  if (p.progress && blockIdx.x == 0 && threadIdx.x == 0)
-    __hip_atomic_store(p.progress, p.progress_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 #ifdef VSD_CONV_PROBE
 inline long long* g_conv_probe = nullptr;
@@ -431,8 +422,8 @@ __device__ __forceinline__ void block_to_tile(const ConvParams& p, int bid, int&
 //   zeros into LDS: the conv's zero padding), and the weight rows need no vector instruction at all.
 template <int BM, int BN, bool GENERIC, int STAGES, bool ILV, bool FAST>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+  VSD_CUT(VSD_CUT_CONV_GEMM, p.cut)
   prefetch_kernargs();
-  publish_progress(p);
   WGTL_START()
   constexpr int WM = 2, WN = 2;             // 2x2 waves
   constexpr int TM = BM / WM, TN = BN / WN;  // wave tile

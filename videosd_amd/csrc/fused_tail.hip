@@ -48,6 +48,7 @@ struct TailParams {
   half_t* out0;         // tail_a: h1 [M][C];  tail_b: block output [M][C]
   half_t* out1;         // tail_a: q [M][C]
   float ln_eps;
+  VSD_CUT_FIELD
 };
 
 // ---- weights: straight from global memory into registers, already in MFMA B-fragment layout.
@@ -249,6 +250,7 @@ __device__ __forceinline__ void load_a_tile(const half_t* g, half_t* X, int m0, 
 
 template <int KIND, int WM, int BM = BM0>
 __global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
+  VSD_CUT(VSD_CUT_TAIL, p.cut)
   constexpr int MI = BM / 16 / WM, NTH = 256 * WM;
   static_assert(MI * 16 * WM == BM, "rows per workgroup = 16 x row fragments per wave x row groups");
   __shared__ __attribute__((aligned(16))) half_t Xs[BM * XP];
@@ -510,6 +512,7 @@ extern "C" int vsd_tail_a(vsd_ctx* ctx, const void* att, const void* h, int m, c
   p.w0 = (const half_t*)w_out; p.b0 = (const half_t*)b_out;
   p.w1 = (const half_t*)w_q; p.ln_s1 = (const float*)ln_s; p.ln_t1 = (const float*)ln_t;
   p.out0 = (half_t*)h1_out; p.out1 = (half_t*)q_out; p.ln_eps = ln_eps;
+  VSD_CUT_SET(p)
   hipStream_t s = (hipStream_t)stream;
   LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * m * 2.0 * C * C);
   // tile height: see pick_tail_bm (64 = the eight-wave form; the others run four waves)
@@ -537,6 +540,7 @@ extern "C" int vsd_tail_b(vsd_ctx* ctx, const void* att2, const void* h1, const 
   p.w2 = (const half_t*)w_ff2; p.b2 = (const half_t*)b_ff2;
   p.w3 = (const half_t*)w_proj; p.b3 = (const half_t*)b_proj;
   p.out0 = (half_t*)out; p.ln_eps = ln_eps;
+  VSD_CUT_SET(p)
   hipStream_t s = (hipStream_t)stream;
   LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * m * (2.0 * C * C + 3.0 * C * FF));
   switch (pick_tail_bm(m, 1)) {

@@ -29,6 +29,7 @@ struct GnParams {
   int nblk;     // stats workgroups (per image)
   int rpp;      // rows per pass = blockDim / c8
   int batch;    // images stacked along the rows (blockIdx.y): each normalised with its own statistics
+  VSD_CUT_FIELD
 };
 
 __device__ __forceinline__ half8 gn_load(const GnParams& p, int row, int ch8) {
@@ -41,6 +42,7 @@ __device__ __forceinline__ half8 gn_load(const GnParams& p, int row, int ch8) {
 // its row loads four at a time before consuming them, and the partial folds are spread over all threads with every
 // load of a thread independent of the others, so each phase costs about one memory round trip.
 __global__ void gn_stats_kernel(const GnParams p) {
+  VSD_CUT(VSD_CUT_GROUPNORM, p.cut)
   extern __shared__ float sm[];  // [16 planes][threads] per-thread channel sums (see below), folded in a fixed order
   const int t = threadIdx.x;
   const int ch8 = t % p.c8;
@@ -108,6 +110,7 @@ __global__ void gn_stats_kernel(const GnParams p) {
 }
 
 __global__ void gn_apply_kernel(const GnParams p) {
+  VSD_CUT(VSD_CUT_GROUPNORM, p.cut)
   extern __shared__ float sm[];  // [groups][2] mean, rstd | [nch][groups*2] partial folds
   const int t = threadIdx.x;
   const int npairs = p.groups * 2;
@@ -207,6 +210,7 @@ __global__ void gn_apply_kernel(const GnParams p) {
 // NV = vectors per row piece (cpg / VW), RMAX rows per thread.
 template <int VW, int NV, int RMAX>
 __global__ void gn_fused_kernel(const GnParams p) {
+  VSD_CUT(VSD_CUT_GROUPNORM, p.cut)
   typedef _Float16 vec_t __attribute__((ext_vector_type(VW)));
   __shared__ float red[2 * 16 + 2];
   const int t = threadIdx.x, T = blockDim.x;
@@ -399,6 +403,7 @@ extern "C" int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void*
   if (batch < 1 || batch > 65535) return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm: batch=%d", batch);
   GnParams p;
   p.batch = batch;
+  VSD_CUT_SET(p)
   p.src0 = (const half_t*)src0;
   p.src1 = (const half_t*)src1;
   p.c0 = c0;

@@ -26,6 +26,7 @@ import os
 import queue
 import socket
 import statistics
+import sys
 import threading
 import time
 from typing import Any, Callable, Dict, List, Optional
@@ -352,6 +353,8 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
         pipe.set_prompt_embeds(buf, key=key)
         return {"epoch": int(got["epoch"]), "rank": rank, "via": dist.get_backend(), "checksum": float(buf.float().sum())}
 
+    abandon_note: Dict[str, Any] = {}  # what abandon_group did (reported with the failed sync and in the metrics)
+
     def abandon_group():
         """After a failed or timed-out collective the communicator is finished (a member is gone; it cannot be re-entered).
         With RCCL the abandoned broadcast is a KERNEL that stays resident on the GPU waiting for its peer, and every later
@@ -362,19 +365,31 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
         if dist is None:
             return
         d, dist = dist, None  # (sync_prompt / sync_tuning take the local path from now on)
+        aborted, why = False, "no communicator on a device"
         try:
             pg = d.distributed_c10d._get_default_group()
             backend = pg._get_backend(dev) if dev.type == "cuda" else None
             if backend is not None and hasattr(backend, "abort"):
                 backend.abort()       # ProcessGroupNCCL.abort: ncclCommAbort -> the stuck kernel exits
+                aborted = True
             elif backend is not None and hasattr(backend, "_shutdown"):
                 backend._shutdown()
-        except Exception:
-            pass
+                aborted = True
+            elif backend is not None:
+                why = "this torch has neither ProcessGroupNCCL.abort nor _shutdown"
+        except Exception as e:  # private torch APIs: say so instead of leaving the abandoned collective queued in silence
+            why = f"{type(e).__name__}: {e}"
+        abandon_note.update(aborted=aborted, why=None if aborted else why)
+        if dev.type == "cuda" and not aborted:
+            # The abandoned broadcast stays queued and the backend's watchdog would take THIS (healthy) worker down when the group
+            # timeout passes: with no abort available the only safeguard left is to tell the watchdog not to (read when the
+            # watchdog fires, so setting it now is in time), and to say what happened.
+            os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"] = "0"
+            print(json.dumps({"kind": "worker", "rank": rank, "event": "abandon_group_without_abort", "why": why}), file=sys.stderr, flush=True)
         try:
             d.destroy_process_group()
-        except Exception:
-            pass
+        except Exception as e:
+            abandon_note["destroy"] = f"{type(e).__name__}: {e}"
 
     def sync_tuning():
         """Rank 0's per-shape kernel choices (its table plus what its warm-up measured) to every rank: one object broadcast."""
@@ -405,7 +420,8 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
                 try:
                     abandon_group()
                     sync_prompt(args[0], None, collective=False)
-                    conn.send((rid, True, {"epoch": epoch, "rank": rank, "via": "local-after-failed-sync", "error": f"{type(e).__name__}: {e}"}))
+                    conn.send((rid, True, {"epoch": epoch, "rank": rank, "via": "local-after-failed-sync", "error": f"{type(e).__name__}: {e}",
+                                           "abandon": dict(abandon_note)}))
                 except BaseException as e2:
                     conn.send((rid, False, (type(e2).__name__, str(e2))))
             continue
@@ -419,6 +435,8 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
         if method == "__metrics__":
             snap = stats.snapshot()
             snap.update({"rank": rank, "world": world, "device": config.get("device", 0), "pid": os.getpid()})
+            if abandon_note:
+                snap["abandoned_group"] = dict(abandon_note)
             if hasattr(pipe, "metrics"):
                 try:
                     snap["pipeline"] = pipe.metrics()
@@ -900,12 +918,13 @@ class RemotePipeline:
 
 def spawn_workers(n: int, factory: str = "videosd_amd.pipeline:VideoSDPipeline", backend: Optional[str] = "auto",
                   devices: Optional[List[int]] = None, sync_timeout: float = 5.0, warm_options: Optional[Dict[str, Any]] = None,
-                  **kwargs) -> List[RemotePipeline]:
+                  group_timeout: float = 120.0, **kwargs) -> List[RemotePipeline]:
     """The reference's `for i in range(gpu_num): pipelines[i] = VideoSDPipeline.remote(**config)` (server.py:317-321):
     N worker processes, worker i on GPU `devices[i]` (default i), all in ONE process group so that a new prompt is one
     RCCL broadcast from rank 0 (`backend` "nccl" = RCCL over xGMI on the GPU box; "gloo" for CPU tests; None: no group,
     every worker encodes for itself).  The workers start concurrently (the rendezvous needs all of them).
     sync_timeout: seconds a prompt broadcast may take before every worker falls back to encoding the prompt itself.
+    group_timeout: the process group's own timeout (the backend's watchdog; a collective abandoned at `sync_timeout` is aborted).
     warm_options: `infer` options of the stream to come: rank 0 prepares (and tunes) those plans first, its per-shape kernel
     choices go to the other ranks (`__sync_tuning__`), then they prepare theirs -- every rank runs the same kernels, so a
     frame's bits do not depend on the rank it lands on; no frame of the stream pays for a `prepare`."""
@@ -918,7 +937,8 @@ def spawn_workers(n: int, factory: str = "videosd_amd.pipeline:VideoSDPipeline",
     ws = []
     try:
         for i in range(n):
-            grp = {"rank": i, "world": n, "port": port, "backend": backend, "sync_timeout": float(sync_timeout)} if backend else None
+            grp = {"rank": i, "world": n, "port": port, "backend": backend, "sync_timeout": float(sync_timeout),
+                   "timeout": float(group_timeout)} if backend else None
             ws.append(RemotePipeline(factory=factory, group=grp, wait=False, device=devices[i], **kwargs))
         for w in ws:
             w.wait_ready()

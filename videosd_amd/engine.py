@@ -87,8 +87,6 @@ class Recorder:
 
     def run(self):
         for fn, a, k in self.calls:
-            if getattr(fn, "__name__", "").startswith("pf_"):
-                continue  # the weight prefetcher exists in ONE captured launch sequence only (Engine._capture(prefetch=True))
             fn(*a, **k)
 
 
@@ -431,14 +429,6 @@ class Engine:
         # form that costs least with four launch lanes busy (throughput; ops.HipOps.tune_conv).  Fixed per plan at `prepare`.
         self.tune_for_lanes = False
         self.graph_serial = None
-        # a third sequence of the same program for a frame that is ALONE on the GPU: as `graph` (ControlNet encoder on the side
-        # stream) plus the weight prefetcher on the lane's third stream (csrc/prefetch.hip; `launch(prefetch=True)`)
-        self.graph_pf = None
-        self.prefetch_launch = False
-        import os as _os0
-        self.use_prefetch = _os0.environ.get("VSD_PREFETCH", "1") != "0"
-        self.pf_lookahead_mb = float(_os0.environ.get("VSD_PF_LOOKAHEAD_MB", "48"))
-        self.pf_workgroups = int(_os0.environ.get("VSD_PF_WGS", "16"))
         # ... and, optionally, while that stream is otherwise idle: the ControlNet skip merges beside the mid block / decoder
         # start and Sobel + conditioning embedding beside the TAESD encoder (`use_side_stream`).  Measured on MI355X (512x512,
         # 4 steps): one frame alone 23.8 -> 23.2 ms, but with two launches in flight 97 -> 81 frames/s -- four busy hardware
@@ -483,8 +473,6 @@ class Engine:
         e._vt_pool = {}
         e.graph = None
         e.graph_serial = None
-        e.graph_pf = None
-        e._pf = None
         e.plan = None
         e._stage = None  # own pinned staging buffers and events (a copy of the parent's would be SHARED with it)
         e.pblock = None
@@ -1070,25 +1058,6 @@ class Engine:
         self.buffers = {"x0": x0, "lat": lat, "eps": eps, "denoised": den, "dec_in": dec_in, "dec_out": dec_out}
         r = Recorder(ops)
         img = lambda t, b, n: t[b * n:(b + 1) * n]  # noqa: E731  rows of image b
-        # the weight prefetcher of the lone-frame sequence (markers `pf_*`: dropped from every other sequence and from eager runs):
-        # progress / stop words reset on the main stream, the kernel on the lane's third stream, joined at the frame's end
-        pf = self._pf = None
-        if self.use_prefetch and B == 1 and hasattr(ops, "prefetch_weights") and hasattr(ops, "pf_launch"):
-            pf = self._pf = {"words": ops.zeros(8, dtype=torch.int32)}  # [0] progress, [4:8] exit record
-            if "pf_stop" not in self.family:
-                self.family["pf_stop"] = ops.zeros(4, dtype=torch.int32)  # ONE stop word for every engine of the family
-                self.family["pf_armed"] = [False]
-            pf["stop"] = self.family["pf_stop"]
-            ops.progress = pf["words"]
-            r.pf_reset(pf)
-            r.pf_signal("pf_go")
-            r.pf_use_stream(2)
-            r.pf_wait("pf_go")
-            r.pf_launch(pf)
-            r.pf_signal("pf_done")
-            r.pf_use_stream(0)
-        elif hasattr(ops, "progress"):
-            ops.progress = None
         r.preprocess_rgb(frame_b, B * H, W, enc_in)
         cond_emb = None
         self._ev_count = 0
@@ -1151,9 +1120,6 @@ class Engine:
             r.lcm_step_dev(eps, cur, nz, c[2 + 6 * i:8 + 6 * i], hw0, B, nxt, den, dec_in if last else None)
         self._decode(r, dec_in, h0, w0, dec_out)
         r.postprocess_rgb(dec_out, 8, B * H * W, out_b)
-        if pf is not None:
-            r.pf_wait("pf_done")
-            self._weight_table(r, pf)
         self.program = r
         self.plan = dict(H=H, W=W, steps=steps, strength=strength, cn_scale=controlnet_scale, cn=use_controlnet, n=n, batch=B,
                          ref_mode=bool(ref_mode), tuned_for_lanes=bool(self.tune_for_lanes),
@@ -1172,15 +1138,12 @@ class Engine:
             self.graph = self._capture(r)
             self.plan["graphs"], self.plan["edges"] = ops.seq_count(self.graph)
             self.graph_serial = self._capture(r, serial=True) if self.plan["edges"] else self.graph
-            self.graph_pf = self._capture(r, prefetch=True) if pf is not None else None
         return self.plan
 
     SYNC_OPS = ("use_stream", "fork", "join", "signal", "wait")
 
-    def _capture(self, r: Recorder, serial: bool = False, prefetch: bool = False):
-        """prefetch=True: the `pf_*` markers are kept (the lone frame's weight prefetcher on the lane's third stream); every other
-        sequence drops them.
-        serial=True: every call on stream 0, no edges (the program's fork / join / signal / wait markers are dropped: in one
+    def _capture(self, r: Recorder, serial: bool = False):
+        """serial=True: every call on stream 0, no edges (the program's fork / join / signal / wait markers are dropped: in one
         in-order stream they hold by construction) -- one graph.
         The recorded program -> a launch sequence (include/vsd.h vsd_seq): every run of kernel calls on one stream becomes ONE
         single-branch hipGraph on that stream, every fork / join / signal / wait an event edge between the two streams, issued
@@ -1205,11 +1168,6 @@ class Engine:
         try:
             for fn, a, k in r.calls:
                 name = getattr(fn, "__name__", "")
-                if name.startswith("pf_"):
-                    if not prefetch or serial:
-                        continue
-                    if name in ("pf_signal", "pf_wait", "pf_use_stream"):
-                        name = name[3:]
                 if name not in self.SYNC_OPS:
                     run.append((fn, a, k))
                     continue
@@ -1238,58 +1196,12 @@ class Engine:
         return seq
 
     def _destroy_graphs(self):
-        g, gs, gp = self.graph, getattr(self, "graph_serial", None), getattr(self, "graph_pf", None)
-        self.graph = self.graph_serial = self.graph_pf = None
+        g, gs = self.graph, getattr(self, "graph_serial", None)
+        self.graph = self.graph_serial = None
         if g is not None:
             self.ops.seq_destroy(g)
         if gs is not None and gs is not g:
             self.ops.seq_destroy(gs)
-        if gp is not None:
-            self.ops.seq_destroy(gp)
-
-    def _weight_table(self, r: Recorder, pf: dict):
-        """The frame's weight table for the prefetcher (include/vsd.h vsd_prefetch_weights): one entry per conv launch in the
-        order the launches USE their weights, and every conv call of the program gets its index (`progress_idx`: what it
-        publishes when it starts).  The two encoders between a fork and a join run side by side: their launches are interleaved
-        by the fraction of their weights they have consumed."""
-        nbytes = lambda c: int(c[1][3].n) * int(c[1][3].kp) * 2  # noqa: E731  (args: src0, src1, geom, PackedConv, out)
-        order, serial, par, cur = [], [], None, 0
-        for c in r.calls:
-            name = getattr(c[0], "__name__", "")
-            if name == "fork":
-                order += serial
-                serial, par = [], {0: [], 1: []}
-            elif name == "join" and par is not None:
-                a, b = par[1], par[0]
-                ta, tb = max(1, sum(map(nbytes, a))), max(1, sum(map(nbytes, b)))
-                ia = ib = 0
-                ca = cb = 0
-                while ia < len(a) or ib < len(b):
-                    if ib >= len(b) or (ia < len(a) and ca * tb <= cb * ta):
-                        order.append(a[ia])
-                        ca += nbytes(a[ia])
-                        ia += 1
-                    else:
-                        order.append(b[ib])
-                        cb += nbytes(b[ib])
-                        ib += 1
-                par = None
-            elif name == "use_stream":
-                cur = c[1][0]
-            elif name == "conv":
-                (par[cur if cur in (0, 1) else 0] if par is not None else serial).append(c)
-        order += serial
-        rows = np.zeros(len(order), dtype=[("ptr", "<u8"), ("bytes", "<u4"), ("cum_kb", "<u4")])
-        cum = 0
-        for i, c in enumerate(order):
-            c[2]["progress_idx"] = i
-            rows[i] = (c[1][3].weight.data_ptr(), nbytes(c), cum >> 10)
-            cum += nbytes(c)
-        pf["n"] = len(order)
-        pf["bytes"] = cum
-        pf["table"] = self.ops.to_device(torch.from_numpy(rows.view(np.uint8).copy()))
-        pf["lookahead_kb"] = int(self.pf_lookahead_mb * 1024)
-        pf["workgroups"] = self.pf_workgroups
 
     def _write_constants(self, sched: LCMSchedule, controlnet_scale: float, use_controlnet: bool):
         """Schedule- and option-dependent constants -> the device block / time-embedding tables the graphs read."""
@@ -1354,26 +1266,13 @@ class Engine:
         return d, torch.cat(ref_draws, dim=0).reshape(n_steps, 4, h * w).contiguous()
 
     # ---------------------------------------------------------------- per frame
-    def launch(self, overlap: Optional[bool] = None, prefetch: Optional[bool] = None):
-        """prefetch: with `overlap`, also run the frame's weight prefetcher on the lane's third stream (default
-        `self.prefetch_launch`): ONLY for a launch that is alone on the GPU -- that stream is another lane's.
-        Enqueue one frame's work (frame_u8 -> out_u8) on the lane's stream(s).  overlap: run the ControlNet encoder on the
+    def launch(self, overlap: Optional[bool] = None):
+        """Enqueue one frame's work (frame_u8 -> out_u8) on the lane's stream(s).  overlap: run the ControlNet encoder on the
         lane's side stream (default: `self.overlap_launch`); pass False when a launch of the lane that OWNS that stream
         (lane + 2 mod 4) may be in flight -- two busy queues on one command-processor pipe take turns (ops.HipOps)."""
         self._sync_prompt()
         if self.graph is not None:
             ov = self.overlap_launch if overlap is None else overlap
-            pfl = (self.prefetch_launch if prefetch is None else prefetch) and ov and getattr(self, "graph_pf", None) is not None
-            armed = self.family.get("pf_armed")
-            if pfl:
-                armed[0] = True
-                self.ops.seq_launch(self.graph_pf)
-                return
-            if armed is not None and armed[0]:
-                # a prefetcher of this family may be running on a stream another lane's launch needs: tell it to leave (one
-                # 4-byte fill on this launch's own stream, ahead of its work; it polls the word every few microseconds)
-                armed[0] = False
-                self.ops.fill32(self.family["pf_stop"], 1)
             self.ops.seq_launch(self.graph if ov else self.graph_serial)
         else:
             if hasattr(self.ops, "tune_mode"):
@@ -1396,7 +1295,7 @@ class Engine:
             self._stage = st
         return st
 
-    def submit_u8(self, frame: np.ndarray, overlap: Optional[bool] = None, prefetch: Optional[bool] = None):
+    def submit_u8(self, frame: np.ndarray, overlap: Optional[bool] = None):
         """Upload + enqueue one frame (or batch) without waiting: pair with `collect_u8`.  Lets the host prepare the
         next frames / post-process the previous ones while this one is on the GPU.  overlap: see `launch`."""
         want = self._want_shape()
@@ -1407,7 +1306,7 @@ class Engine:
         self.ops.upload(self.frame_u8, hin)
         if e0 is not None:
             e0.record(self.ops.stream)
-        self.launch(overlap, prefetch)
+        self.launch(overlap)
         if e1 is not None:
             e1.record(self.ops.stream)
 

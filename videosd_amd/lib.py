@@ -45,7 +45,6 @@ class ConvDesc(C.Structure):
         ("batch", C.c_int32), ("t_img", C.c_int32),
         ("out_scale_dev", C.c_void_p),
         ("softmax_cols", C.c_int32),
-        ("progress", C.c_void_p), ("progress_idx", C.c_int32),
     ]
 
 
@@ -88,9 +87,6 @@ SIGNATURES = {
     "vsd_embed_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vsd_postprocess_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vsd_axpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]),
-    "vsd_prefetch_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
-                                      C.c_void_p, C.c_void_p]),
-    "vsd_fill32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vsd_graph_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vsd_graph_end": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "vsd_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

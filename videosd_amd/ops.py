@@ -127,22 +127,13 @@ class HipOps:
         self.lane = int(lane)
         self._lanes = _lanes if _lanes is not None else LaneBook()  # shared with every clone
         self._plain = _os.environ.get("VSD_STREAMS") == "plain"
-        # streams[2]: where a LONE frame's weight prefetcher runs (csrc/prefetch.hip) -- the pool stream that neither this lane nor
-        # its side branch uses; it belongs to another lane, so the prefetching launch sequence is only taken while no other
-        # launch is in flight, and any other launch raises the prefetcher's stop word (Engine.launch)
         if stream is not None:
-            self.streams = [stream, torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+            self.streams = [stream, torch.cuda.Stream(device=self.device)]
         elif self._plain:
-            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            self.streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
         else:
             pool = self.pool_streams()
-            self.streams = [pool[self.lane % L.POOL_STREAMS], pool[(self.lane + 2) % L.POOL_STREAMS], pool[(self.lane + 3) % L.POOL_STREAMS]]
-            pm = _os.environ.get("VSD_POOL_MASK", "")
-            if pm.startswith("p") and pm[1:].isdigit() and int(pm[1:]) > 0:
-                # experiment (round 5): the prefetcher on compute units of its own -- the launch streams were made without the last
-                # k CUs of every XCD (vsd_stream_pool), this stream has only those; it is the 6th CU-masked stream of the process
-                # (a dummy 5th in front of it), i.e. on command-processor pipe 1, not on lane 0's
-                self.streams[2] = self._pf_stream(int(pm[1:]))
+            self.streams = [pool[self.lane % L.POOL_STREAMS], pool[(self.lane + 2) % L.POOL_STREAMS]]
         self.stream = self.streams[0]
         if _register:  # (the tuner's helper objects do not occupy a lane)
             self._lanes.register(self)
@@ -166,7 +157,6 @@ class HipOps:
         self.one_launch_bias_us = float(_os.environ.get("VSD_ONE_LAUNCH_BIAS_US", "0.5"))  # tune_conv: see there
         self.no_halo = bool(__import__("os").environ.get("VSD_NO_HALO"))  # debugging: run halo-tuned shapes on the generic ring
         self.default_pipeline = 3
-        self.progress = None  # int32 device word the conv launches publish their weight-table index to (Engine sets it)
         with torch.cuda.stream(self.stream):
             self._counters = [torch.zeros(L.SPLITK_MAX_TILES, dtype=torch.int32, device=self.device) for _ in range(2)]
         with torch.cuda.stream(self.stream):
@@ -179,25 +169,6 @@ class HipOps:
         h = (C.c_void_p * L.POOL_STREAMS)()
         self.ctx.call("vsd_stream_pool", h)
         return [torch.cuda.ExternalStream(int(h[i]), device=self.device) for i in range(L.POOL_STREAMS)]
-
-    _PF_STREAMS = {}
-
-    def _pf_stream(self, k: int):
-        key = (self.device_id, k)
-        st = HipOps._PF_STREAMS.get(key)
-        if st is None:
-            ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
-            words = (ncu + 31) // 32
-            dummy = C.c_void_p()
-            self.ctx.call("vsd_stream_create", None, 0, C.byref(dummy))  # (all CUs; never used: it takes the queue on pipe 0)
-            mask = (C.c_uint32 * words)()
-            for b in range(ncu):
-                if b // 8 >= ncu // 8 - k:
-                    mask[b // 32] |= 1 << (b % 32)
-            h = C.c_void_p()
-            self.ctx.call("vsd_stream_create", mask, words, C.byref(h))
-            st = HipOps._PF_STREAMS[key] = torch.cuda.ExternalStream(int(h.value), device=self.device)
-        return st
 
     def pool_check(self, chain: int = 100) -> float:
         """time of four frame-like kernel chains on the four launch streams at once / one chain alone: ~1.0 when they run side
@@ -357,7 +328,7 @@ class HipOps:
     def conv(self, src0, src1, g: Geom, w: PackedConv, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None,
              residual2=None, ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0,
              t_col0=0, tile=None, split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None,
-             ln_eps=1e-5, chanstat_out=None, t_img=0, out_scale_dev=None, softmax_cols=0, progress_idx=None):
+             ln_eps=1e-5, chanstat_out=None, t_img=0, out_scale_dev=None, softmax_cols=0):
         """t_img: with g.batch > 1, columns of out_t per image (image b's pixels start at column b * t_img).
         out_scale_dev: one fp32 in device memory that replaces out_scale at run time (changeable under a captured graph)."""
         m = g.m
@@ -418,8 +389,6 @@ class HipOps:
         d.batch, d.t_img = g.batch, t_img
         d.tile, d.split_k = tile, split_k
         d.pipeline = self.default_pipeline if pipeline is None else pipeline
-        if progress_idx is not None and self.progress is not None:
-            d.progress, d.progress_idx = self._p(self.progress), int(progress_idx)
         if split_k > 1:
             ws = workspace if workspace is not None else self.workspace("splitk", split_k * m * w.n * 4)
             d.workspace = self._p(ws)
@@ -520,7 +489,7 @@ class HipOps:
                     cands.append((t, sp, False, 7))
                     if sp > 1 and hblocks <= L.SPLITK_MAX_TILES:
                         cands.append((t, sp, True, 7))
-        kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline", "progress_idx")}
+        kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline")}
         table = []
         saved = self.tile_override.pop(key, None)
         if self.tune_mode == 1:
@@ -771,33 +740,6 @@ class HipOps:
 
     def postprocess_rgb(self, img, ld, hw, rgb_u8):
         self.ctx.call("vsd_postprocess_rgb", self._p(img), ld, hw, self._p(rgb_u8), self.s)
-
-    def fill32(self, dst, value: int, count: int = 1):
-        """32-bit fill on the current stream (a memset node under capture)"""
-        self.ctx.call("vsd_fill32", self._p(dst), int(value), int(count), self.s)
-
-    def prefetch_weights(self, table, n, progress, stop, lookahead_kb, workgroups, stall_ms, limit_ms, exit_record=None):
-        """the lone frame's weight prefetcher on the current stream (include/vsd.h vsd_prefetch_weights)"""
-        self.ctx.call("vsd_prefetch_weights", self._p(table), int(n), self._p(progress), self._p(stop), int(lookahead_kb), int(workgroups),
-                      float(stall_ms), float(limit_ms), self._p(exit_record), self.s)
-
-    # ---- the lone frame's weight prefetcher as recorded by the engine (markers `pf_*`: Engine._capture(prefetch=True) only)
-    def pf_reset(self, pf: dict):
-        self.fill32(pf["words"], 0, 8)   # progress word + exit record
-        self.fill32(pf["stop"], 0, 1)
-
-    def pf_launch(self, pf: dict):
-        self.prefetch_weights(pf["table"], pf["n"], pf["words"], pf["stop"], pf["lookahead_kb"], pf["workgroups"], stall_ms=5.0,
-                              limit_ms=200.0, exit_record=pf["words"][4:])
-
-    def pf_signal(self, name: str):
-        self.signal(name)
-
-    def pf_wait(self, name: str):
-        self.wait(name)
-
-    def pf_use_stream(self, idx: int):
-        self.use_stream(idx)
 
     def axpy(self, a, b, scale, n, out):
         self.ctx.call("vsd_axpy", self._p(a), self._p(b), scale, n, self._p(out), self.s)

@@ -413,7 +413,7 @@ class VideoSDPipeline:
         np.random.seed(seed)  # kept for parity with videopipeline.py:112 (nothing downstream consumes it)
         t0 = time.perf_counter()
         frames = np.stack([np.asarray(im if im.mode == "RGB" else im.convert("RGB"), dtype=np.uint8) for im in imgs])
-        eng.submit_u8(frames[0] if len(imgs) == 1 else frames, overlap=self._overlap_now(lane), prefetch=self._prefetch_now(lane))
+        eng.submit_u8(frames[0] if len(imgs) == 1 else frames, overlap=self._overlap_now(lane))
         self._outstanding.append(eng)
         self._lanes_busy.append(int(lane))
         self._note("upload_enqueue", t0)
@@ -427,12 +427,6 @@ class VideoSDPipeline:
         if os.environ.get("VSD_OVERLAP_CN") is not None:
             return os.environ.get("VSD_OVERLAP_CN") == "1"
         return int(lane) < 2 and all(l < 2 for l in self._lanes_busy) and len(self._lanes_busy) < 2
-
-    def _prefetch_now(self, lane: int) -> bool:
-        """A launch that is ALONE on the GPU (lane 0, nothing else in flight) also runs the frame's weight prefetcher on the
-        lane's third stream (Engine.launch(prefetch=True); one-frame plans only -- the engine has no such sequence otherwise).
-        That stream is another lane's: whatever is launched while the frame runs raises the prefetcher's stop word first."""
-        return int(lane) == 0 and not self._lanes_busy
 
     def collect_batch(self, handle):
         eng, n = handle
