@@ -578,6 +578,32 @@ def run_rank(args):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # ---- what the families OCCUPY of the chip while the TIMED program runs (5 frames per launch x 4 lanes, throughput-mode kernel
+    #      forms): the sum of workgroup lives per family under captured-graph replay on all lanes, from the instrumented build
+    #      (scripts/wg_cu_time.py; a constant of the committed profile, not measured in this run -- like `traffic`)
+    in_situ = None
+    cut = os.path.join(ROOT, "profiles", "round5_wg_cu_time_5x4.txt")
+    if os.path.exists(cut):
+        try:
+            runs = json.loads(open(cut).read().strip().splitlines()[-1])["runs"]
+            timed = next(r for r in runs if r["mode"] == 1 and r["lanes"] == 4)
+            alone = next(r for r in runs if r["mode"] == 0 and r["lanes"] == 1)
+            per_cu_peak = MFMA_PEAK_TFLOPS / 256.0
+            fams = [f for f, v in timed["families"].items() if v["wg_ms_per_frame"] > 0]
+            in_situ = {"source": "profiles/round5_wg_cu_time_5x4.txt (scripts/wg_cu_time.py with the -DVSD_WG_TIMELINE build: every workgroup adds its life to a per-family "
+                                 "counter; a constant of the committed profile)",
+                       "program": f"{timed['frames_per_launch']} frames per launch x {timed['lanes']} lanes, throughput-mode kernel forms, captured graphs",
+                       "wg_ms_per_frame": {f: timed["families"][f]["wg_ms_per_frame"] for f in fams},
+                       "wg_ms_per_frame_fastest_alone_forms_one_lane": {f: alone["families"][f]["wg_ms_per_frame"] for f in fams},
+                       "tflop_per_wg_second": {f: timed["families"][f]["tflop_per_wg_second"] for f in fams if timed["families"][f]["tflop_per_wg_second"]},
+                       "frac_of_per_cu_mfma_peak_while_resident": {f: round(timed["families"][f]["tflop_per_wg_second"] / per_cu_peak, 4) for f in fams
+                                                                   if timed["families"][f]["tflop_per_wg_second"]},
+                       "per_cu_peak_tflops": round(per_cu_peak, 3),
+                       "workgroups_resident_on_average": round(timed["wg_ms_per_frame_total"] / timed["wall_ms_per_frame"], 1),
+                       "mean_resident_waves_per_simd": timed["mean_resident_waves_per_simd"],
+                       "fps_of_the_instrumented_run": timed["fps"]}
+        except Exception as e:  # reporting only
+            in_situ = {"error": f"{type(e).__name__}: {e}"}
     roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear, all shapes of one frame)",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -587,7 +613,8 @@ def run_rank(args):
                 "avg_launch_us_raw_events": round(cg["ms"] * 1e3 / max(cg["launches"], 1), 2),
                 "event_bracket_overhead_us": round(ovh_ms * 1e3, 2),
                 "flop_per_launch_avg": cg["flops"] / max(cg["launches"], 1),
-                "families_ms_per_pass": {k: round(v["ms"], 3) for k, v in st.items()}}
+                "families_ms_per_pass": {k: round(v["ms"], 3) for k, v in st.items()},
+                "in_situ": in_situ}
 
     out = {
         "metric": METRIC,

@@ -913,7 +913,10 @@ def test_qkv_batched_transposed_output_slabs(ops):
             assert (vt[:, b * t_img + hw:(b + 1) * t_img] == 0).all()
 
 
-@pytest.mark.parametrize("c0,c1,hw,silu", [(320, 0, 1024, True), (128, 64, 35, False), (1280, 1280, 64, True)])
+@pytest.mark.parametrize("c0,c1,hw,silu", [(320, 0, 1024, True), (128, 64, 35, False), (1280, 1280, 64, True),
+                                           # several groups per workgroup (80-byte row pieces): 2 x 20 channels, also over a concat whose
+                                           # boundary falls between two pieces, a ragged row count, and 4 x 10 channels at 16 x 16
+                                           (640, 0, 1024, True), (320, 320, 1024, False), (640, 0, 1000, True), (320, 0, 256, True)])
 def test_groupnorm_batched(ops, c0, c1, hw, silu):
     B, c = 3, c0 + c1
     a = rnd(B * hw, c0, seed=1) * torch.tensor([1.0, 3.0, 0.3]).repeat_interleave(hw)[:, None].half() + 0.5

@@ -208,17 +208,23 @@ __global__ void gn_apply_kernel(const GnParams p) {
 // registers and stored.  The two-launch form above spends ~9 + ~6 us on these few-hundred-KB tensors, all of it launch
 // and memory latency; this is one launch and one round trip.  VW = halfs per vector load (the alignment cpg allows),
 // NV = vectors per row piece (cpg / VW), RMAX rows per thread.
-template <int VW, int NV, int RMAX>
+// GPW = groups per workgroup (1 in every shipped instantiation).  Round 5 measured 2 groups of 20 channels / 4 of 10 per workgroup
+// (80-byte row pieces, 16-byte vectors, half the workgroups) at 32 x 32 x 640: 9.6 against 8.3 us for one image, 12.5 against 13.2 for
+// five (scripts/gn_bench.py) -- the kernel is launch + two dependent round trips, not line traffic: not used.
+template <int VW, int NV, int RMAX, int GPW = 1>
 __global__ void gn_fused_kernel(const GnParams p) {
   VSD_CUT(VSD_CUT_GROUPNORM, p.cut)
   typedef _Float16 vec_t __attribute__((ext_vector_type(VW)));
-  __shared__ float red[2 * 16 + 2];
+  constexpr int CPG = NV * VW / GPW;  // channels per group (compile time: the element -> group map is static)
+  __shared__ float red[GPW * (2 * 16 + 2)];
   const int t = threadIdx.x, T = blockDim.x;
-  const int g = blockIdx.x;
+  const int g0 = blockIdx.x * GPW;
   const size_t img0 = (size_t)blockIdx.y * p.hw;
-  const int ch0 = g * p.cpg;
+  const int ch0 = g0 * CPG;
   vec_t x[RMAX][NV];
-  float s = 0.f, q = 0.f;
+  float s[GPW], q[GPW];
+#pragma unroll
+  for (int g = 0; g < GPW; ++g) s[g] = q[g] = 0.f;
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) {
     const int row = t + r * T;
@@ -240,36 +246,40 @@ __global__ void gn_fused_kernel(const GnParams p) {
 #pragma unroll
         for (int i = 0; i < VW; ++i) {
           const float f = (float)x[r][v][i];
-          s += f;
-          q += f * f;
+          s[(v * VW + i) / CPG] += f;
+          q[(v * VW + i) / CPG] += f * f;
         }
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o);
-    q += __shfl_xor(q, o);
-  }
+  for (int g = 0; g < GPW; ++g)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s[g] += __shfl_xor(s[g], o);
+      q[g] += __shfl_xor(q[g], o);
+    }
   const int wave = t >> 6, nw = T >> 6;
   if ((t & 63) == 0) {
-    red[2 * wave] = s;
-    red[2 * wave + 1] = q;
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+      red[g * 34 + 2 * wave] = s[g];
+      red[g * 34 + 2 * wave + 1] = q[g];
+    }
   }
   __syncthreads();
-  if (t == 0) {
+  if (t < GPW) {
     float S = 0.f, Q = 0.f;
     for (int w = 0; w < nw; ++w) {
-      S += red[2 * w];
-      Q += red[2 * w + 1];
+      S += red[t * 34 + 2 * w];
+      Q += red[t * 34 + 2 * w + 1];
     }
-    const float n = (float)p.hw * (float)p.cpg;
+    const float n = (float)p.hw * (float)CPG;
     const float mean = S / n;
     const float var = fmaxf(Q / n - mean * mean, 0.f);
-    red[32] = mean;
-    red[33] = rsqrtf(var + p.eps);
+    red[t * 34 + 32] = mean;
+    red[t * 34 + 33] = rsqrtf(var + p.eps);
   }
   __syncthreads();
-  const float mean = red[32], rstd = red[33];
   float a[NV][VW], b[NV][VW];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
@@ -277,8 +287,9 @@ __global__ void gn_fused_kernel(const GnParams p) {
     const vec_t be = *reinterpret_cast<const vec_t*>(p.beta + ch0 + v * VW);
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
-      a[v][i] = rstd * (float)ga[i];
-      b[v][i] = (float)be[i] - mean * a[v][i];
+      const int g = (v * VW + i) / CPG;
+      a[v][i] = red[g * 34 + 33] * (float)ga[i];
+      b[v][i] = (float)be[i] - red[g * 34 + 32] * a[v][i];
     }
   }
 #pragma unroll
@@ -317,11 +328,9 @@ static bool gn_try_fused(const GnParams& p, int batch, hipStream_t s, bool dry) 
     return true;                                                                                  \
   }
   if (a8 && p.cpg == 40) GN_GO(8, 5)
-  if (a8 && p.cpg == 80) GN_GO(8, 10)
   if (a8 && p.cpg == 8) GN_GO(8, 1)
   if (a8 && p.cpg == 16) GN_GO(8, 2)
   if (a4 && p.cpg == 20) GN_GO(4, 5)
-  if (a4 && p.cpg == 60) GN_GO(4, 15)
   if (a4 && p.cpg == 4) GN_GO(4, 1)
   if (a4 && p.cpg == 12) GN_GO(4, 3)
   if (p.cpg == 10 && p.c0 % 2 == 0 && p.c1 % 2 == 0) GN_GO(2, 5)
