@@ -149,6 +149,15 @@ typedef struct vsd_conv_desc {
 
 int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream);
 
+/* `n` (1..VSD_CONV_GROUP_MAX) INDEPENDENT problems as one launch: the reference runs the ControlNet's 13 zero-conv residual
+ * merges of a denoising step (`down_block_additional_residuals`, lcm_controlnet.py:558-577) as 13 cuDNN launches plus 13 adds;
+ * here each is one descriptor: a 1x1 conv with a device-side scale and the UNet tensor as residual, and seven / six of them share a
+ * grid.  Every member as for vsd_conv_gemm, restricted to ONE kernel form for all: the same tile (64x64, 64x128, 128x64 or
+ * 128x128) and pipeline (3 or 5), the buffer-load operand path (Cin % 64 == 0 per source, no resize), split-K only with
+ * `counters` (and then a workspace and a counter slice per member).  Same bits as the members launched one by one. */
+#define VSD_CONV_GROUP_MAX 8
+int vsd_conv_gemm_group(vsd_ctx* ctx, const vsd_conv_desc* descs, int n, void* stream);
+
 /* ---- fused per-token chains of a BasicTransformerBlock at the 320-wide level (csrc/fused_tail.hip) ---------------------
  * One workgroup owns 64 tokens for the whole chain; only the weights stream.  All matrices fp16 row-major, C = 320.
  * Weight operands are the packed forms of videosd_amd/packing.py ([N][K]; LayerNorm-consuming layers hold W*gamma with

@@ -29,6 +29,9 @@ for m in ops:
     if m["op"] == "conv":
         key = ("conv", m["M"], m["N"], m["K"], m["ks"], m["tile"], m["split"])
         assert "conv_gemm" in ks[0]["Kernel_Name"] or "conv_halo" in ks[0]["Kernel_Name"], (m, ks[0]["Kernel_Name"][:60])
+    elif m["op"] == "conv_group":
+        key = ("conv_group", m["members"], m["M"])
+        assert "conv_gemm_group" in ks[0]["Kernel_Name"], (m, ks[0]["Kernel_Name"][:60])
     elif m["op"] in ("tail_a", "tail_b"):
         key = (m["op"], m["M"])
         assert "tail_kernel" in ks[0]["Kernel_Name"], (m, ks[0]["Kernel_Name"][:60])
@@ -51,7 +54,7 @@ frame_ns = int(last[pos - 1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])
 print(f"frame span {frame_ns/1e6:.2f} ms, kernel busy {busy/1e6:.2f} ms, {total} kernels")
 fam = collections.Counter()
 for k, a in agg.items():
-    fam["conv" if k[0] in ("tail_a", "tail_b") else k[0]] += a["ns"] + a["ns2"]
+    fam["conv" if k[0] in ("tail_a", "tail_b", "conv_group") else k[0]] += a["ns"] + a["ns2"]
 print({k: round(v / 1e6, 2) for k, v in fam.items()})
 print(f"{'op':48s} {'cnt':>4s} {'tot ms':>8s} {'avg us':>8s} {'2nd us':>7s} {'TF/s':>7s} {'wGB/s':>7s}")
 for k, a in sorted(agg.items(), key=lambda kv: -(kv[1]["ns"] + kv[1]["ns2"])):

@@ -34,7 +34,7 @@ eng.overlap_controlnet = False
 eng.prepare(size, size, steps, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False, autotune=False)
 ops.upload(eng.frame_u8, torch.from_numpy(_frame(size, size, seed=71)))
 eng._sync_prompt()
-OUT = {"conv": lambda a, k: [a[4], k.get("out_t"), k.get("out2")], "groupnorm": lambda a, k: [a[10]], "attention": lambda a, k: [a[6]],
+OUT = {"conv": lambda a, k: [a[4], k.get("out_t"), k.get("out2")], "conv_group": lambda a, k: [m[0][4] for m in a[0]], "groupnorm": lambda a, k: [a[10]], "attention": lambda a, k: [a[6]],
        "tail_a": lambda a, k: [a[5], a[6]], "tail_b": lambda a, k: [a[8]], "lcm_step_dev": lambda a, k: [a[6], a[7]], "add_noise_dev": lambda a, k: [a[5]]}
 seen = []
 first = None

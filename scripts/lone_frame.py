@@ -58,6 +58,8 @@ for fn, a, k in eng.program.calls:
     if name in Engine.SYNC_OPS:
         continue
     kinds[name] = kinds.get(name, 0) + 1
+    if name == "conv_group":
+        kinds["convs_in_groups"] = kinds.get("convs_in_groups", 0) + len(a[0])
     if name == "conv":
         key = ops.conv_key_of(a[2], a[3], k)
         ent = ops.tile_override.get(key)

@@ -45,6 +45,10 @@ for fn, a, k in eng.program.calls:
         split = min(split, kt); per = -(-kt // split); split = -(-kt // per)
         m.update(M=g.m, N=w.n, K=w.k, ks=g.ksize, stride=g.stride, resize=(g.hi != g.hs), tile=tile, split=split if not ink else -split,
                  flops=2.0 * g.m * w.n * w.k, wbytes=2 * w.n * w.kp, geglu=w.geglu)
+    elif name == "conv_group":  # several independent convs in one grid (the ControlNet merges): one kernel, the members' sums
+        mem = [aa for aa, _kk in a[0]]
+        m.update(members=len(mem), M=sum(aa[2].m for aa in mem), flops=sum(2.0 * aa[2].m * aa[3].n * aa[3].k for aa in mem),
+                 wbytes=sum(2 * aa[3].n * aa[3].kp for aa in mem))
     elif name == "tail_a":
         m.update(M=a[2], flops=2.0 * a[2] * 2 * 320 * 320, wbytes=2 * 2 * 320 * 320)
     elif name == "tail_b":

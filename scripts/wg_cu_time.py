@@ -72,7 +72,10 @@ def family_flops(e):
     fl = dict.fromkeys(FAMS, 0.0)
     for fn, a, k in e.program.calls:
         name = fn.__name__
-        if name == "conv":
+        if name == "conv_group":
+            for aa, _kk in a[0]:
+                fl["conv_gemm"] += 2.0 * aa[2].m * aa[3].n * aa[3].k
+        elif name == "conv":
             g, w = a[2], a[3]
             ent = e.ops.tile_override.get(e.ops.conv_key_of(g, w, k))
             halo = ent is not None and ent[3] == 7

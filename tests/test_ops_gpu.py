@@ -155,6 +155,56 @@ def test_splitk_in_the_launch_on_a_grid_larger_than_the_chip(ops):
     assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
 
 
+def test_conv_group_equals_its_members_launched_one_by_one(ops):
+    """vsd_conv_gemm_group (round 5): several independent problems in ONE grid, every workgroup running what the plain kernel would
+    run for its problem.  Members of different shapes -- the ControlNet merges (1x1, a scale read from device memory, the UNet tensor
+    as residual; M from 64 to 4096, ragged M and N) and a 3x3 layer with a time vector -- in every kernel form a group may take:
+    bit for bit what the members give launched one by one in that form, against fp32 too; the tuned form is remembered per group;
+    what a group cannot hold is refused by name."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv, pack_linear
+
+    members, refs = [], []
+    scales = torch.tensor([0.1, 0.4, 1.0, 2.5, 1.0, 1.0], dtype=torch.float32, device="cuda")
+    for i, (m, c, n) in enumerate([(4096, 320, 320), (1024, 640, 640), (256, 1280, 1280), (64, 1280, 1280), (100, 320, 200)]):
+        x, res = rnd(m, c, seed=10 + i), rnd(m, n, seed=20 + i)
+        wt, b = rnd(n, c, seed=30 + i, scale=c ** -0.5), rnd(n, seed=40 + i, scale=0.1)
+        pw = ops.to_device_pack(pack_linear(wt, b))
+        out = torch.zeros(m, (n + 7) // 8 * 8, dtype=torch.float16, device="cuda")
+        members.append(((x.cuda(), None, Geom.linear(m), pw, out), dict(out_scale_dev=scales[i:i + 1], residual=res.cuda(), ldo=out.shape[1], ldr=n)))
+        refs.append((F.linear(x.float(), wt.float(), b.float()) * float(scales[i]) + res.float(), n))
+    h, w, c, n = 18, 14, 128, 192   # a 3x3 member with a time vector and SiLU
+    x = rnd(1, c, h, w, seed=50)
+    wt, b, rv = rnd(n, c, 3, 3, seed=51, scale=(9 * c) ** -0.5), rnd(n, seed=52, scale=0.1), rnd(n, seed=53, scale=0.1)
+    pw = ops.to_device_pack(pack_conv(wt, b))
+    out = torch.zeros(h * w, n, dtype=torch.float16, device="cuda")
+    members.append(((to_nhwc(x).cuda(), None, Geom.conv(h, w), pw, out), dict(rowvec=rv.cuda(), act=2)))
+    refs.append((to_nhwc(F.silu(F.conv2d(x.float(), wt.float(), b.float(), padding=1) + rv.float()[None, :, None, None])), n))
+    for form in ops.GROUP_FORMS:
+        for a, kw in members:
+            a[4].zero_()
+        ops.conv_group(members, form=form)
+        ops.synchronize()
+        got = [a[4].clone() for a, kw in members]
+        for (a, kw), g_, (ref, n_) in zip(members, got, refs):
+            check(g_[:, :n_], ref, f"group form {form}")
+            a[4].zero_()
+            ops.conv(*a, tile=form[0], split_k=1, pipeline=form[1], **kw)
+            ops.synchronize()
+            assert torch.equal(a[4], g_), f"member alone differs from the group, form {form}"
+    best, table = ops.tune_group(members)
+    assert ops.tile_override[ops.group_key(members)] == (best[1], 1, True, best[4]) and len(table) == len(ops.GROUP_FORMS)
+    ops.conv_group(members)  # (takes the remembered form)
+    ops.synchronize()
+    check(members[0][0][4][:, :320], refs[0][0], "group, tuned form")
+    with pytest.raises(ValueError):
+        ops.conv_group(members + members)  # more than VSD_CONV_GROUP_MAX
+    x8 = rnd(64, 8, seed=60)  # Cin % 64 != 0: the generic operand path, which a group does not have
+    p8 = ops.to_device_pack(pack_linear(rnd(64, 8, seed=61), None))
+    with pytest.raises(RuntimeError, match="buffer-load"):
+        ops.conv_group([((x8.cuda(), None, Geom.linear(64), p8, torch.zeros(64, 64, dtype=torch.float16, device="cuda")), {})])
+
+
 def test_throughput_mode_tuning_times_candidates_with_four_lanes_busy(ops):
     """HipOps.tune_conv with tune_mode = 1: every candidate alone first, then the shortlist with four copies in flight on the four
     launch lanes (captured graphs); the choice lands under a key of its own (last field 1) beside the latency-mode entry, and a

@@ -15,10 +15,16 @@ extern "C" int64_t vsd_wgtl_used(void) { return (int64_t)g_wgtl_off; }
 extern "C" void vsd_cut_set(void* buf) { g_cut = (unsigned long long*)buf; }
 #endif
 
-extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream) {
-  if (!ctx || !d) return VSD_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
+// one launch, ready to go: the kernel's argument block, its form (tile, pipeline, halo) and its grid
+struct ConvLaunch {
   ConvParams p;
+  int BM, BN, grid, stages;
+  bool halo;
+};
+
+// argument checks + everything the host derives from a descriptor (shared by vsd_conv_gemm and vsd_conv_gemm_group)
+static int conv_setup(vsd_ctx* ctx, const vsd_conv_desc* d, ConvLaunch& cl, bool grouped) {
+  ConvParams& p = cl.p;
   p.src0 = (const half_t*)d->src0;
   p.src1 = (const half_t*)d->src1;
   p.c0 = d->c0;
@@ -197,8 +203,25 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     p.fd_tpi = fast_div((unsigned)tpi);
   }
 #ifdef VSD_WG_TIMELINE
-  p.wgtl = wgtl_claim(grid);
+  p.wgtl = grouped ? nullptr : wgtl_claim(grid);
 #endif
+  cl.BM = BM;
+  cl.BN = BN;
+  cl.grid = grid;
+  cl.stages = stages;
+  cl.halo = halo;
+  return VSD_OK;
+}
+
+extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream) {
+  if (!ctx || !d) return VSD_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  ConvLaunch cl;
+  int rc0 = conv_setup(ctx, d, cl, false);
+  if (rc0 != VSD_OK) return rc0;
+  const ConvParams& p = cl.p;
+  const int BM = cl.BM, BN = cl.BN, grid = cl.grid, stages = cl.stages;
+  const bool halo = cl.halo;
   {
     LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
     if (halo) vsd_launch_conv_halo(p, BM, BN, grid, s);
@@ -220,4 +243,45 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     if (rc) return rc;
   }
   return VSD_OK;
+}
+
+// Several independent conv / linear problems as ONE launch (conv_gemm_group_kernel, conv_kernels.h): every descriptor as for
+// vsd_conv_gemm, with these restrictions -- the same tile (64x64, 64x128, 128x64 or 128x128) and pipeline (3 or 5) for all,
+// the buffer-load operand path for all (Cin % 64 == 0 per source, no resize), and split-K only in the in-launch form (each
+// member with a workspace AND a counter slice of its own: no reducer kernel runs for a group).
+extern "C" int vsd_conv_gemm_group(vsd_ctx* ctx, const vsd_conv_desc* descs, int n, void* stream) {
+  if (!ctx || !descs) return VSD_ERR_ARG;
+  if (n < 1 || n > VSD_GROUP_MAX) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm_group: %d problems (1..%d)", n, VSD_GROUP_MAX);
+  hipStream_t s = (hipStream_t)stream;
+  ConvGroup g;
+  int BM = 0, BN = 0, stages = 0, grid = 0;
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) {
+    ConvLaunch cl;
+    int rc = conv_setup(ctx, &descs[i], cl, true);
+    if (rc != VSD_OK) return rc;
+    if (cl.halo || cl.BM == 256 || !cl.p.fast || cl.p.generic || (cl.stages != 3 && cl.stages != 5))
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm_group: member %d needs a 64- / 128-row tile, pipeline 3 or 5 and the buffer-load operand "
+                      "path (Cin %% 64 == 0 per source, no resize)", i);
+    if (cl.p.split_k > 1 && !cl.p.counters)
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm_group: member %d is split over K without counters (a group reduces in the launch)", i);
+    if (i == 0) {
+      BM = cl.BM; BN = cl.BN; stages = cl.stages;
+    } else if (cl.BM != BM || cl.BN != BN || cl.stages != stages) {
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm_group: member %d has another tile / pipeline than member 0", i);
+    }
+    g.p[i] = cl.p;
+    g.start[i] = grid;
+    grid += cl.grid;
+    flops += 2.0 * cl.p.M * (double)cl.p.N * cl.p.K;
+  }
+  for (int i = n; i <= VSD_GROUP_MAX; ++i) g.start[i] = grid;
+  for (int i = n; i < VSD_GROUP_MAX; ++i) g.p[i] = g.p[0];
+  g.n = n;
+  LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, flops);
+  if (BM == 128 && BN == 128) vsd_launch_conv_group_128x128(g, grid, stages, s);
+  else if (BM == 128 && BN == 64) vsd_launch_conv_group_128x64(g, grid, stages, s);
+  else if (BM == 64 && BN == 64) vsd_launch_conv_group_64x64(g, grid, stages, s);
+  else vsd_launch_conv_group_64x128(g, grid, stages, s);
+  return ls.finish();
 }

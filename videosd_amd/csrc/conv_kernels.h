@@ -24,6 +24,7 @@
 #include "common.h"
 
 constexpr int BK = 64;  // halfs per K tile (128-byte LDS rows)
+constexpr int VSD_GROUP_MAX = VSD_CONV_GROUP_MAX;  // problems per grouped launch (conv_gemm_group_kernel; include/vsd.h)
 
 struct ConvParams {
   const half_t* src0;
@@ -88,6 +89,14 @@ struct ConvParams {
   FastDiv fd_span, fd_s, fd_tiles_n, fd_hw_out, fd_wo, fd_tpi, fd_ppr, fd_gx;
 };
 
+// the argument block of a grouped launch (conv_gemm_group_kernel below): problems start[i] <= blockIdx.x < start[i + 1]
+struct ConvGroup {
+  ConvParams p[VSD_GROUP_MAX];
+  int start[VSD_GROUP_MAX + 1];
+  int n;
+};
+static_assert(sizeof(ConvGroup) <= 4000, "the group's argument block must fit the 4 KB kernel-argument segment");
+
 #ifdef VSD_CONV_PROBE
 inline long long* g_conv_probe = nullptr;
 #define CPROBE(I_)                                         \
@@ -115,6 +124,10 @@ void vsd_launch_conv_64x64(const ConvParams& p, int grid, int stages, hipStream_
 void vsd_launch_conv_64x128(const ConvParams& p, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_256x128(const ConvParams& p, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_halo(const ConvParams& p, int bm, int bn, int grid, hipStream_t s);
+void vsd_launch_conv_group_64x64(const ConvGroup& g, int grid, int stages, hipStream_t s);
+void vsd_launch_conv_group_64x128(const ConvGroup& g, int grid, int stages, hipStream_t s);
+void vsd_launch_conv_group_128x64(const ConvGroup& g, int grid, int stages, hipStream_t s);
+void vsd_launch_conv_group_128x128(const ConvGroup& g, int grid, int stages, hipStream_t s);
 void vsd_launch_splitk_reduce(const ConvParams& p, int grid, hipStream_t s);
 
 namespace {
@@ -425,511 +438,39 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   VSD_CUT(VSD_CUT_CONV_GEMM, p.cut)
   prefetch_kernargs();
   WGTL_START()
-  constexpr int WM = 2, WN = 2;             // 2x2 waves
-  constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
-  constexpr int FM = TM / 16, FN = TN / 16;  // 16x16 fragments per wave
-  constexpr int AR = BM / 32, BR = BN / 32;  // 16-byte chunks per thread per K tile
-  constexpr int BNP = BN + 4;                // fp32 epilogue row pitch
-  constexpr int NBUF = STAGES == 0 ? 2 : STAGES;
-  constexpr int STAGE_HALFS = (BM + BN) * BK;
-  constexpr int STAGE_BYTES = NBUF * STAGE_HALFS * 2;
-  constexpr int EPI_BYTES = BM * BNP * 4;
-  constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + BM * 8];  // + per-row (mean, rstd) of a fused LN
-  half_t* As = reinterpret_cast<half_t*>(smem);                                        // register path: [2][BM][64]
-  half_t* Bs = reinterpret_cast<half_t*>(smem) + 2 * BM * BK;                          //                [2][BN][64]
+#define CONV_BID blockIdx.x
+#include "conv_gemm_body.inc"
+#undef CONV_BID
+}
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+// ---------------------------------------------------------------- several problems in one launch
+// Up to VSD_GROUP_MAX independent problems of ONE kernel form (same tile, pipeline, buffer-load path) in one grid: workgroup b
+// belongs to problem i with start[i] <= b < start[i + 1] and runs exactly what the plain kernel would run for it (its own split-K
+// slabs / tickets included: every problem carries its own workspace and counter pointers).  For chains of small launches that do
+// not depend on each other -- the ControlNet's 13 zero-conv merges per denoising step (lcm_controlnet.py:558-577's
+// down_block_additional_residuals): 11.5 us of a lone frame each as launches of their own, measured by leaving them out.
 
-  // block -> (tile_m, tile_n, split).  Workgroups b and b+8 share an XCD (round-robin dispatch), so the tiles_m
-  // workgroups that stream the SAME weight tile (same tile_n / split) are given ids b, b+8, b+16, ...: the tile is
-  // then fetched into one XCD's L2 once instead of once per XCD.  Pure speed: any placement gives the same result.
-  int tile_m, grp;
-  block_to_tile(p, blockIdx.x, tile_m, grp);
-  const int split = fdiv(grp, p.fd_tiles_n);
-  const int tile_n = grp - split * p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int KT = p.Kp / BK;
-  const int kt_begin = split * p.kt_per_split;
-  const int kt_end = min(KT, kt_begin + p.kt_per_split);
+template <int BM, int BN, bool GENERIC, int STAGES, bool ILV, bool FAST>
+__global__ __launch_bounds__(256) void conv_gemm_group_kernel(const ConvGroup g) {
+  int prob = 0;
+#pragma unroll
+  for (int i = 1; i < VSD_GROUP_MAX; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.start[i]) prob = i;
+  const ConvParams& p = g.p[prob];
+  VSD_CUT(VSD_CUT_CONV_GEMM, p.cut)
+  WGTL_START()
+  const int conv_bid = (int)blockIdx.x - g.start[prob];
+#define CONV_BID conv_bid
+#include "conv_gemm_body.inc"
+#undef CONV_BID
+}
 
-  // ---- loader coordinates
-  const int cc = tid & 7;    // 16-byte chunk within the 128-byte tile row
-  const int lr = tid >> 3;   // 0..31
-  int iy0[AR], ix0[AR], ib[AR];  // ib: first source pixel of the row's image
-  bool mvalid[AR];
-  // (a pointwise layer on the buffer-load path needs none of this: its row m reads source pixel m -- two integer divisions
-  // per row, ~0.3 us of a short-K workgroup's prologue)
-  const bool pointwise = FAST && p.pointwise;
-#pragma unroll
-  for (int i = 0; i < AR; ++i) {
-    int m = m0 + lr + 32 * i;
-    mvalid[i] = m < p.M;
-    ib[i] = iy0[i] = ix0[i] = 0;
-    if (!pointwise) {
-      int mm = mvalid[i] ? m : 0;
-      int b = 0;
-      if (p.batch > 1) {
-        b = fdiv(mm, p.fd_hw_out);
-        mm -= b * p.hw_out;
-      }
-      ib[i] = b * p.img_in;
-      int oy = fdiv(mm, p.fd_wo), ox = mm - oy * p.wo;
-      iy0[i] = oy * p.stride - p.pad;
-      ix0[i] = ox * p.stride - p.pad;
-    }
-  }
-  const half_t* wrow[BR];
-  bool nvalid[BR];
-#pragma unroll
-  for (int i = 0; i < BR; ++i) {
-    int n = n0 + lr + 32 * i;
-    nvalid[i] = n < p.N;
-    wrow[i] = p.w + (size_t)(nvalid[i] ? n : 0) * p.Kp + cc * 8;
-  }
-
-  u32x4 areg[AR], breg[BR];
-  const u32x4 zero4 = (u32x4){0u, 0u, 0u, 0u};
-
-// Tile loader (macro, not a lambda: keeps areg/breg in registers).  Loads are unconditional from a
-// clamped, always-valid address and zeroed by a select, so there is no divergent control flow.
-#define VSD_LOAD_TILE(KT_)                                                                          \
-  {                                                                                                 \
-    const int kt_ = (KT_);                                                                          \
-    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                \
-      u32x4 v = *reinterpret_cast<const u32x4*>(wrow[i] + (size_t)kt_ * BK);                        \
-      breg[i] = nvalid[i] ? v : zero4;                                                              \
-    }                                                                                               \
-    int k_, cs_;                                                                                    \
-    const half_t* src_;                                                                             \
-    bool kok_ = true;                                                                               \
-    if (!GENERIC) {                                                                                 \
-      k_ = kt_ * BK; /* uniform: the whole tile lies inside one tap and one source */              \
-    } else {                                                                                        \
-      k_ = kt_ * BK + cc * 8;                                                                       \
-      kok_ = k_ < p.K;                                                                              \
-    }                                                                                               \
-    const int tap_ = k_ / p.cin;                                                                    \
-    int c_ = k_ - tap_ * p.cin;                                                                     \
-    const int ky_ = tap_ / p.ksize, kx_ = tap_ - ky_ * p.ksize;                                     \
-    if (!GENERIC && c_ >= p.c0) {                                                                   \
-      src_ = p.src1; cs_ = p.c1; c_ -= p.c0;                                                        \
-    } else {                                                                                        \
-      src_ = p.src0; cs_ = p.c0;                                                                    \
-    }                                                                                               \
-    if (!GENERIC) c_ += cc * 8;                                                                     \
-    _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                \
-      int iy = iy0[i] + ky_, ix = ix0[i] + kx_;                                                     \
-      bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi; \
-      /* nearest resize as a fixed-point multiply: floor(i*hs/hi) exactly for i*hi < 2^22 (identity: 2^22) */ \
-      const int sy = (int)(((unsigned)iy * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)ix * p.rmul_x) >> p.rshift); \
-      size_t off = ok ? ((size_t)(ib[i] + sy * p.ws + sx)) * cs_ + c_ : 0;                                  \
-      u32x4 v = *reinterpret_cast<const u32x4*>(src_ + off);                                        \
-      areg[i] = ok ? v : zero4;                                                                     \
-    }                                                                                               \
-  }
-#define VSD_STORE_TILE(BUF_)                                                                        \
-  {                                                                                                 \
-    half_t* a_ = As + (BUF_) * BM * BK;                                                             \
-    half_t* b_ = Bs + (BUF_) * BN * BK;                                                             \
-    _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                \
-      int r = lr + 32 * i;                                                                          \
-      *reinterpret_cast<u32x4*>(a_ + r * BK + ((cc ^ (r & 7)) << 3)) = areg[i];                     \
-    }                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                \
-      int r = lr + 32 * i;                                                                          \
-      *reinterpret_cast<u32x4*>(b_ + r * BK + ((cc ^ (r & 7)) << 3)) = breg[i];                     \
-    }                                                                                               \
-  }
-
-#ifdef VSD_CONV_PROBE
-  long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long plast = __builtin_readcyclecounter();
-#endif
-  f32x4 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  float* rowms = reinterpret_cast<float*>(smem + LDS_BYTES);  // per-row (mean, rstd) of a fused input LayerNorm
-// issued right after the prologue tile loads so that its memory latency overlaps theirs
-#define VSD_LN_ROWSTATS()                                              \
-  if (p.ln_part && tid < BM) {                                         \
-    float mean = 0.f, rstd = 0.f;                                      \
-    if (m0 + tid < p.M) ln_row_stats(p, m0 + tid, mean, rstd);         \
-    rowms[2 * tid] = mean;                                             \
-    rowms[2 * tid + 1] = rstd;                                         \
-  }
-  const int fr = lane & 15;  // fragment row (A) / column (B)
-  const int fq = lane >> 4;  // k-chunk quarter
-
-  if constexpr (STAGES == 0) {
-    if (kt_begin < kt_end) {
-      VSD_LOAD_TILE(kt_begin)
-      VSD_LN_ROWSTATS()
-      VSD_STORE_TILE(0)
-    } else {
-      VSD_LN_ROWSTATS()
-    }
-    __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int buf = (kt - kt_begin) & 1;
-      const bool more = kt + 1 < kt_end;
-      if (more) VSD_LOAD_TILE(kt + 1)
-      const half_t* a = As + buf * BM * BK;
-      const half_t* b = Bs + buf * BN * BK;
-  #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        half8 af[FM], bf[FN];
-  #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          int r = wm * TM + i * 16 + fr;
-          af[i] = *reinterpret_cast<const half8*>(a + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
-        }
-  #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          int r = wn * TN + j * 16 + fr;
-          bf[j] = *reinterpret_cast<const half8*>(b + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
-        }
-  #pragma unroll
-        for (int i = 0; i < FM; ++i)
-  #pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
-      if (more) VSD_STORE_TILE(buf ^ 1)
-      __syncthreads();
-    }
-  } else {
-    // ------------------------------------------------------------ direct-to-LDS ring
-    constexpr int LPT = AR + BR;            // LDS-DMA instructions per thread per tile
-    const int lc = cc ^ (lr & 7);           // logical 16-byte chunk this lane fetches; it lands in slot cc of its row
-    const int nt = kt_end - kt_begin;
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-    // ---- FAST path state (see the kernel's header comment)
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // scalar: the DMA's LDS base goes to M0 without a v_readfirstlane
-    [[maybe_unused]] int apix[AR];          // centre pixel (oy*stride, ox*stride) of the row, in pixels from the tensor start
-    [[maybe_unused]] unsigned tapmask[AR];  // bit (ky*ksize + kx): that tap of this row lies inside the image
-    [[maybe_unused]] int bvoff[BR];         // weight row byte offset (+ this lane's chunk), or out of range
-    [[maybe_unused]] int cur_c = 0, cur_tap = 0, cur_ky = 0, cur_kx = 0, cur_kt = kt_begin;  // scalar cursor: next tile to fetch
-    // the A descriptors start (pad*ws + pad) pixels BEFORE the tensor: soffset = (ky*ws + kx)*cs*2 + c*2 is then
-    // never negative; a lane only ever adds it to a centre pixel whose tap is inside the image.  (Descriptors are
-    // rebuilt from these scalars per tile: a handful of SALU moves.)
-    const int neg_pix = p.pad * p.ws + p.pad;
-    [[maybe_unused]] const half_t* abase0 = p.src0 - (size_t)neg_pix * p.c0;
-    [[maybe_unused]] const half_t* abase1 = (p.src1 ? p.src1 : p.src0) - (size_t)neg_pix * p.c1;
-    [[maybe_unused]] const int anr0 = (int)(((size_t)p.batch * p.img_in + neg_pix) * p.c0 * 2);
-    [[maybe_unused]] const int anr1 = (int)(((size_t)p.batch * p.img_in + neg_pix) * p.c1 * 2);
-    [[maybe_unused]] const int bnr = (int)((size_t)p.N * p.Kp * 2);
-    constexpr int OOB = (int)0x80000000;
-    if constexpr (FAST) {
-#pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        if (pointwise) {
-          apix[i] = mvalid[i] ? m0 + lr + 32 * i : 0;
-          tapmask[i] = mvalid[i] ? 1u : 0u;
-          continue;
-        }
-        apix[i] = ib[i] + (iy0[i] + p.pad) * p.ws + (ix0[i] + p.pad);
-        unsigned mk = 0;
-        for (int ky = 0; ky < p.ksize; ++ky)
-          for (int kx = 0; kx < p.ksize; ++kx) {
-            const bool in = mvalid[i] && (unsigned)(iy0[i] + ky) < (unsigned)p.hi && (unsigned)(ix0[i] + kx) < (unsigned)p.wi;
-            mk |= (in ? 1u : 0u) << (ky * p.ksize + kx);
-          }
-        tapmask[i] = mk;
-      }
-#pragma unroll
-      for (int i = 0; i < BR; ++i) {
-        const int n = n0 + lr + 32 * i;
-        bvoff[i] = n < p.N ? n * p.Kp * 2 + lc * 16 : OOB;
-      }
-      if (kt_begin > 0) {  // (only a later K split starts inside the tap / channel sequence)
-        const int k0 = kt_begin * BK;
-        cur_tap = k0 / p.cin;
-        cur_c = k0 - cur_tap * p.cin;
-        cur_ky = cur_tap / p.ksize;
-        cur_kx = cur_tap - cur_ky * p.ksize;
-      }
-    }
-// fetch the cursor's tile into ring slot SLOT_, then (ADV_) move the cursor one K tile on
-#define VSD_ISSUE_FAST(SLOT_, ADV_)                                                                    \
-  {                                                                                                    \
-    half_t* a_ = reinterpret_cast<half_t*>(smem) + (SLOT_) * STAGE_HALFS;                              \
-    half_t* b_ = a_ + BM * BK;                                                                         \
-    const int soff_b_ = cur_kt * (BK * 2);                                                             \
-    /* (descriptors are made next to their use: hipcc drops the host stub of a kernel that reads one declared in an \
-       outer scope) */                                                                                 \
-    const __amdgpu_buffer_rsrc_t rsb_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, bnr, 0x00020000); \
-    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                   \
-      const int bv_ = bvoff[i] + 0;                                                                    \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb_, (lds_ptr_t)(b_ + (8 * wave_s + 32 * i) * BK), 16, bv_, soff_b_, 0, 0); \
-    }                                                                                                  \
-    const bool second_ = cur_c >= p.c0;                                                                \
-    const int cs2_ = (second_ ? p.c1 : p.c0) * 2;                                                      \
-    const int soff_a_ = (cur_ky * p.ws + cur_kx) * cs2_ + (second_ ? cur_c - p.c0 : cur_c) * 2;        \
-    const __amdgpu_buffer_rsrc_t rs_ =                                                                 \
-        __builtin_amdgcn_make_buffer_rsrc((void*)(second_ ? abase1 : abase0), 0, second_ ? anr1 : anr0, 0x00020000); \
-    const unsigned bit_ = 1u << cur_tap;                                                               \
-    _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                   \
-      const int vo_ = (tapmask[i] & bit_) ? __mul24(apix[i], cs2_) + lc * 16 : OOB; /* < 2^24 pixels: host check */                            \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)(a_ + (8 * wave_s + 32 * i) * BK), 16, vo_, soff_a_, 0, 0); \
-    }                                                                                                  \
-    if (ADV_) {                                                                                        \
-      ++cur_kt;                                                                                        \
-      cur_c += BK;                                                                                     \
-      if (cur_c >= p.cin) {                                                                            \
-        cur_c = 0;                                                                                     \
-        ++cur_tap;                                                                                     \
-        if (++cur_kx == p.ksize) {                                                                     \
-          cur_kx = 0;                                                                                  \
-          ++cur_ky;                                                                                    \
-        }                                                                                              \
-      }                                                                                                \
-    }                                                                                                  \
-  }
-#define VSD_ISSUE_TILE(KT_, SLOT_)                                                                    \
-  {                                                                                                   \
-    const int kt_ = (KT_);                                                                            \
-    half_t* a_ = reinterpret_cast<half_t*>(smem) + (SLOT_) * STAGE_HALFS;                             \
-    half_t* b_ = a_ + BM * BK;                                                                        \
-    _Pragma("unroll") for (int i = 0; i < BR; ++i) {                                                  \
-      const half_t* g_ = nvalid[i] ? (wrow[i] - cc * 8 + lc * 8 + (size_t)kt_ * BK) : p.zeros;        \
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(b_ + (8 * wave + 32 * i) * BK), 16, 0, 0); \
-    }                                                                                                 \
-    int k_, cs_;                                                                                      \
-    const half_t* src_;                                                                               \
-    bool kok_ = true;                                                                                 \
-    if (!GENERIC) {                                                                                   \
-      k_ = kt_ * BK;                                                                                  \
-    } else {                                                                                          \
-      k_ = kt_ * BK + lc * 8;                                                                         \
-      kok_ = k_ < p.K;                                                                                \
-    }                                                                                                 \
-    const int tap_ = k_ / p.cin;                                                                      \
-    int c_ = k_ - tap_ * p.cin;                                                                       \
-    const int ky_ = tap_ / p.ksize, kx_ = tap_ - ky_ * p.ksize;                                       \
-    if (!GENERIC && c_ >= p.c0) {                                                                     \
-      src_ = p.src1; cs_ = p.c1; c_ -= p.c0;                                                          \
-    } else {                                                                                          \
-      src_ = p.src0; cs_ = p.c0;                                                                      \
-    }                                                                                                 \
-    if (!GENERIC) c_ += lc * 8;                                                                       \
-    _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                  \
-      int iy = iy0[i] + ky_, ix = ix0[i] + kx_;                                                       \
-      bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi;  \
-      const int sy = (int)(((unsigned)iy * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)ix * p.rmul_x) >> p.rshift); \
-      const half_t* g_ = ok ? src_ + ((size_t)(ib[i] + sy * p.ws + sx)) * cs_ + c_ : p.zeros;                 \
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(a_ + (8 * wave + 32 * i) * BK), 16, 0, 0); \
-    }                                                                                                 \
-  }
-    if constexpr (!ILV) {
-  #pragma unroll
-      for (int st = 0; st < STAGES - 1; ++st)
-        if (st < nt) {
-          if constexpr (FAST) VSD_ISSUE_FAST(st, true)
-          else VSD_ISSUE_TILE(kt_begin + st, st)
-        }
-      VSD_LN_ROWSTATS()
-      CPROBE(0)
-      WGTL_MARK(c)
-      int slot = 0;
-      for (int t = 0; t < nt; ++t) {
-        // tile t has landed once all but the younger tiles' loads are done; then everyone's has (barrier)
-        const int rem = min(STAGES - 2, nt - 1 - t);
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        CPROBE(1)
-        __builtin_amdgcn_s_barrier();
-        CPROBE(2)
-        if (t + STAGES - 1 < nt) {
-          int ns = slot + STAGES - 1;
-          if (ns >= STAGES) ns -= STAGES;
-          if constexpr (FAST) VSD_ISSUE_FAST(ns, true)
-          else VSD_ISSUE_TILE(kt_begin + t + STAGES - 1, ns)
-        }
-        CPROBE(3)
-        const half_t* a = reinterpret_cast<const half_t*>(smem) + slot * STAGE_HALFS;
-        const half_t* b = a + BM * BK;
-  #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          half8 af[FM], bf[FN];
-  #pragma unroll
-          for (int i = 0; i < FM; ++i) {
-            int r = wm * TM + i * 16 + fr;
-            af[i] = *reinterpret_cast<const half8*>(a + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
-          }
-  #pragma unroll
-          for (int j = 0; j < FN; ++j) {
-            int r = wn * TN + j * 16 + fr;
-            bf[j] = *reinterpret_cast<const half8*>(b + r * BK + (((ks * 4 + fq) ^ (r & 7)) << 3));
-          }
-  #pragma unroll
-          for (int i = 0; i < FM; ++i)
-  #pragma unroll
-            for (int j = 0; j < FN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        CPROBE(4)
-        if (++slot == STAGES) slot = 0;
-      }
-
-    } else {
-      // Interleaved form: every iteration is ONE basic block -- the next tile's LDS-DMA issue is unconditional (tile
-      // index clamped: the last iterations re-fetch the final tile into a slot nobody reads) so the wait count is a
-      // constant and the scheduler may spread the DMA issues and LDS fragment reads between the MFMAs
-      // (sched_group_barrier), instead of running "all loads, then all reads, then all MFMAs" back to back.
-      const int kt_last = kt_end - 1;
-#pragma unroll
-      for (int st = 0; st < STAGES - 1; ++st) {
-        if constexpr (FAST) VSD_ISSUE_FAST(st, cur_kt < kt_last)
-        else VSD_ISSUE_TILE(min(kt_begin + st, kt_last), st)
-      }
-      VSD_LN_ROWSTATS()
-      WGTL_MARK(c)
-      int slot = 0;
-      constexpr int NM = FM * FN * 2;       // MFMAs per tile per wave
-      for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPT) : "memory");
-        __builtin_amdgcn_s_barrier();
-        int ns = slot + STAGES - 1;
-        if (ns >= STAGES) ns -= STAGES;
-        // ---- per-tile scalars of the tile to fetch (same arithmetic as VSD_ISSUE_TILE / VSD_ISSUE_FAST)
-        half_t* na = reinterpret_cast<half_t*>(smem) + ns * STAGE_HALFS;
-        half_t* nb = na + BM * BK;
-        [[maybe_unused]] int ktn = 0, k_ = 0, cs_ = 0, c_ = 0, ky_ = 0, kx_ = 0;
-        [[maybe_unused]] const half_t* src_ = nullptr;
-        [[maybe_unused]] bool kok_ = true;
-        [[maybe_unused]] int f_soff_b = 0, f_soff_a = 0, f_cs2 = 0;
-        [[maybe_unused]] unsigned f_bit = 0;
-        const bool f_second = FAST && cur_c >= p.c0;
-        [[maybe_unused]] const __amdgpu_buffer_rsrc_t f_rs =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(f_second ? abase1 : abase0), 0, f_second ? anr1 : anr0, 0x00020000);
-        [[maybe_unused]] const __amdgpu_buffer_rsrc_t f_rsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, bnr, 0x00020000);
-        if constexpr (FAST) {
-          f_soff_b = cur_kt * (BK * 2);
-          f_cs2 = (f_second ? p.c1 : p.c0) * 2;
-          f_soff_a = (cur_ky * p.ws + cur_kx) * f_cs2 + (f_second ? cur_c - p.c0 : cur_c) * 2;
-          f_bit = 1u << cur_tap;
-        } else {
-          ktn = min(kt_begin + t + STAGES - 1, kt_last);
-          if (!GENERIC) {
-            k_ = ktn * BK;
-          } else {
-            k_ = ktn * BK + lc * 8;
-            kok_ = k_ < p.K;
-          }
-          const int tap_ = k_ / p.cin;
-          c_ = k_ - tap_ * p.cin;
-          ky_ = tap_ / p.ksize;
-          kx_ = tap_ - ky_ * p.ksize;
-          if (!GENERIC && c_ >= p.c0) {
-            src_ = p.src1; cs_ = p.c1; c_ -= p.c0;
-          } else {
-            src_ = p.src0; cs_ = p.c0;
-          }
-          if (!GENERIC) c_ += lc * 8;
-        }
-        const half_t* a = reinterpret_cast<const half_t*>(smem) + slot * STAGE_HALFS;
-        const half_t* b = a + BM * BK;
-        half8 af[2][FM], bf[2][FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          int r = wm * TM + i * 16 + fr;
-          af[0][i] = *reinterpret_cast<const half8*>(a + r * BK + (((fq) ^ (r & 7)) << 3));
-        }
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          int r = wn * TN + j * 16 + fr;
-          bf[0][j] = *reinterpret_cast<const half8*>(b + r * BK + (((fq) ^ (r & 7)) << 3));
-        }
-        // ---- LPT pieces: one LDS-DMA issue, then MPP MFMAs; the k-step-1 fragments are read half way
-#pragma unroll
-        for (int pc = 0; pc < LPT; ++pc) {
-          if constexpr (FAST) {
-            if (pc < BR) {
-              const int bv_ = bvoff[pc < BR ? pc : 0] + 0;
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rsb, (lds_ptr_t)(nb + (8 * wave_s + 32 * pc) * BK), 16, bv_, f_soff_b, 0, 0);
-            } else {
-              const int i = pc - BR;
-              const int vo_ = (tapmask[i] & f_bit) ? __mul24(apix[i], f_cs2) + lc * 16 : OOB;
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(f_rs, (lds_ptr_t)(na + (8 * wave_s + 32 * i) * BK), 16, vo_, f_soff_a, 0, 0);
-            }
-          } else if (pc < BR) {
-            const int i = pc;
-            const half_t* g_ = nvalid[i] ? (wrow[i] - cc * 8 + lc * 8 + (size_t)ktn * BK) : p.zeros;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(nb + (8 * wave + 32 * i) * BK), 16, 0, 0);
-          } else {
-            const int i = pc - BR;
-            int iy = iy0[i] + ky_, ix = ix0[i] + kx_;
-            bool ok = kok_ && mvalid[i] && (unsigned)iy < (unsigned)p.hi && (unsigned)ix < (unsigned)p.wi;
-            const int sy = (int)(((unsigned)iy * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)ix * p.rmul_x) >> p.rshift);
-            const half_t* g_ = ok ? src_ + ((size_t)(ib[i] + sy * p.ws + sx)) * cs_ + c_ : p.zeros;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)g_, (lds_ptr_t)(na + (8 * wave + 32 * i) * BK), 16, 0, 0);
-          }
-          // (256-row tiles: both k-steps' fragments live at once are 96 registers on top of 128 accumulators -- the compiler then
-          //  shuffles accumulators through AGPR copies inside the loop (340 v_accvgpr moves per tile seen); their k-step-1
-          //  fragments are therefore read two pieces before they are needed instead of at the top)
-          if (pc == (BM >= 256 ? LPT / 2 - 2 : 0)) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-              int r = wm * TM + i * 16 + fr;
-              af[1][i] = *reinterpret_cast<const half8*>(a + r * BK + (((4 + fq) ^ (r & 7)) << 3));
-            }
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-              int r = wn * TN + j * 16 + fr;
-              bf[1][j] = *reinterpret_cast<const half8*>(b + r * BK + (((4 + fq) ^ (r & 7)) << 3));
-            }
-          }
-#pragma unroll
-          for (int idx = pc * NM / LPT; idx < (pc + 1) * NM / LPT; ++idx) {  // this piece's share of the NM MFMAs
-            const int ks = idx / (FM * FN), ij = idx % (FM * FN);        // k-step 0 first, then k-step 1
-            const int i = ij / FN, j = ij % FN;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);  // keep the DMA / MFMA alternation as written
-        }
-        if constexpr (FAST) {
-          if (cur_kt < kt_last) {  // clamped like ktn: past the end the last tile is fetched again into a slot nobody reads
-            ++cur_kt;
-            cur_c += BK;
-            if (cur_c >= p.cin) {
-              cur_c = 0;
-              ++cur_tap;
-              if (++cur_kx == p.ksize) {
-                cur_kx = 0;
-                ++cur_ky;
-              }
-            }
-          }
-        }
-        if (++slot == STAGES) slot = 0;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail fetches must land before the LDS is reused
-    }
-    __syncthreads();  // every wave is done reading the ring before the epilogue reuses the LDS
-#undef VSD_ISSUE_TILE
-#undef VSD_ISSUE_FAST
-  }
-
-  WGTL_LOOP()
-#define EPI_PART split
-#define EPI_NPARTS p.split_k
-#define EPI_EXIT { WGTL_END(0) return; }
-#include "conv_epilogue.inc"
-#undef EPI_PART
-#undef EPI_NPARTS
-#undef EPI_EXIT
-  CPROBE(6)
-  CPROBE_OUT()
-  WGTL_END(0)
+template <int BM, int BN>
+void launch_group(const ConvGroup& g, int grid, int stages, hipStream_t s) {
+  // (buffer-load path only: every member has Cin % 64 == 0 per source and no resize; pipelines 3 / 5 = the 3-stage ring, plain /
+  //  interleaved)
+  if (stages == 5) hipLaunchKernelGGL((conv_gemm_group_kernel<BM, BN, false, 3, true, true>), dim3(grid), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((conv_gemm_group_kernel<BM, BN, false, 3, false, true>), dim3(grid), dim3(256), 0, s, g);
 }
 
 // the FAST form exists for the direct-to-LDS rings only (STAGES >= 3)

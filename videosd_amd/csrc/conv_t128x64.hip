@@ -2,3 +2,4 @@
 #include "conv_kernels.h"
 
 void vsd_launch_conv_128x64(const ConvParams& p, int grid, int stages, hipStream_t s) { launch<128, 64>(p, grid, stages, s); }
+void vsd_launch_conv_group_128x64(const ConvGroup& g, int grid, int stages, hipStream_t s) { launch_group<128, 64>(g, grid, stages, s); }

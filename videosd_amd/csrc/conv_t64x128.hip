@@ -2,3 +2,4 @@
 #include "conv_kernels.h"
 
 void vsd_launch_conv_64x128(const ConvParams& p, int grid, int stages, hipStream_t s) { launch<64, 128>(p, grid, stages, s); }
+void vsd_launch_conv_group_64x128(const ConvGroup& g, int grid, int stages, hipStream_t s) { launch_group<64, 128>(g, grid, stages, s); }

@@ -453,6 +453,7 @@ class Engine:
         self._want = None       # `use_prompt`: this engine's prompt (None: the family default)
         self.absorb_cross_attention = True  # cross-attention of the wide blocks as two GEMMs (vsd_xattn_fold)
         self.use_fused_tail = True          # 320-wide blocks: per-token chains as fused launches (csrc/fused_tail.hip)
+        self.group_merges = not __import__("os").environ.get("VSD_NO_GROUP")  # the ControlNet merges of a step as two grouped launches
         self.tail_b_min_rows = 1024         # ... the feed-forward chain from this many tokens per launch on (see _transformer)
 
     def make_slot(self, share_plan: bool = True, lane: Optional[int] = None) -> "Engine":
@@ -850,6 +851,26 @@ class Engine:
         # needs them, each followed by a named event the consuming ResnetBlock waits for.
         side = self.overlap_controlnet and self.use_side_stream
         merged = [None] * len(cn_skips)
+        if not side and self.group_merges and hasattr(self.ops, "conv_group"):
+            # The 13 merges do not depend on each other and are small (11.5 us of a lone frame each as launches of their own: leaving
+            # the 12 skip merges out of a 4-step frame takes 0.55 ms off it): ONE grid per group of up to eight of them
+            # (vsd_conv_gemm_group) -- first the mid block's and the deepest skips' (what the decoder needs first), then the rest.
+            hh, ww = sizes[-1]
+            rows = self.batch * hh * ww
+            mid = a.alloc(rows, net.cfg.block_out_channels[-1])
+            calls = [((cn_mid, None, Geom.linear(rows), net.zero_mid, mid), dict(out_scale_dev=sc[nres - 1:nres], residual=u_mid))]
+            for i in reversed(range(len(cn_skips))):
+                (s, c, lvl), (us, uc, ulvl) = cn_skips[i], u_skips[i]
+                assert (c, lvl) == (uc, ulvl)
+                hh, ww = sizes[lvl]
+                rows = self.batch * hh * ww
+                o = a.alloc(rows, c)
+                calls.append(((s, None, Geom.linear(rows), net.zero_convs[i], o), dict(out_scale_dev=sc[i:i + 1], residual=us)))
+                merged[i] = (o, c, lvl, None)
+            gmax = 7
+            for g0 in range(0, len(calls), gmax):
+                r.conv_group(calls[g0:g0 + gmax])
+            return mid, merged
         if side:
             r.signal("enc_done")
             r.use_stream(1)
@@ -948,6 +969,14 @@ class Engine:
         online = mode == 0 or getattr(ops, "tune_lanes_online", False)
         try:
             for fn, a, k in self.program.calls:
+                if fn.__name__ == "conv_group" and hasattr(ops, "tune_group"):
+                    ops.tune_mode = mode if online else 0  # (a group's form is timed alone either way; see ops.tune_group)
+                    key = ops.group_key(a[0])
+                    if key not in seen and key not in ops.tile_override:
+                        seen[key] = ops.tune_group(a[0])[0]
+                        if verbose:
+                            print("tune", key, "->", seen[key], flush=True)
+                    continue
                 if fn.__name__ != "conv":
                     continue
                 ops.tune_mode = mode

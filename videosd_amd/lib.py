@@ -12,6 +12,7 @@ ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_QUICKGELU, ACT_SOFTMAX, ACT_GELU = 
 ACT_POST = 256
 SPLITK_MAX_TILES = 16384
 POOL_STREAMS = 4  # include/vsd.h VSD_POOL_STREAMS
+CONV_GROUP_MAX = 8  # include/vsd.h VSD_CONV_GROUP_MAX
 TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128, TILE_256x128, TILE_256x64 = range(6)
 TILE_DIMS = {TILE_128x128: (128, 128), TILE_128x64: (128, 64), TILE_64x64: (64, 64), TILE_64x128: (64, 128),
              TILE_256x128: (256, 128), TILE_256x64: (256, 64)}
@@ -58,6 +59,7 @@ SIGNATURES = {
     "vsd_destroy": (None, [C.c_void_p]),
     "vsd_last_error": (C.c_char_p, [C.c_void_p]),
     "vsd_conv_gemm": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p]),
+    "vsd_conv_gemm_group": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "vsd_tail_a": (C.c_int, [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 3),
     "vsd_tail_b": (C.c_int, [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 6),
     "vsd_groupnorm_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

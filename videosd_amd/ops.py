@@ -328,7 +328,7 @@ class HipOps:
     def conv(self, src0, src1, g: Geom, w: PackedConv, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None,
              residual2=None, ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0,
              t_col0=0, tile=None, split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None,
-             ln_eps=1e-5, chanstat_out=None, t_img=0, out_scale_dev=None, softmax_cols=0):
+             ln_eps=1e-5, chanstat_out=None, t_img=0, out_scale_dev=None, softmax_cols=0, _desc_only=False):
         """t_img: with g.batch > 1, columns of out_t per image (image b's pixels start at column b * t_img).
         out_scale_dev: one fp32 in device memory that replaces out_scale at run time (changeable under a captured graph)."""
         m = g.m
@@ -396,7 +396,62 @@ class HipOps:
                 d.counters = self._p(self._counters[self._sidx])
         elif workspace is not None:  # (development probes pass a buffer through)
             d.workspace = self._p(workspace)
+        if _desc_only:
+            return d
         self.ctx.call("vsd_conv_gemm", C.byref(d), self.s)
+
+    # ---- several independent convs as ONE launch (include/vsd.h vsd_conv_gemm_group)
+    GROUP_FORMS = [(L.TILE_64x64, 3), (L.TILE_64x64, 5), (L.TILE_64x128, 3), (L.TILE_64x128, 5), (L.TILE_128x64, 3), (L.TILE_128x64, 5),
+                   (L.TILE_128x128, 3), (L.TILE_128x128, 5)]
+
+    def group_key(self, calls):
+        k = ["group"]
+        for a, kw in calls:
+            k += [a[2].m, a[3].n, a[3].kp]
+        return tuple(k) + (int(self.tune_mode),)
+
+    def conv_group(self, calls, form=None):
+        """calls: [(args, kwargs), ...] as for `conv` (1 x 1 / 3 x 3 layers on the buffer-load path, no split-K): ONE launch for all
+        of them, every member in the same kernel form (tile, pipeline) -- `form`, else this group's entry of the tuning table
+        (`tune_group`), else 64 x 64 tiles on the 3-stage ring.  Same bits as the members launched one by one in that form."""
+        if not 1 <= len(calls) <= L.CONV_GROUP_MAX:
+            raise ValueError(f"conv_group: {len(calls)} members (1..{L.CONV_GROUP_MAX})")
+        if form is None:
+            ent = self.tile_override.get(self.group_key(calls))
+            if ent is None and self.tune_mode == 1:
+                ent = self.tile_override.get(self.group_key(calls)[:-1] + (0,))
+            form = (ent[0], ent[3]) if ent is not None else (L.TILE_64x64, 3)
+        descs = (L.ConvDesc * len(calls))()
+        for i, (a, kw) in enumerate(calls):
+            kw = {k: v for k, v in kw.items() if k not in ("tile", "split_k", "pipeline")}
+            descs[i] = self.conv(*a, tile=form[0], split_k=1, pipeline=form[1], _desc_only=True, **kw)
+        self.ctx.call("vsd_conv_gemm_group", descs, len(calls), self.s)
+
+    def tune_group(self, calls, reps: int = 12):
+        """time the kernel forms a group may take (GROUP_FORMS) back to back on this stream; remember the fastest"""
+        table = []
+        for form in self.GROUP_FORMS:
+            try:
+                for _ in range(2):
+                    self.conv_group(calls, form=form)
+                best = 1e30
+                for _trial in range(2):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.stream)
+                    for _ in range(reps):
+                        self.conv_group(calls, form=form)
+                    e1.record(self.stream)
+                    e1.synchronize()
+                    best = min(best, e0.elapsed_time(e1) / reps * 1e3)
+                table.append((best, form[0], 1, True, form[1]))
+            except RuntimeError:
+                continue
+        if not table:
+            raise RuntimeError("tune_group: no kernel form ran for this group")
+        table.sort()
+        b = table[0]
+        self.tile_override[self.group_key(calls)] = (b[1], b[2], b[3], b[4])
+        return b, table
 
     @staticmethod
     def _halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part) -> bool:
