@@ -272,6 +272,21 @@ int vsd_postprocess_rgb(vsd_ctx* ctx, const void* img, int ld, int hw, void* rgb
 /* out = a + b * scale   (fp16, n elements, n % 8 == 0) */
 int vsd_axpy(vsd_ctx* ctx, const void* a, const void* b, float scale, int64_t n, void* out, void* stream);
 
+/* ---- two independent operations as ONE grid per kernel ------------------------------------------------
+ * The reference runs the ControlNet and then the UNet encoder of a denoising step -- the same topology with two weight sets on the
+ * same latents (lcm_controlnet.py:539-577) -- as two sequences of cuDNN / cuBLAS launches.  Here the two walk in lock step:
+ *     pair_begin(ctx); op(ctx, A...); pair_join(ctx); op(ctx, B...); pair_end(ctx, &joined);
+ * every launch of the first operation is held back, and the second operation's k-th launch joins the k-th held one when it is
+ * the same kernel with the same launch geometry on the same stream (one grid, gridDim.z = 2: half the launches, twice the
+ * workgroups per launch); a launch that finds no partner goes out alone, in order -- the results never depend on what joined.
+ * Pairable today: vsd_groupnorm*, vsd_attention*, vsd_tail_a / vsd_tail_b (two convolutions share a grid through
+ * vsd_conv_gemm_group).  The two operations must not depend on each other and must use separate scratch.  `joined_out` (may be
+ * null) receives the number of launches that went out as pairs.  While profiling (vsd_profile_begin) every launch goes out alone:
+ * the per-family times are those of single launches. */
+int vsd_pair_begin(vsd_ctx* ctx);
+int vsd_pair_join(vsd_ctx* ctx);
+int vsd_pair_end(vsd_ctx* ctx, int* joined_out);
+
 /* ---- hipGraph capture / replay (reference intent: compile_model, videopipeline.py:35-47) ----------- */
 int vsd_graph_begin(vsd_ctx* ctx, void* stream);
 int vsd_graph_end(vsd_ctx* ctx, void* stream, void** graph_exec_out);

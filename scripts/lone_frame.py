@@ -51,26 +51,8 @@ t0 = time.perf_counter()
 plan = eng.prepare(512, 512, 4, 0.6, use_controlnet=use_cn, batch=1, use_graph=True)
 prepare_s = time.perf_counter() - t0
 
-# launches of the one-frame program by kind (what a graph replay issues)
-kinds = {}
-for fn, a, k in eng.program.calls:
-    name = fn.__name__
-    if name in Engine.SYNC_OPS:
-        continue
-    kinds[name] = kinds.get(name, 0) + 1
-    if name == "conv_group":
-        kinds["convs_in_groups"] = kinds.get("convs_in_groups", 0) + len(a[0])
-    if name == "conv":
-        key = ops.conv_key_of(a[2], a[3], k)
-        ent = ops.tile_override.get(key)
-        if ent is not None and ent[1] > 1 and not ent[2] and not a[3].tile128:
-            kinds["splitk_reduce"] = kinds.get("splitk_reduce", 0) + 1
-    if name == "groupnorm":  # (csrc/norm.hip gn_try_fused: one launch for small images, else statistics + apply)
-        c, hw, groups = a[2] + a[3], a[4], a[5]
-        cpg = c // groups
-        fused = ((hw <= 256 and cpg <= 40) or (hw <= 1024 and cpg <= 20)) and cpg in (40, 80, 8, 16, 20, 60, 4, 12, 10, 2, 6)
-        if not fused:
-            kinds["gn_second"] = kinds.get("gn_second", 0) + 1
+launches, kinds = eng.launches_by_kind()  # what a graph replay issues: the two-stream form (a lone launch) ...
+launches_serial, kinds_serial = eng.launches_by_kind(serial=True)  # ... and the one-stream form (a launch among busy lanes)
 
 frames = np.random.default_rng(0).integers(0, 256, (12, 512, 512, 3), dtype=np.uint8)
 for i in range(5):
@@ -83,7 +65,8 @@ for i in range(40):
     gpu.append(getattr(eng, "last_gpu_ms", 0.0))
 out = {"tag": tag, "controlnet": use_cn, "retune": retune, "table_entries_loaded": n_loaded, "prepare_s": round(prepare_s, 2),
        "p50_ms": round(statistics.median(lat), 3), "min_ms": round(min(lat), 3), "gpu_p50_ms": round(statistics.median(gpu), 3),
-       "n_ops": plan["n_ops"], "launches_by_kind": kinds, "graphs": plan.get("graphs"), "edges": plan.get("edges")}
+       "n_ops": plan["n_ops"], "launches": launches, "launches_by_kind": kinds, "launches_one_stream_form": launches_serial,
+       "launches_by_kind_one_stream_form": kinds_serial, "graphs": plan.get("graphs"), "edges": plan.get("edges")}
 
 # the serial sequence (everything on the lane's own stream): what a launch takes when three or four lanes are busy
 ops.synchronize()

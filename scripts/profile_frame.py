@@ -23,6 +23,7 @@ eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
 eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half())
 ops.load_tuning(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tuning_mi355x.json"))
 eng.overlap_controlnet = False
+eng.twin_encoders = False  # (a table of LAYERS: the two encoders' twin layers as launches of their own)
 eng.prepare(size, size, 4, 0.6, use_controlnet=cn, use_graph=False, batch=batch)
 meta = []
 for fn, a, k in eng.program.calls:

@@ -25,7 +25,7 @@ EPI = ["plain", "ln", "rowstat", "ln+rowstat", "softmax", "general", "plain+act"
 want = {(256, 1280, 1280), (64, 1280, 1280), (256, 1024, 1280), (64, 1024, 1280), (256, 3840, 1280), (64, 1280, 2560), (256, 1280, 5120)}
 seen = set()
 print("one-frame program (512x512, 4 steps, ControlNet), M <= 256 1x1 GEMMs: us per launch, alone, back to back (12 launches, best of 2)")
-for fn, a, k in eng.program.calls:
+for fn, a, k in Engine.flat_calls(eng.program.calls):
     if fn.__name__ != "conv":
         continue
     g, w = a[2], a[3]
@@ -33,7 +33,7 @@ for fn, a, k in eng.program.calls:
     if g.ksize != 1 or (g.m, w.n, w.kp) not in want or key in seen:
         continue
     seen.add(key)
-    count = sum(1 for f2, a2, k2 in eng.program.calls if f2.__name__ == "conv" and ops.conv_key_of(a2[2], a2[3], k2) == key)
+    count = sum(1 for f2, a2, k2 in Engine.flat_calls(eng.program.calls) if f2.__name__ == "conv" and ops.conv_key_of(a2[2], a2[3], k2) == key)
     chosen = ops.tile_override.get(key)
     best, table = ops.tune_conv(a, k)
     rows = {}

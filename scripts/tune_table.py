@@ -13,7 +13,7 @@ eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
 eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half())
 eng.prepare(512, 512, 4, 0.6, use_controlnet=True, use_graph=False, autotune=False)
 cnt = collections.Counter(); first = {}
-for fn, a, k in eng.program.calls:
+for fn, a, k in Engine.flat_calls(eng.program.calls):
     if fn.__name__ != "conv": continue
     key = ops.conv_key_of(a[2], a[3], k)
     cnt[key] += 1; first.setdefault(key, (a, k))

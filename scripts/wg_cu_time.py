@@ -70,12 +70,9 @@ def cut_read(reset):
 def family_flops(e):
     """algorithmic FLOP of one launch of e's program, by family"""
     fl = dict.fromkeys(FAMS, 0.0)
-    for fn, a, k in e.program.calls:
+    for fn, a, k in Engine.flat_calls(e.program.calls):
         name = fn.__name__
-        if name == "conv_group":
-            for aa, _kk in a[0]:
-                fl["conv_gemm"] += 2.0 * aa[2].m * aa[3].n * aa[3].k
-        elif name == "conv":
+        if name == "conv":
             g, w = a[2], a[3]
             ent = e.ops.tile_override.get(e.ops.conv_key_of(g, w, k))
             halo = ent is not None and ent[3] == 7

@@ -63,7 +63,7 @@ host = log[:used].cpu().numpy().astype(np.uint64)
 
 # the conv calls of the program, in launch order (pipelines 9 / 10 are not instrumented and not used by default)
 convs = []
-for fn, a, k in eng.program.calls:
+for fn, a, k in Engine.flat_calls(eng.program.calls):
     if fn.__name__ != "conv":
         continue
     g, w = a[2], a[3]

@@ -74,6 +74,10 @@ class FakeOps:
         for a, kw in calls:
             self.conv(*a, **kw)
 
+    def pair(self, a, b):
+        for fn, aa, kk in (a, b):
+            fn(*aa, **kk)
+
     def conv(self, src0, src1, g, w, out, *, ldo=None, c0=None, c1=0, rowvec=None, residual=None, residual2=None,
              ldr=None, out_scale=1.0, act=L.ACT_NONE, out2=None, add2=None, out_t=None, ldt=0, t_col0=0, tile=None,
              split_k=None, workspace=None, pipeline=None, rowstat_out=None, ln_part=None, ln_eps=1e-5,

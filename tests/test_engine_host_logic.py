@@ -212,14 +212,14 @@ def test_absorbed_cross_attention_wiring(mini, monkeypatch):
     assert all(t.xa_raw is not None for t in eng.unet.transformers)
     eng.set_text_embeds(text)
     eng.prepare(64, 64, 2, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
-    n_soft = sum(1 for fn, a, k in eng.program.calls if fn.__name__ == "conv" and k.get("softmax_cols"))
-    n_attn = sum(1 for fn, a, k in eng.program.calls if fn.__name__ == "attention")
+    n_soft = sum(1 for fn, a, k in eng.flat_calls(eng.program.calls) if fn.__name__ == "conv" and k.get("softmax_cols"))
+    n_attn = sum(1 for fn, a, k in eng.flat_calls(eng.program.calls) if fn.__name__ == "attention")
     nblk = len(eng.unet.transformers) + len(eng.cn.transformers)
     assert n_soft == 2 * nblk and n_attn == 2 * nblk  # every cross-attention absorbed, the self-attentions remain
     got = eng.infer_u8(frame)
     eng.absorb_cross_attention = False
     eng.prepare(64, 64, 2, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
-    assert sum(1 for fn, a, k in eng.program.calls if fn.__name__ == "attention") == 4 * nblk
+    assert sum(1 for fn, a, k in eng.flat_calls(eng.program.calls) if fn.__name__ == "attention") == 4 * nblk
     ref = eng.infer_u8(frame)
     assert np.abs(got.astype(int) - ref.astype(int)).mean() < 0.3
     # another prompt: the absorbed weights follow
@@ -250,7 +250,7 @@ def test_fused_tail_wiring(mini, monkeypatch):
         eng.set_text_embeds(text)
         eng.prepare(64, 64, 2, 0.6, controlnet_scale=1.0, use_controlnet=True, use_graph=False)
         counts.append(len(eng.program.calls))
-        names = [fn.__name__ for fn, a, k in eng.program.calls]
+        names = [fn.__name__ for fn, a, k in eng.flat_calls(eng.program.calls)]
         assert ("tail_a" in names) == fused and ("tail_b" in names) == (fused and min_rows == 1)
         outs.append(eng.infer_u8(frame))
     assert counts[1] < counts[2] < counts[0]
@@ -276,6 +276,27 @@ def test_arena_gives_oversized_tensors_their_own_chunk_and_rewinds_to_the_same_a
     assert all(p0 + n0 <= p1 for (p0, n0), (p1, _) in zip(ptrs, ptrs[1:]))  # nothing overlaps
 
 
+def _packed_convs(net):
+    """every PackedConv object a NetWeights holds (any depth of its containers)"""
+    from videosd_amd.packing import PackedConv
+
+    out, seen, stack = [], set(), [net]
+    while stack:
+        o = stack.pop()
+        if id(o) in seen:
+            continue
+        seen.add(id(o))
+        if isinstance(o, PackedConv):
+            out.append(o)
+        elif isinstance(o, (list, tuple)):
+            stack += list(o)
+        elif isinstance(o, dict):
+            stack += list(o.values())
+        elif hasattr(o, "__dict__") and not isinstance(o, (torch.Tensor, type)):
+            stack += list(vars(o).values())
+    return out
+
+
 def test_captured_program_is_a_sequence_of_single_branch_graphs_and_event_edges(mini):
     """Engine._capture: every run of kernel calls on one stream is one graph, every fork / join / signal / wait an event edge
     (record on the producing stream, wait on the consuming one), in program order; without a second stream the frame is ONE
@@ -283,18 +304,43 @@ def test_captured_program_is_a_sequence_of_single_branch_graphs_and_event_edges(
     wu, wc, wv, text = mini
     steps = 2
 
-    def build(overlap, side=False, cn=True):
+    def build(overlap, side=False, cn=True, twin=False):
         eng = Engine(FakeOps(), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
         eng.set_text_embeds(text)
-        eng.overlap_controlnet, eng.use_side_stream = overlap, side
+        eng.overlap_controlnet, eng.use_side_stream, eng.twin_encoders = overlap, side, twin
         eng.prepare(64, 64, steps, 0.6, use_controlnet=cn, use_graph=False)
         seq = eng._capture(eng.program)
         return eng, seq["items"]
 
+    per_step = [("record", 0), ("wait", 1), ("graph", 1), ("graph", 0), ("record", 1), ("wait", 0)]
     eng, items = build(False)
     assert items == [("graph", 0)]
     eng, items = build(True, cn=False)
     assert items == [("graph", 0)]
+    # the two encoders in lock step (round 5, the default): their twin calls are pairs on ONE stream -- one graph, no edges --
+    # and a pair holds the UNet's and the ControlNet's call of one op, in that order
+    eng, items = build(False, twin=True)
+    assert items == [("graph", 0)]
+    pairs = [a for fn, a, k in eng.program.calls if fn.__name__ == "pair"]
+    assert len(pairs) > 20 * steps and all(a[0][0].__name__ == a[1][0].__name__ for a in pairs)
+    convs = [a for a in pairs if a[0][0].__name__ == "conv"]
+    unet_w = {id(w) for w in _packed_convs(eng.unet)}
+    assert all(id(a[0][1][3]) in unet_w and id(a[1][1][3]) not in unet_w for a in convs)
+    assert not any(fn.__name__ in Engine.SYNC_OPS for fn, a, k in eng.program.calls)
+    # with both options on (the default) the engine holds BOTH forms of the program: two streams for a lone launch, lock step for a
+    # launch among busy lanes -- the same calls on the same buffers, so either gives the frame the other gives
+    eng, items = build(True, twin=True)
+    assert [i[:2] for i in items] == [("graph", 0)] + (per_step + [("graph", 0)]) * steps
+    assert eng.program_serial is not eng.program and eng._capture(eng.program_serial, serial=True)["items"] == [("graph", 0)]
+    flat = lambda prog: sorted((fn.__name__, tuple(id(x) for x in a)) for fn, a, k in eng.flat_calls(prog.calls)  # noqa: E731
+                               if fn.__name__ not in Engine.SYNC_OPS)
+    assert flat(eng.program) == flat(eng.program_serial)
+    frame = np.random.default_rng(5).integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    outs = []
+    for ov in (True, False):
+        eng.overlap_launch = ov
+        outs.append(eng.infer_u8(frame))
+    assert np.array_equal(outs[0], outs[1])
     # the two encoders on two streams: per step  main | record(0) wait(1) | ControlNet graph on 1 | UNet encoder graph on 0 |
     # record(1) wait(0), then the merges + decoder (+ next step's head) on 0
     eng, items = build(True)

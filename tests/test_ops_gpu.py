@@ -183,7 +183,7 @@ def test_conv_group_equals_its_members_launched_one_by_one(ops):
     for form in ops.GROUP_FORMS:
         for a, kw in members:
             a[4].zero_()
-        ops.conv_group(members, form=form)
+        ops.conv_group(members, form=(form[0], 1, True, form[1]))
         ops.synchronize()
         got = [a[4].clone() for a, kw in members]
         for (a, kw), g_, (ref, n_) in zip(members, got, refs):
@@ -193,7 +193,8 @@ def test_conv_group_equals_its_members_launched_one_by_one(ops):
             ops.synchronize()
             assert torch.equal(a[4], g_), f"member alone differs from the group, form {form}"
     best, table = ops.tune_group(members)
-    assert ops.tile_override[ops.group_key(members)] == (best[1], 1, True, best[4]) and len(table) == len(ops.GROUP_FORMS)
+    # (members of different shapes: unsplit forms + "every member as a launch of its own")
+    assert ops.tile_override[ops.group_key(members)] == (best[1], 1, True, best[4]) and len(table) == len(ops.GROUP_FORMS) + 1
     ops.conv_group(members)  # (takes the remembered form)
     ops.synchronize()
     check(members[0][0][4][:, :320], refs[0][0], "group, tuned form")
@@ -203,6 +204,172 @@ def test_conv_group_equals_its_members_launched_one_by_one(ops):
     p8 = ops.to_device_pack(pack_linear(rnd(64, 8, seed=61), None))
     with pytest.raises(RuntimeError, match="buffer-load"):
         ops.conv_group([((x8.cuda(), None, Geom.linear(64), p8, torch.zeros(64, 64, dtype=torch.float16, device="cuda")), {})])
+
+
+def test_twin_convs_split_over_k_share_a_grid_and_a_reducer(ops):
+    """A group whose members are split over K (round 5: the twin layers of the UNet and the ControlNet encoder, one shape, two weight
+    sets): slabs reduced by ONE more launch for the group, or by the last workgroup of each tile in the launch -- every member with a
+    workspace and a counter set of its own.  Bit for bit the members launched one by one in the same form; the tuner's table for such
+    a pair holds split forms and the "alone" entry, and what it picks reproduces the reference."""
+    from videosd_amd import lib as L
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    h = w = 8
+    c, n = 1280, 1280
+    members, refs = [], []
+    for i in range(2):
+        x = rnd(1, c, h, w, seed=70 + i)
+        wt, b, rv = rnd(n, c, 3, 3, seed=72 + i, scale=(9 * c) ** -0.5), rnd(n, seed=74 + i, scale=0.1), rnd(n, seed=76 + i, scale=0.1)
+        res = rnd(h * w, n, seed=78 + i)
+        pw = ops.to_device_pack(pack_conv(wt, b))
+        out = torch.zeros(h * w, n, dtype=torch.float16, device="cuda")
+        members.append(((to_nhwc(x).cuda(), None, Geom.conv(h, w), pw, out), dict(rowvec=rv.cuda(), residual=res.cuda())))
+        refs.append(to_nhwc(F.conv2d(x.float(), wt.float(), b.float(), padding=1) + rv.float()[None, :, None, None]) + res.float())
+    for form in [(L.TILE_64x64, 6, False, 3), (L.TILE_64x64, 6, True, 3), (L.TILE_64x128, 4, False, 5), (L.TILE_128x64, 8, True, 5),
+                 (L.TILE_64x64, 12, False, 5)]:
+        for a, kw in members:
+            a[4].zero_()
+        for _ in range(3):  # (the counters of the in-launch form return to zero: a second and third launch see them clean)
+            ops.conv_group(members, form=form)
+        ops.synchronize()
+        got = [a[4].clone() for a, kw in members]
+        ops.inkernel_splitk = form[2]
+        for (a, kw), g_, ref in zip(members, got, refs):
+            check(g_, ref, f"twin group form {form}")
+            a[4].zero_()
+            ops.conv(*a, tile=form[0], split_k=form[1], pipeline=form[3], **kw)
+            ops.synchronize()
+            assert torch.equal(a[4], g_), f"member alone differs from the twin group, form {form}"
+        ops.inkernel_splitk = True
+    best, table = ops.tune_group(members, split=6)
+    forms = {t[1:] for t in table}
+    assert any(f[1] == 6 and not f[2] for f in forms) and any(f[1] == 6 and f[2] for f in forms) and (ops.GROUP_ALONE, 1, True, 0) in forms
+    assert all(f[1] == 6 for f in forms if f[0] != ops.GROUP_ALONE) and ops.group_key(members, 6) in ops.tile_override
+    # `pair` (the engine's entry point) runs two twin convs at the split they have as launches of their own -- a conv's bits depend
+    # on its split alone, not on tile / pipeline / where the slabs are summed -- so the pair gives the bits the two launches give
+    for a, kw in members:
+        a[4].zero_()
+        ops.conv(*a, **kw)
+    ops.synchronize()
+    alone = [a[4].clone() for a, kw in members]
+    sp = ops.pair_split(*members[0], *members[1])
+    assert sp is not None and sp == ops.conv(*members[0][0], _desc_only=True, **members[0][1]).split_k
+    ops.tune_group(members, split=sp)
+    for a, kw in members:
+        a[4].zero_()
+    ops.pair((ops.conv, members[0][0], members[0][1]), (ops.conv, members[1][0], members[1][1]))
+    ops.synchronize()
+    for (a, kw), ref, al in zip(members, refs, alone):
+        check(a[4], ref, "twin pair")
+        assert torch.equal(a[4], al), "the pair's bits differ from the two launches'"
+    # members whose own forms sum over K in different orders (here: one forced into the halo-patch form) do not share a grid
+    key = ops.conv_key_of(members[0][0][2], members[0][0][3], members[0][1])
+    saved = ops.tile_override.get(key)
+    ops.tile_override[key] = (L.TILE_128x64, 1, True, 7)
+    halo_ok = ops._halo_call_ok(members[0][0][2], members[0][0][3], 0, 0, 1.0, None, None, None, None, None, None)
+    assert (ops.pair_split(*members[0], *members[1]) is None) == halo_ok
+    if saved is None:
+        del ops.tile_override[key]
+    else:
+        ops.tile_override[key] = saved
+
+
+def test_pair_runs_two_calls_of_one_op_as_one_grid(ops):
+    """vsd_pair_begin / join / end (round 5): the second operation's launches join the first one's -- GroupNorm (one-launch and
+    two-launch forms), attention, the fused transformer tails -- same bits as the two calls alone; the library reports how many
+    launches went out as pairs; a second operation of another shape joins nothing and both still run; pair calls out of order are
+    refused."""
+    import ctypes as C
+
+    def joined(run_a, run_b):
+        ops.ctx.call("vsd_pair_begin")
+        run_a()
+        ops.ctx.call("vsd_pair_join")
+        ops._widx = 1
+        try:
+            run_b()
+        finally:
+            ops._widx = None
+        n = C.c_int(-1)
+        ops.ctx.call("vsd_pair_end", C.byref(n))
+        return n.value
+
+    # GroupNorm: 16x16x1280 (one launch), 64x64x320 (two launches)
+    for hw, c, want in ((256, 1280, 1), (4096, 320, 2)):
+        xs = [rnd(hw, c, seed=80 + i).cuda() for i in range(2)]
+        gb = [(rnd(c, seed=82 + i).cuda(), rnd(c, seed=84 + i).cuda()) for i in range(2)]
+        alone = [torch.zeros(hw, c, dtype=torch.float16, device="cuda") for _ in range(2)]
+        both = [torch.zeros(hw, c, dtype=torch.float16, device="cuda") for _ in range(2)]
+        for i in range(2):
+            ops.groupnorm(xs[i], None, c, 0, hw, 32, 1e-5, gb[i][0], gb[i][1], True, alone[i])
+        n = joined(lambda: ops.groupnorm(xs[0], None, c, 0, hw, 32, 1e-5, gb[0][0], gb[0][1], True, both[0]),
+                   lambda: ops.groupnorm(xs[1], None, c, 0, hw, 32, 1e-5, gb[1][0], gb[1][1], True, both[1]))
+        ops.synchronize()
+        assert n == want, (hw, c, n)
+        assert torch.equal(alone[0], both[0]) and torch.equal(alone[1], both[1]) and not torch.equal(both[0], both[1])
+        ref = F.silu(F.group_norm(xs[1].float().t().reshape(1, c, hw), 32, gb[1][0].float(), gb[1][1].float(), 1e-5))[0].t()
+        check(both[1], ref.cpu(), f"paired groupnorm {hw}x{c}")
+    # attention: 1024 queries x 77 keys, 8 heads of 80 (the 640-wide level's cross-attention)
+    sq, sk, heads, d = 1024, 77, 8, 80
+    qs = [rnd(sq, heads * d, seed=90 + i).cuda() for i in range(2)]
+    ks = [rnd(sk, heads * d, seed=92 + i).cuda() for i in range(2)]
+    vts = [torch.zeros(heads * d, 128, dtype=torch.float16, device="cuda") for _ in range(2)]
+    for i in range(2):
+        vts[i][:, :sk] = rnd(heads * d, sk, seed=94 + i).cuda()
+    alone = [torch.zeros(sq, heads * d, dtype=torch.float16, device="cuda") for _ in range(2)]
+    both = [torch.zeros(sq, heads * d, dtype=torch.float16, device="cuda") for _ in range(2)]
+    att = lambda i, o: ops.attention(qs[i], heads * d, ks[i], heads * d, vts[i], 128, o, heads * d, sq, sk, heads, d, d ** -0.5)  # noqa: E731
+    for i in range(2):
+        att(i, alone[i])
+    assert joined(lambda: att(0, both[0]), lambda: att(1, both[1])) == 1
+    ops.synchronize()
+    assert torch.equal(alone[0], both[0]) and torch.equal(alone[1], both[1]) and not torch.equal(both[0], both[1])
+    qh = qs[1].float().reshape(sq, heads, d).transpose(0, 1)
+    kh = ks[1].float().reshape(sk, heads, d).transpose(0, 1)
+    vh = vts[1][:, :sk].float().reshape(heads, d, sk).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(1, 2) * d ** -0.5, -1) @ vh).transpose(0, 1).reshape(sq, heads * d)
+    check(both[1], ref.cpu(), "paired attention")
+    # the fused transformer tails, through ops.pair (the engine's entry point)
+    c, m = 320, 4096
+    _w, packs = _tail_weights(c)
+    pk = {k: ops.to_device_pack(v) for k, v in packs.items()}
+    ins = [(rnd(m, c, seed=110 + i).cuda(), (rnd(m, c, seed=112 + i).float() * 2 + 0.5).half().cuda(), rnd(m, c, seed=114 + i).cuda(),
+            rnd(m, c, seed=116 + i).cuda()) for i in range(2)]
+    z = lambda: torch.zeros(m, c, dtype=torch.float16, device="cuda")  # noqa: E731
+    alone = [(z(), z(), z()) for _ in range(2)]
+    both = [(z(), z(), z()) for _ in range(2)]
+    for i in range(2):
+        ops.tail_a(ins[i][0], ins[i][1], m, pk["out1"], pk["q2"], alone[i][0], alone[i][1])
+        ops.tail_b(ins[i][3], alone[i][0], ins[i][2], m, pk["out2"], pk["ff1"], pk["ff2"], pk["proj"], alone[i][2])
+    ops.pair((ops.tail_a, (ins[0][0], ins[0][1], m, pk["out1"], pk["q2"], both[0][0], both[0][1]), {}),
+             (ops.tail_a, (ins[1][0], ins[1][1], m, pk["out1"], pk["q2"], both[1][0], both[1][1]), {}))
+    ops.pair((ops.tail_b, (ins[0][3], both[0][0], ins[0][2], m, pk["out2"], pk["ff1"], pk["ff2"], pk["proj"], both[0][2]), {}),
+             (ops.tail_b, (ins[1][3], both[1][0], ins[1][2], m, pk["out2"], pk["ff1"], pk["ff2"], pk["proj"], both[1][2]), {}))
+    ops.synchronize()
+    for i in range(2):
+        for j in range(3):
+            assert torch.equal(alone[i][j], both[i][j]) and float(both[i][j].abs().sum()) > 0, (i, j)
+    assert not torch.equal(both[0][2], both[1][2])
+    # a second operation of another shape: nothing joins, both run
+    y0, y1 = torch.zeros(256, 1280, dtype=torch.float16, device="cuda"), torch.zeros(1024, 640, dtype=torch.float16, device="cuda")
+    x1 = rnd(1024, 640, seed=99).cuda()
+    g1, b1 = rnd(640, seed=98).cuda(), rnd(640, seed=97).cuda()
+    n = joined(lambda: ops.groupnorm(xs[0][:256].contiguous() if xs[0].shape[0] != 256 else xs[0], None, 320, 0, 256, 32, 1e-5,
+                                     g1[:320].contiguous(), b1[:320].contiguous(), False, y0),
+               lambda: ops.groupnorm(x1, None, 640, 0, 1024, 32, 1e-5, g1, b1, False, y1))
+    ops.synchronize()
+    assert n == 0 and float(y0[:, :320].abs().sum()) > 0 and float(y1.abs().sum()) > 0
+    # protocol errors are reported, and leave no pair open
+    with pytest.raises(RuntimeError, match="pair_join"):
+        ops.ctx.call("vsd_pair_join")
+    with pytest.raises(RuntimeError, match="pair_end"):
+        ops.ctx.call("vsd_pair_end", None)
+    ops.ctx.call("vsd_pair_begin")
+    with pytest.raises(RuntimeError, match="already open"):
+        ops.ctx.call("vsd_pair_begin")
+    ops.ctx.call("vsd_pair_join")
+    ops.ctx.call("vsd_pair_end", None)
 
 
 def test_throughput_mode_tuning_times_candidates_with_four_lanes_busy(ops):

@@ -355,14 +355,18 @@ def test_baseline_config2_on_range_stress_weights_matches_oracle(case):
 
 
 def test_side_stream_and_single_stream_sequences_give_the_same_bits(mini_setup):
-    """Every engine is captured twice (Engine._capture): the ControlNet encoder on the lane's side stream (graphs + event
-    edges) and everything on the lane's own stream (one graph).  Same kernels, same buffers: the frame must not depend on
-    which of the two a launch takes -- nor on another lane running beside it."""
+    """Every engine holds two forms of its program (Engine.prepare / _capture): the ControlNet encoder on the lane's side stream
+    (graphs + event edges) and everything on the lane's own stream (one graph), where the two encoders walk in lock step and their
+    twin layers share a grid (ops.pair; round 5).  Same buffers, and every kernel sums in the same order in both: the frame must
+    not depend on which of the two a launch takes -- nor on another lane running beside it."""
     eng, orc, text = mini_setup
     eng.overlap_controlnet = True
     eng.prepare(128, 128, 4, 0.6, controlnet_scale=1.5, use_controlnet=True)
     assert eng.plan["edges"] == 2 * 4 and eng.plan["graphs"] == 1 + 3 * 4 and eng.graph_serial is not eng.graph
     assert eng.ops.seq_count(eng.graph_serial) == (1, 0)
+    n2, k2 = eng.launches_by_kind()
+    n1, k1 = eng.launches_by_kind(serial=True)
+    assert eng.program_serial is not eng.program and n1 < 0.85 * n2 and k1.get("pair_conv", 0) > 20 and not any(k.startswith("pair") for k in k2)
     f = _frame(128, 128, seed=9)
     eng.overlap_launch = True
     a = eng.infer_u8(f)

@@ -46,6 +46,43 @@ extern "C" void vsd_destroy(vsd_ctx* ctx) {
 
 extern "C" const char* vsd_last_error(vsd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+// ---- two operations as one grid per kernel (common.h launch_pairable)
+static void pair_flush(vsd_ctx* ctx) {
+  for (; ctx->pair_next < ctx->pair_held.size(); ++ctx->pair_next) {
+    const PairHeld& h = ctx->pair_held[ctx->pair_next];
+    h.alone(h.kernel, h.params, h.grid, h.block, h.shmem, h.stream);
+  }
+  ctx->pair_held.clear();
+  ctx->pair_next = 0;
+}
+
+extern "C" int vsd_pair_begin(vsd_ctx* ctx) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (ctx->pair_state != 0) return vsd_fail(ctx, VSD_ERR_STATE, "pair_begin: a pair is already open");
+  // (while profiling, per-family events bracket single launches: the pair is accepted and its launches go out one by one)
+  ctx->pair_state = ctx->profiling ? 3 : 1;
+  ctx->pair_joined = 0;
+  return VSD_OK;
+}
+
+extern "C" int vsd_pair_join(vsd_ctx* ctx) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (ctx->pair_state != 1 && ctx->pair_state != 3) return vsd_fail(ctx, VSD_ERR_STATE, "pair_join: no pair_begin before it");
+  if (ctx->pair_state == 1) ctx->pair_state = 2;
+  return VSD_OK;
+}
+
+extern "C" int vsd_pair_end(vsd_ctx* ctx, int* joined_out) {
+  if (!ctx) return VSD_ERR_ARG;
+  if (ctx->pair_state == 0) return vsd_fail(ctx, VSD_ERR_STATE, "pair_end: no pair is open");
+  pair_flush(ctx);  // (held launches that found no partner, or everything when the second operation never came)
+  ctx->pair_state = 0;
+  if (joined_out) *joined_out = ctx->pair_joined;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vsd_fail(ctx, VSD_ERR_HIP, "pair_end: kernel launch failed: %s", hipGetErrorString(e));
+  return VSD_OK;
+}
+
 extern "C" int vsd_graph_begin(vsd_ctx* ctx, void* stream) {
   if (!ctx) return VSD_ERR_ARG;
   if (ctx->capturing) return vsd_fail(ctx, VSD_ERR_STATE, "graph_begin: already capturing");

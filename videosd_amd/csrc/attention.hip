@@ -78,7 +78,7 @@ __device__ __forceinline__ float xhalf_max(float x) {  // max over the two half-
 //  maximum moved; the max-subtract as 16 v_pk_add_f32 measured 9-34 % SLOWER (the compiler no longer shares the two row-sum
 //  branches' code, 174 registers) and was not kept.)
 template <int NQK, int NPV, int NW, int QB, int KSP>
-__global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnParams pp) {
+__device__ __forceinline__ void attention_body(const AttnParams& pp, const unsigned image) {
   VSD_CUT(VSD_CUT_ATTENTION, pp.cut)
   constexpr int NTG = 64 * NW;       // threads of one key-split group (they stage that group's tiles)
   constexpr int KS = NQK * 16 + 8;   // K tile row pitch (halfs): 4 * odd dwords -> conflict-free ds_read_b128
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
 
   AttnParams p = pp;
   {  // batch: this workgroup's image
-    const size_t b = blockIdx.z;
+    const size_t b = image;
     p.q += b * p.sq * p.ldq;
     p.out += b * p.sq * p.ldo;
     p.k += b * p.k_brows * p.ldk;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
     PROBE(5)
   }
 #ifdef VSD_ATTN_PROBE
-  if (p.probe && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
+  if (p.probe && blockIdx.x == 0 && blockIdx.y == 0 && image == 0 && tid == 0)
     for (int i = 0; i < 8; ++i) p.probe[i] = pacc[i];
 #endif
 #undef ATT_LOAD
@@ -458,27 +458,38 @@ __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnPara
   }
 }
 
+template <int NQK, int NPV, int NW, int QB, int KSP>
+__global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnParams pp) {
+  attention_body<NQK, NPV, NW, QB, KSP>(pp, blockIdx.z);
+}
+// two attention problems of one shape as one grid (common.h launch_pairable): the upper half of gridDim.z is the second one
+template <int NQK, int NPV, int NW, int QB, int KSP>
+__global__ __launch_bounds__(64 * NW * KSP) void attention_pair_kernel(const Pair<AttnParams> g) {
+  const unsigned nb = gridDim.z >> 1, which = blockIdx.z >= nb;
+  attention_body<NQK, NPV, NW, QB, KSP>(g.p[which], blockIdx.z - which * nb);
+}
+
 // (waves per group, query blocks per wave, key-split groups)
 struct AttnShape {
   int nw, qb, ksp;
 };
 
 template <int NQK, int NPV, int NW, int QB, int KSP>
-void launch_one(const AttnParams& p, int batch, hipStream_t s) {
+void launch_one(vsd_ctx* ctx, const AttnParams& p, int batch, hipStream_t s) {
   dim3 grid(p.heads, (p.sq + 32 * NW * QB - 1) / (32 * NW * QB), batch);
-  hipLaunchKernelGGL((attention_kernel<NQK, NPV, NW, QB, KSP>), grid, dim3(64 * NW * KSP), 0, s, p);
+  launch_pairable(ctx, attention_kernel<NQK, NPV, NW, QB, KSP>, attention_pair_kernel<NQK, NPV, NW, QB, KSP>, grid, dim3(64 * NW * KSP), 0, s, p);
 }
 
 template <int NQK, int NPV>
-void launch_attn(const AttnParams& p, AttnShape sh, int batch, hipStream_t s) {
+void launch_attn(vsd_ctx* ctx, const AttnParams& p, AttnShape sh, int batch, hipStream_t s) {
   // QB = 2 (two query blocks per wave) is implemented but not instantiated: measured 1.3x SLOWER on MI355X at every
   // shape (the kernel is issue-bound, not LDS-bound; two blocks per wave need > 256 VGPRs, i.e. one wave per SIMD).
   constexpr bool SMALL = NPV <= 3;  // LDS budget of the KSP = 2 form
   if constexpr (SMALL) {
-    if (sh.ksp == 2) return launch_one<NQK, NPV, 4, 1, 2>(p, batch, s);
+    if (sh.ksp == 2) return launch_one<NQK, NPV, 4, 1, 2>(ctx, p, batch, s);
   }
-  if (sh.nw == 2) return launch_one<NQK, NPV, 2, 1, 1>(p, batch, s);
-  return launch_one<NQK, NPV, 4, 1, 1>(p, batch, s);
+  if (sh.nw == 2) return launch_one<NQK, NPV, 2, 1, 1>(ctx, p, batch, s);
+  return launch_one<NQK, NPV, 4, 1, 1>(ctx, p, batch, s);
 }
 
 }  // namespace
@@ -537,13 +548,13 @@ extern "C" int vsd_attention_batched(vsd_ctx* ctx, const void* q, int ldq, const
       sh.ksp = (c == 2 && d <= 96) ? 2 : 1;
     }
   }
-  if (nqk <= 1) launch_attn<1, 1>(p, sh, batch, s);
-  else if (nqk == 2) launch_attn<2, 1>(p, sh, batch, s);
-  else if (nqk == 3) launch_attn<3, 2>(p, sh, batch, s);
-  else if (nqk == 4) launch_attn<4, 2>(p, sh, batch, s);
-  else if (nqk == 5) launch_attn<5, 3>(p, sh, batch, s);
-  else if (nqk == 6) launch_attn<6, 3>(p, sh, batch, s);
-  else if (nqk <= 8) launch_attn<8, 4>(p, sh, batch, s);
-  else launch_attn<10, 5>(p, sh, batch, s);
+  if (nqk <= 1) launch_attn<1, 1>(ctx, p, sh, batch, s);
+  else if (nqk == 2) launch_attn<2, 1>(ctx, p, sh, batch, s);
+  else if (nqk == 3) launch_attn<3, 2>(ctx, p, sh, batch, s);
+  else if (nqk == 4) launch_attn<4, 2>(ctx, p, sh, batch, s);
+  else if (nqk == 5) launch_attn<5, 3>(ctx, p, sh, batch, s);
+  else if (nqk == 6) launch_attn<6, 3>(ctx, p, sh, batch, s);
+  else if (nqk <= 8) launch_attn<8, 4>(ctx, p, sh, batch, s);
+  else launch_attn<10, 5>(ctx, p, sh, batch, s);
   return ls.finish();
 }

@@ -4,7 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/vsd.h"
@@ -23,8 +25,28 @@ struct ProfEvent {
   int fam;
 };
 
+// ---- two independent launches of ONE kernel as one grid (include/vsd.h vsd_pair_begin): the first operation's launches are
+// held here, the second operation's launches join them one by one -- the lower half of gridDim.z runs the held argument block, the upper half the joining one
+template <class P>
+struct Pair {
+  P p[2];
+};
+struct PairHeld {
+  const void* pair_kernel;  // identity of the two-problem kernel this launch may join
+  const void* kernel;       // ... and the one-problem kernel, for launching it alone after all
+  void (*alone)(const void* kernel, const void* params, dim3 grid, dim3 block, unsigned shmem, hipStream_t s);
+  dim3 grid, block;
+  unsigned shmem, size;
+  hipStream_t stream;
+  alignas(16) unsigned char params[480];
+};
+
 struct vsd_ctx {
   int device;
+  int pair_state = 0;  // 0: launches go out as they come; 1: hold (first operation); 2: join (second operation); 3: pass through
+  std::vector<PairHeld> pair_held;
+  size_t pair_next = 0;
+  int pair_joined = 0;
   std::string err;
   bool profiling = false;
   bool capturing = false;
@@ -77,6 +99,47 @@ struct LaunchScope {
     return VSD_OK;
   }
 };
+
+template <class P>
+static void pair_launch_alone(const void* kernel, const void* params, dim3 grid, dim3 block, unsigned shmem, hipStream_t s) {
+  hipLaunchKernelGGL(reinterpret_cast<void (*)(const P)>(const_cast<void*>(kernel)), grid, block, shmem, s, *reinterpret_cast<const P*>(params));
+}
+
+// Launch `k1(p)`, or -- between vsd_pair_begin and vsd_pair_end -- hold it / join it with the held launch of the same kernel,
+// launch geometry and stream as ONE grid of `k2` (gridDim.z doubled: its upper half is the joining problem).  A launch that finds no partner goes out alone, in order.
+template <class P>
+static inline void launch_pairable(vsd_ctx* ctx, void (*k1)(const P), void (*k2)(const Pair<P>), dim3 grid, dim3 block, unsigned shmem,
+                                   hipStream_t s, const P& p) {
+  static_assert(sizeof(P) <= sizeof(PairHeld::params) && std::is_trivially_copyable<P>::value, "argument block too large to hold");
+  if (ctx->pair_state == 0 || ctx->pair_state == 3) {
+    hipLaunchKernelGGL(k1, grid, block, shmem, s, p);
+    return;
+  }
+  if (ctx->pair_state == 1) {
+    PairHeld h;
+    h.pair_kernel = reinterpret_cast<const void*>(k2);
+    h.kernel = reinterpret_cast<const void*>(k1);
+    h.alone = &pair_launch_alone<P>;
+    h.grid = grid; h.block = block; h.shmem = shmem; h.size = sizeof(P); h.stream = s;
+    memcpy(h.params, &p, sizeof(P));
+    ctx->pair_held.push_back(h);
+    return;
+  }
+  if (ctx->pair_next < ctx->pair_held.size()) {
+    const PairHeld& h = ctx->pair_held[ctx->pair_next++];
+    if (h.pair_kernel == reinterpret_cast<const void*>(k2) && h.grid.x == grid.x && h.grid.y == grid.y && h.grid.z == grid.z && h.block.x == block.x &&
+        h.block.y == block.y && h.block.z == block.z && h.shmem == shmem && h.stream == s) {
+      Pair<P> g;
+      memcpy(&g.p[0], h.params, sizeof(P));
+      g.p[1] = p;
+      hipLaunchKernelGGL(k2, dim3(grid.x, grid.y, 2 * grid.z), block, shmem, s, g);
+      ctx->pair_joined += 1;
+      return;
+    }
+    h.alone(h.kernel, h.params, h.grid, h.block, h.shmem, h.stream);
+  }
+  hipLaunchKernelGGL(k1, grid, block, shmem, s, p);
+}
 
 // (rcp instead of an IEEE division: 1 ulp, far below the fp16 rounding of the result, and 10 instructions fewer per element)
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

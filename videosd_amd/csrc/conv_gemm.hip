@@ -247,14 +247,15 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
 
 // Several independent conv / linear problems as ONE launch (conv_gemm_group_kernel, conv_kernels.h): every descriptor as for
 // vsd_conv_gemm, with these restrictions -- the same tile (64x64, 64x128, 128x64 or 128x128) and pipeline (3 or 5) for all,
-// the buffer-load operand path for all (Cin % 64 == 0 per source, no resize), and split-K only in the in-launch form (each
-// member with a workspace AND a counter slice of its own: no reducer kernel runs for a group).
+// the buffer-load operand path for all (Cin % 64 == 0 per source, no resize); a member split over K brings a workspace of its own
+// (and, for the in-launch reduction, a counter slice of its own).  The members that leave slabs behind are reduced by ONE more
+// launch for the whole group (splitk_reduce_group_kernel).
 extern "C" int vsd_conv_gemm_group(vsd_ctx* ctx, const vsd_conv_desc* descs, int n, void* stream) {
   if (!ctx || !descs) return VSD_ERR_ARG;
   if (n < 1 || n > VSD_GROUP_MAX) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm_group: %d problems (1..%d)", n, VSD_GROUP_MAX);
   hipStream_t s = (hipStream_t)stream;
   ConvGroup g;
-  int BM = 0, BN = 0, stages = 0, grid = 0;
+  int BM = 0, BN = 0, stages = 0, grid = 0, rgrid = 0, nreduce = 0, last_reduce = 0;
   double flops = 0.0;
   for (int i = 0; i < n; ++i) {
     ConvLaunch cl;
@@ -263,8 +264,13 @@ extern "C" int vsd_conv_gemm_group(vsd_ctx* ctx, const vsd_conv_desc* descs, int
     if (cl.halo || cl.BM == 256 || !cl.p.fast || cl.p.generic || (cl.stages != 3 && cl.stages != 5))
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm_group: member %d needs a 64- / 128-row tile, pipeline 3 or 5 and the buffer-load operand "
                       "path (Cin %% 64 == 0 per source, no resize)", i);
-    if (cl.p.split_k > 1 && !cl.p.counters)
-      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm_group: member %d is split over K without counters (a group reduces in the launch)", i);
+    if (cl.p.split_k > 1 && !cl.p.counters) {
+      size_t total = (size_t)cl.p.M * ((cl.p.N + 7) / 8);
+      int rg = (int)((total + 255) / 256);
+      rgrid = rg > rgrid ? rg : rgrid;
+      ++nreduce;
+      last_reduce = i;
+    }
     if (i == 0) {
       BM = cl.BM; BN = cl.BN; stages = cl.stages;
     } else if (cl.BM != BM || cl.BN != BN || cl.stages != stages) {
@@ -278,10 +284,21 @@ extern "C" int vsd_conv_gemm_group(vsd_ctx* ctx, const vsd_conv_desc* descs, int
   for (int i = n; i <= VSD_GROUP_MAX; ++i) g.start[i] = grid;
   for (int i = n; i < VSD_GROUP_MAX; ++i) g.p[i] = g.p[0];
   g.n = n;
-  LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, flops);
-  if (BM == 128 && BN == 128) vsd_launch_conv_group_128x128(g, grid, stages, s);
-  else if (BM == 128 && BN == 64) vsd_launch_conv_group_128x64(g, grid, stages, s);
-  else if (BM == 64 && BN == 64) vsd_launch_conv_group_64x64(g, grid, stages, s);
-  else vsd_launch_conv_group_64x128(g, grid, stages, s);
-  return ls.finish();
+  {
+    LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, flops);
+    if (BM == 128 && BN == 128) vsd_launch_conv_group_128x128(g, grid, stages, s);
+    else if (BM == 128 && BN == 64) vsd_launch_conv_group_128x64(g, grid, stages, s);
+    else if (BM == 64 && BN == 64) vsd_launch_conv_group_64x64(g, grid, stages, s);
+    else vsd_launch_conv_group_64x128(g, grid, stages, s);
+    int rc = ls.finish();
+    if (rc) return rc;
+  }
+  if (nreduce) {
+    LaunchScope ls(ctx, s, VSD_FAM_SPLITK_REDUCE, 0.0);
+    if (rgrid > 2048) rgrid = 2048;
+    if (nreduce == 1) vsd_launch_splitk_reduce(g.p[last_reduce], rgrid, s);
+    else vsd_launch_splitk_reduce_group(g, rgrid, s);
+    return ls.finish();
+  }
+  return VSD_OK;
 }

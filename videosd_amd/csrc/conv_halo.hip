@@ -9,7 +9,7 @@ namespace {
 // (up to 8 slabs at a time and the residual chunk) is issued BEFORE the first is consumed, so that the
 // thread pays one memory round trip instead of one per slab (the first form's runtime-bounded loop: a dependent chain of
 // split_k round trips, then the epilogue's own loads).  The additions run in the same order: same bits.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
+__device__ __forceinline__ void splitk_reduce_body(const ConvParams& p) {
   VSD_CUT(VSD_CUT_REDUCE, p.cut)
   const int nch = (p.N + 7) / 8;
   const size_t total = (size_t)p.M * nch;
@@ -86,6 +86,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
     }
     epilogue_store8(p, m, n, v, rs, rq, pre_res, rres, pre_brv, blo, bhi);
   }
+}
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) { splitk_reduce_body(p); }
+// the reducers of a conv group (vsd_conv_gemm_group) as one grid: blockIdx.y = member; members that were not split, or reduced in
+// their own launch, have nothing to do
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const ConvGroup g) {
+  const ConvParams& p = g.p[blockIdx.y];
+  if (p.split_k <= 1 || p.counters) return;
+  splitk_reduce_body(p);
 }
 
 // ---------------------------------------------------------------- 3x3 conv with an LDS halo patch
@@ -491,4 +499,7 @@ void vsd_launch_conv_halo(const ConvParams& p, int BM, int BN, int grid, hipStre
 
 void vsd_launch_splitk_reduce(const ConvParams& p, int grid, hipStream_t s) {
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, p);
+}
+void vsd_launch_splitk_reduce_group(const ConvGroup& g, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(grid, g.n), dim3(256), 0, s, g);
 }

@@ -128,6 +128,7 @@ void vsd_launch_conv_group_64x64(const ConvGroup& g, int grid, int stages, hipSt
 void vsd_launch_conv_group_64x128(const ConvGroup& g, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_group_128x64(const ConvGroup& g, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_group_128x128(const ConvGroup& g, int grid, int stages, hipStream_t s);
+void vsd_launch_splitk_reduce_group(const ConvGroup& g, int grid, hipStream_t s);
 void vsd_launch_splitk_reduce(const ConvParams& p, int grid, hipStream_t s);
 
 namespace {

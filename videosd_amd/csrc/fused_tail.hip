@@ -249,7 +249,7 @@ __device__ __forceinline__ void load_a_tile(const half_t* g, half_t* X, int m0, 
 }
 
 template <int KIND, int WM, int BM = BM0>
-__global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
+__device__ __forceinline__ void tail_body(const TailParams& p) {
   VSD_CUT(VSD_CUT_TAIL, p.cut)
   constexpr int MI = BM / 16 / WM, NTH = 256 * WM;
   static_assert(MI * 16 * WM == BM, "rows per workgroup = 16 x row fragments per wave x row groups");
@@ -472,6 +472,16 @@ __global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
   }
 }
 
+template <int KIND, int WM, int BM = BM0>
+__global__ __launch_bounds__(256 * WM) void tail_kernel(const TailParams p) {
+  tail_body<KIND, WM, BM>(p);
+}
+// two token sets with their own weights as one grid (common.h launch_pairable; blockIdx.z = which)
+template <int KIND, int WM, int BM = BM0>
+__global__ __launch_bounds__(256 * WM) void tail_pair_kernel(const Pair<TailParams> g) {
+  tail_body<KIND, WM, BM>(g.p[blockIdx.z]);
+}
+
 }  // namespace
 
 // Tokens per workgroup.  tail_b runs one workgroup per CU (330+ registers per lane), so a launch runs in rounds of 256
@@ -517,11 +527,11 @@ extern "C" int vsd_tail_a(vsd_ctx* ctx, const void* att, const void* h, int m, c
   LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * m * 2.0 * C * C);
   // tile height: see pick_tail_bm (64 = the eight-wave form; the others run four waves)
   switch (pick_tail_bm(m, 0)) {
-    case 16: hipLaunchKernelGGL((tail_kernel<0, 1, 16>), dim3(cdiv(m, 16)), dim3(256), 0, s, p); break;
-    case 32: hipLaunchKernelGGL((tail_kernel<0, 1, 32>), dim3(cdiv(m, 32)), dim3(256), 0, s, p); break;
-    case 48: hipLaunchKernelGGL((tail_kernel<0, 1, 48>), dim3(cdiv(m, 48)), dim3(256), 0, s, p); break;
-    case 80: hipLaunchKernelGGL((tail_kernel<0, 1, 80>), dim3(cdiv(m, 80)), dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL((tail_kernel<0, 2>), dim3(cdiv(m, BM0)), dim3(512), 0, s, p);
+    case 16: launch_pairable(ctx, tail_kernel<0, 1, 16>, tail_pair_kernel<0, 1, 16>, dim3(cdiv(m, 16)), dim3(256), 0, s, p); break;
+    case 32: launch_pairable(ctx, tail_kernel<0, 1, 32>, tail_pair_kernel<0, 1, 32>, dim3(cdiv(m, 32)), dim3(256), 0, s, p); break;
+    case 48: launch_pairable(ctx, tail_kernel<0, 1, 48>, tail_pair_kernel<0, 1, 48>, dim3(cdiv(m, 48)), dim3(256), 0, s, p); break;
+    case 80: launch_pairable(ctx, tail_kernel<0, 1, 80>, tail_pair_kernel<0, 1, 80>, dim3(cdiv(m, 80)), dim3(256), 0, s, p); break;
+    default: launch_pairable(ctx, tail_kernel<0, 2>, tail_pair_kernel<0, 2>, dim3(cdiv(m, BM0)), dim3(512), 0, s, p);
   }
   return ls.finish();
 }
@@ -544,11 +554,11 @@ extern "C" int vsd_tail_b(vsd_ctx* ctx, const void* att2, const void* h1, const 
   hipStream_t s = (hipStream_t)stream;
   LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * m * (2.0 * C * C + 3.0 * C * FF));
   switch (pick_tail_bm(m, 1)) {
-    case 16: hipLaunchKernelGGL((tail_kernel<1, 1, 16>), dim3(cdiv(m, 16)), dim3(256), 0, s, p); break;
-    case 32: hipLaunchKernelGGL((tail_kernel<1, 1, 32>), dim3(cdiv(m, 32)), dim3(256), 0, s, p); break;
-    case 48: hipLaunchKernelGGL((tail_kernel<1, 1, 48>), dim3(cdiv(m, 48)), dim3(256), 0, s, p); break;
-    case 80: hipLaunchKernelGGL((tail_kernel<1, 1, 80>), dim3(cdiv(m, 80)), dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL((tail_kernel<1, 1>), dim3(cdiv(m, BM0)), dim3(256), 0, s, p);
+    case 16: launch_pairable(ctx, tail_kernel<1, 1, 16>, tail_pair_kernel<1, 1, 16>, dim3(cdiv(m, 16)), dim3(256), 0, s, p); break;
+    case 32: launch_pairable(ctx, tail_kernel<1, 1, 32>, tail_pair_kernel<1, 1, 32>, dim3(cdiv(m, 32)), dim3(256), 0, s, p); break;
+    case 48: launch_pairable(ctx, tail_kernel<1, 1, 48>, tail_pair_kernel<1, 1, 48>, dim3(cdiv(m, 48)), dim3(256), 0, s, p); break;
+    case 80: launch_pairable(ctx, tail_kernel<1, 1, 80>, tail_pair_kernel<1, 1, 80>, dim3(cdiv(m, 80)), dim3(256), 0, s, p); break;
+    default: launch_pairable(ctx, tail_kernel<1, 1>, tail_pair_kernel<1, 1>, dim3(cdiv(m, BM0)), dim3(256), 0, s, p);
   }
   return ls.finish();
 }

@@ -41,7 +41,7 @@ __device__ __forceinline__ half8 gn_load(const GnParams& p, int row, int ch8) {
 // Both kernels are latency- rather than bandwidth-bound at these sizes (a few MB, L2 resident): every thread issues
 // its row loads four at a time before consuming them, and the partial folds are spread over all threads with every
 // load of a thread independent of the others, so each phase costs about one memory round trip.
-__global__ void gn_stats_kernel(const GnParams p) {
+__device__ __forceinline__ void gn_stats_body(const GnParams& p) {
   VSD_CUT(VSD_CUT_GROUPNORM, p.cut)
   extern __shared__ float sm[];  // [16 planes][threads] per-thread channel sums (see below), folded in a fixed order
   const int t = threadIdx.x;
@@ -109,7 +109,11 @@ __global__ void gn_stats_kernel(const GnParams p) {
   }
 }
 
-__global__ void gn_apply_kernel(const GnParams p) {
+__global__ void gn_stats_kernel(const GnParams p) { gn_stats_body(p); }
+// (two tensors as one grid: common.h launch_pairable; blockIdx.z = which)
+__global__ void gn_stats_pair_kernel(const Pair<GnParams> g) { gn_stats_body(g.p[blockIdx.z]); }
+
+__device__ __forceinline__ void gn_apply_body(const GnParams& p) {
   VSD_CUT(VSD_CUT_GROUPNORM, p.cut)
   extern __shared__ float sm[];  // [groups][2] mean, rstd | [nch][groups*2] partial folds
   const int t = threadIdx.x;
@@ -201,6 +205,8 @@ __global__ void gn_apply_kernel(const GnParams p) {
     if (ok3) norm_store(r + 3 * p.rpp, x3);
   }
 }
+__global__ void gn_apply_kernel(const GnParams p) { gn_apply_body(p); }
+__global__ void gn_apply_pair_kernel(const Pair<GnParams> g) { gn_apply_body(g.p[blockIdx.z]); }
 
 // ------------------------------------------------------------------ one-launch GroupNorm for small images
 // One workgroup per (image, group): the group's cpg channels of every pixel (a cpg*2-byte piece of each NHWC row) are
@@ -212,7 +218,7 @@ __global__ void gn_apply_kernel(const GnParams p) {
 // (80-byte row pieces, 16-byte vectors, half the workgroups) at 32 x 32 x 640: 9.6 against 8.3 us for one image, 12.5 against 13.2 for
 // five (scripts/gn_bench.py) -- the kernel is launch + two dependent round trips, not line traffic: not used.
 template <int VW, int NV, int RMAX, int GPW = 1>
-__global__ void gn_fused_kernel(const GnParams p) {
+__device__ __forceinline__ void gn_fused_body(const GnParams& p) {
   VSD_CUT(VSD_CUT_GROUPNORM, p.cut)
   typedef _Float16 vec_t __attribute__((ext_vector_type(VW)));
   constexpr int CPG = NV * VW / GPW;  // channels per group (compile time: the element -> group map is static)
@@ -311,8 +317,17 @@ __global__ void gn_fused_kernel(const GnParams p) {
   }
 }
 
+template <int VW, int NV, int RMAX>
+__global__ void gn_fused_kernel(const GnParams p) {
+  gn_fused_body<VW, NV, RMAX>(p);
+}
+template <int VW, int NV, int RMAX>
+__global__ void gn_fused_pair_kernel(const Pair<GnParams> g) {
+  gn_fused_body<VW, NV, RMAX>(g.p[blockIdx.z]);
+}
+
 // launches the one-kernel form when the shape fits it (dry: only says whether it would); returns false otherwise
-static bool gn_try_fused(const GnParams& p, int batch, hipStream_t s, bool dry) {
+static bool gn_try_fused(vsd_ctx* ctx, const GnParams& p, int batch, hipStream_t s, bool dry) {
   if (getenv("VSD_GN_NO_FUSED")) return false;
   // measured on MI355X (us, one launch vs two): 8x8x1280 5.5 vs 14.5; 16x16x1280 6.3 vs 14.2; 32x32x640 11.5 vs 13.6;
   // it loses with more registers per thread (32x32x1920: 133 vs 14) and with 20-byte row pieces at 64x64 (31 vs 15)
@@ -324,7 +339,7 @@ static bool gn_try_fused(const GnParams& p, int batch, hipStream_t s, bool dry) 
 #define GN_GO(VW_, NV_)                                                                           \
   {                                                                                               \
     if (dry) return true;                                                                         \
-    hipLaunchKernelGGL((gn_fused_kernel<VW_, NV_, 1>), grid, block, 0, s, p); /* threads >= hw: one row per thread */ \
+    launch_pairable(ctx, gn_fused_kernel<VW_, NV_, 1>, gn_fused_pair_kernel<VW_, NV_, 1>, grid, block, 0, s, p); /* threads >= hw: one row per thread */ \
     return true;                                                                                  \
   }
   if (a8 && p.cpg == 40) GN_GO(8, 5)
@@ -443,16 +458,16 @@ extern "C" int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void*
   if (nblk < 1) nblk = 1;
   p.nblk = nblk;
   hipStream_t s = (hipStream_t)stream;
-  if (gn_try_fused(p, batch, s, true)) {
+  if (gn_try_fused(ctx, p, batch, s, true)) {
     LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
-    gn_try_fused(p, batch, s, false);
+    gn_try_fused(ctx, p, batch, s, false);
     return ls.finish();
   }
   const size_t smem = (size_t)groups * 2 * 9 * sizeof(float);
   {
     const size_t smem_stats = (size_t)p.rpp * p.c * 2 * sizeof(float);
     LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, batch), dim3(threads), smem_stats, s, p);
+    launch_pairable(ctx, gn_stats_kernel, gn_stats_pair_kernel, dim3(nblk, batch), dim3(threads), (unsigned)smem_stats, s, p);
     int rc = ls.finish();
     if (rc) return rc;
   }
@@ -461,7 +476,7 @@ extern "C" int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void*
     static const int ablk_cap = getenv("VSD_GN_ABLK") ? atoi(getenv("VSD_GN_ABLK")) : 256;  // (benchmarking: apply workgroups per image)
     if (ablk > ablk_cap) ablk = ablk_cap;
     LaunchScope ls(ctx, s, VSD_FAM_GROUPNORM, 0.0);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(ablk, batch), dim3(threads), smem, s, p);
+    launch_pairable(ctx, gn_apply_kernel, gn_apply_pair_kernel, dim3(ablk, batch), dim3(threads), (unsigned)smem, s, p);
     return ls.finish();
   }
 }

@@ -89,6 +89,23 @@ class Recorder:
         for fn, a, k in self.calls:
             fn(*a, **k)
 
+    # a stretch of the program recorded in two FORMS (same buffers, same results): `flavor(i)` is the program with form i
+    def variants(self, form0, form1):
+        self.calls.append((_variants, (form0, form1), {}))
+
+    def flavor(self, i: int) -> "Recorder":
+        out = Recorder(self.ops)
+        for c in self.calls:
+            if c[0] is _variants:
+                out.calls += c[1][i]
+            else:
+                out.calls.append(c)
+        return out
+
+
+def _variants(*a, **k):
+    raise RuntimeError("a program with variants is run through Recorder.flavor")
+
 
 # ------------------------------------------------------------------------------------------ packed weights
 @dataclass
@@ -420,6 +437,7 @@ class Engine:
         self.added = None  # SDXL: (pooled text embeds, 6 time ids)
         self.plan = None
         self.graph = None
+        self.program = self.program_serial = None
         self.use_graph = True
         self.is_slot = False
         self.batch = 1
@@ -454,6 +472,9 @@ class Engine:
         self.absorb_cross_attention = True  # cross-attention of the wide blocks as two GEMMs (vsd_xattn_fold)
         self.use_fused_tail = True          # 320-wide blocks: per-token chains as fused launches (csrc/fused_tail.hip)
         self.group_merges = not __import__("os").environ.get("VSD_NO_GROUP")  # the ControlNet merges of a step as two grouped launches
+        # the one-stream form of the program runs the UNet and the ControlNet encoder of a step in lock step, twin layers as one
+        # grid (`prepare`: both forms are recorded, `launch` picks)
+        self.twin_encoders = not __import__("os").environ.get("VSD_NO_TWIN")
         self.tail_b_min_rows = 1024         # ... the feed-forward chain from this many tokens per launch on (see _transformer)
 
     def make_slot(self, share_plan: bool = True, lane: Optional[int] = None) -> "Engine":
@@ -896,6 +917,22 @@ class Engine:
         r.conv(cn_mid, None, Geom.linear(rows), net.zero_mid, mid, out_scale_dev=sc[nres - 1:nres], residual=u_mid)
         return mid, merged
 
+    @staticmethod
+    def _zip_pairs(r, first, second):
+        """two recorded call lists of one topology -> pairs; calls without a twin (another op, or one list longer) go out alone"""
+        sync = Engine.SYNC_OPS
+        first = [c for c in first if c[0].__name__ not in sync]
+        second = [c for c in second if c[0].__name__ not in sync]
+        for i in range(max(len(first), len(second))):
+            a = first[i] if i < len(first) else None
+            b = second[i] if i < len(second) else None
+            if a is not None and b is not None and a[0].__name__ == b[0].__name__ and a[0].__name__ in ("conv", "groupnorm", "attention", "tail_a", "tail_b"):
+                r.pair(a, b)
+            else:
+                for c in (a, b):
+                    if c is not None:
+                        r.calls.append(c)
+
     def _cond_embedding(self, r, ctrl, H, W):
         a, net = self.arena, self.cn
         h, hh, ww = ctrl, H, W
@@ -968,12 +1005,26 @@ class Engine:
         mode = getattr(ops, "tune_mode", 0)
         online = mode == 0 or getattr(ops, "tune_lanes_online", False)
         try:
-            for fn, a, k in self.program.calls:
-                if fn.__name__ == "conv_group" and hasattr(ops, "tune_group"):
+            # the two-stream form first: a twin pair of the one-stream form runs at the split its members have as launches of their own
+            calls = self.program.calls + (self.program_serial.calls if self.program_serial is not self.program else [])
+            for fn, a, k in calls:
+                if fn.__name__ in ("conv_group", "pair") and hasattr(ops, "tune_group"):
                     ops.tune_mode = mode if online else 0  # (a group's form is timed alone either way; see ops.tune_group)
-                    key = ops.group_key(a[0])
+                    members, split = a[0], None
+                    if fn.__name__ == "pair":
+                        if a[0][0].__name__ != "conv" or a[1][0].__name__ != "conv":
+                            continue
+                        members = [(a[0][1], a[0][2]), (a[1][1], a[1][2])]
+                        for aa, kk in members:  # (a pair the one-stream form alone holds: its members' own forms first)
+                            mk = ops.conv_key_of(aa[2], aa[3], kk)
+                            if mk not in ops.tile_override and kk.get("tile") is None:
+                                seen[mk] = ops.tune_conv(aa, kk)[0]
+                        split = ops.pair_split(*members[0], *members[1])
+                        if split is None:
+                            continue
+                    key = ops.group_key(members, split)
                     if key not in seen and key not in ops.tile_override:
-                        seen[key] = ops.tune_group(a[0])[0]
+                        seen[key] = ops.tune_group(members, split=split)[0]
                         if verbose:
                             print("tune", key, "->", seen[key], flush=True)
                     continue
@@ -1123,14 +1174,30 @@ class Engine:
             if use_controlnet:
                 # the ControlNet encoder and the UNet encoder both depend only on the current latents: run them
                 # on two streams (two parallel branches of the captured graph), join before the zero-convs
+                # ... or in lock step on ONE stream: the ControlNet is a copy of the UNet encoder's topology, so the k-th call of
+                # one is the k-th call of the other with another weight set -- each such pair goes out as one grid per kernel
+                # (ops.pair): a quarter of a frame's launches less, and the small layers fill twice the chip.  Measured on MI355X
+                # (one frame per launch, 512x512 4-step): a lone launch 20.8 ms on two streams | 21.3 ms in lock step; with three /
+                # four lanes busy (no second stream to be had) 75.0 / 84.1 | 82.1 / 88.8 frames/s.  So both forms are recorded
+                # -- same buffers, same results -- and `launch` takes the one its moment calls for.
+                rc_, ru_ = Recorder(ops), Recorder(ops)
+                cn_mid, cn_skips = self._controlnet_encoder(rc_, i, cur, sizes, cond_emb)
+                u_mid, u_skips = self._unet_encoder(ru_, i, cur, sizes)
+                two = Recorder(ops)
                 if self.overlap_controlnet:
-                    r.fork()
-                    r.use_stream(1)
-                cn_mid, cn_skips = self._controlnet_encoder(r, i, cur, sizes, cond_emb)
-                r.use_stream(0)
-                u_mid, u_skips = self._unet_encoder(r, i, cur, sizes)
+                    two.fork()
+                    two.use_stream(1)
+                two.calls += rc_.calls
+                two.use_stream(0)
+                two.calls += ru_.calls
                 if self.overlap_controlnet:
-                    r.join()
+                    two.join()
+                if self.twin_encoders and hasattr(ops, "pair"):
+                    twin = Recorder(ops)
+                    self._zip_pairs(twin, ru_.calls, rc_.calls)
+                    r.variants(two.calls, twin.calls)
+                else:
+                    r.variants(two.calls, two.calls)
                 u_mid, u_skips = self._controlnet_merge(r, cn_mid, cn_skips, u_mid, u_skips, sizes, controlnet_scale)
             elif ref_mode:
                 rc = RefCtx(self.ucfg)
@@ -1149,27 +1216,104 @@ class Engine:
             r.lcm_step_dev(eps, cur, nz, c[2 + 6 * i:8 + 6 * i], hw0, B, nxt, den, dec_in if last else None)
         self._decode(r, dec_in, h0, w0, dec_out)
         r.postprocess_rgb(dec_out, 8, B * H * W, out_b)
-        self.program = r
+        # program: what a lone launch runs (the ControlNet encoder on the side stream when `overlap_controlnet`);
+        # program_serial: everything on the lane's own stream (the encoders in lock step when `twin_encoders`)
+        self.program = r.flavor(0 if self.overlap_controlnet or not self.twin_encoders else 1)
+        self.program_serial = r.flavor(1) if self.twin_encoders and self.overlap_controlnet and use_controlnet else self.program
         self.plan = dict(H=H, W=W, steps=steps, strength=strength, cn_scale=controlnet_scale, cn=use_controlnet, n=n, batch=B,
                          ref_mode=bool(ref_mode), tuned_for_lanes=bool(self.tune_for_lanes),
-                         sizes=sizes, timesteps=sched.timesteps, n_ops=len(r.calls), arena_bytes=a.peak)
+                         sizes=sizes, timesteps=sched.timesteps, n_ops=len(self.program.calls), arena_bytes=a.peak)
         # per-shape kernel configuration (timed once per shape, cached in ops.tile_override), warm-up, capture
         torch.cuda.synchronize() if torch.cuda.is_available() else None  # allocation fills vs. kernel streams
         self._sync_prompt()
         if autotune:  # (only shapes missing from the shared table are timed: a slot with the parent's batch size finds all)
             self.autotune()
-        r.run()
+        self.program.run()
+        if self.program_serial is not self.program:
+            self.program_serial.run()
         ops.synchronize()
         if self.use_graph:
             # two launch sequences of the SAME program (same kernels, same buffers): the ControlNet encoder on the lane's side
             # stream (a lone launch: ~4 ms less per frame), and everything on the lane's own stream (what a launch takes when
             # three or four lanes are busy: the side stream IS another lane's stream).  `launch(overlap=...)` picks per launch.
-            self.graph = self._capture(r)
+            self.graph = self._capture(self.program)
             self.plan["graphs"], self.plan["edges"] = ops.seq_count(self.graph)
-            self.graph_serial = self._capture(r, serial=True) if self.plan["edges"] else self.graph
+            two_forms = self.plan["edges"] or self.program_serial is not self.program
+            self.graph_serial = self._capture(self.program_serial, serial=True) if two_forms else self.graph
         return self.plan
 
     SYNC_OPS = ("use_stream", "fork", "join", "signal", "wait")
+
+    @staticmethod
+    def flat_calls(calls):
+        """the recorded calls as single-op calls: the members of pairs and groups one by one (analysis scripts)"""
+        for fn, a, k in calls:
+            if fn.__name__ == "pair":
+                yield a[0]
+                yield a[1]
+            elif fn.__name__ == "conv_group":
+                for aa, kk in a[0]:
+                    yield (fn.__self__.conv, aa, kk)
+            else:
+                yield (fn, a, k)
+
+    def launches_by_kind(self, serial: bool = False):
+        """kernel launches one replay of the recorded program (serial: of its one-stream form) issues, by kind ("pair_*": two twin calls in one grid;
+        "convs_in_groups" counts members, not launches) -> (total, {kind: launches})"""
+        ops, kinds = self.ops, {}
+
+        def count(name, n=1):
+            if n:
+                kinds[name] = kinds.get(name, 0) + n
+
+        def gn_launches(a):  # (csrc/norm.hip gn_try_fused: one launch for small images, else statistics + apply)
+            c, hw, groups = a[2] + a[3], a[4], a[5]
+            cpg = c // groups
+            fused = ((hw <= 256 and cpg <= 40) or (hw <= 1024 and cpg <= 20)) and cpg in (40, 8, 16, 20, 4, 12, 10, 2, 6)
+            return 1 if fused else 2
+
+        def table(key):
+            ent = ops.tile_override.get(key)
+            if ent is None and key[-1] == 1:
+                ent = ops.tile_override.get(key[:-1] + (0,))
+            return ent
+
+        def conv_reducer(a, k):
+            ent = table(ops.conv_key_of(a[2], a[3], k))
+            return int(ent is not None and ent[1] > 1 and not ent[2] and not a[3].tile128)
+
+        for fn, a, k in (self.program_serial if serial else self.program).calls:
+            name = fn.__name__
+            if name in self.SYNC_OPS:
+                continue
+            if name == "pair":
+                (fa, aa, ka), (fb, ab, kb) = a
+                op = fa.__name__
+                if op == "conv":
+                    sp = ops.pair_split(aa, ka, ab, kb)
+                    ent = table(ops.group_key([(aa, ka), (ab, kb)], sp)) if sp is not None else (ops.GROUP_ALONE,)
+                    if ent is None:
+                        ent = (0, sp, True, 3)
+                    if ent[0] != ops.GROUP_ALONE:
+                        count("pair_conv")
+                        count("pair_splitk_reduce", int(ent[1] > 1 and not ent[2]))
+                    else:
+                        count("conv", 2)
+                        count("splitk_reduce", conv_reducer(aa, ka) + conv_reducer(ab, kb))
+                elif op == "groupnorm":
+                    count("pair_groupnorm")
+                    count("pair_gn_second", gn_launches(aa) - 1)
+                else:
+                    count("pair_" + op)
+                continue
+            count(name)
+            if name == "conv_group":
+                count("convs_in_groups", len(a[0]))
+            elif name == "conv":
+                count("splitk_reduce", conv_reducer(a, k))
+            elif name == "groupnorm":
+                count("gn_second", gn_launches(a) - 1)
+        return sum(v for k, v in kinds.items() if k != "convs_in_groups"), kinds
 
     def _capture(self, r: Recorder, serial: bool = False):
         """serial=True: every call on stream 0, no edges (the program's fork / join / signal / wait markers are dropped: in one
@@ -1306,7 +1450,8 @@ class Engine:
         else:
             if hasattr(self.ops, "tune_mode"):
                 self.ops.tune_mode = 1 if self.tune_for_lanes else 0
-            self.program.run()
+            ov = self.overlap_launch if overlap is None else overlap
+            (self.program if ov else self.program_serial).run()
 
     def _want_shape(self):
         p = self.plan

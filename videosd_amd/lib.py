@@ -60,6 +60,9 @@ SIGNATURES = {
     "vsd_last_error": (C.c_char_p, [C.c_void_p]),
     "vsd_conv_gemm": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p]),
     "vsd_conv_gemm_group": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
+    "vsd_pair_begin": (C.c_int, [C.c_void_p]),
+    "vsd_pair_join": (C.c_int, [C.c_void_p]),
+    "vsd_pair_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "vsd_tail_a": (C.c_int, [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 3),
     "vsd_tail_b": (C.c_int, [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 6),
     "vsd_groupnorm_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

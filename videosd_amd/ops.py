@@ -143,6 +143,8 @@ class HipOps:
             torch.cuda.set_stream(self.stream)
         self.device_id = device_id
         self._sidx = 0
+        self._pair_default = None
+        self._widx = None  # scratch set of the call being issued when it is not the stream's own (members of a pair / group)
         self._events = {}
         self._ws = {}
         self.tile_override = {} if tile_override is None else tile_override
@@ -284,8 +286,20 @@ class HipOps:
                 setattr(p, f, self.to_device(v) if self.allocator is not None else v.to(self.device).contiguous())
         return p
 
+    @property
+    def _scratch(self) -> int:
+        return self._sidx if self._widx is None else self._widx
+
+    def _counter_set(self, sets, n):
+        """split-K / channel-statistics counters of the current scratch set (zeroed once; the kernels leave them at zero)"""
+        while len(sets) <= self._scratch:
+            with torch.cuda.stream(self.stream):
+                sets.append(torch.zeros(n, dtype=torch.int32, device=self.device))
+            self.stream.synchronize()
+        return sets[self._scratch]
+
     def workspace(self, key: str, nbytes: int) -> torch.Tensor:
-        key = (key, self._sidx)  # kernels on different streams may run concurrently: separate scratch
+        key = (key, self._scratch)  # kernels on different streams / members of one grid may run concurrently: separate scratch
         cur = self._ws.get(key)
         if cur is None or cur.numel() < nbytes:
             with torch.cuda.stream(self.stream):
@@ -374,7 +388,7 @@ class HipOps:
         if chanstat_out is not None:
             d.chanstat_out = self._p(chanstat_out)
             d.chanstat_part = self._p(self.workspace("chanpart", (-(-m // 64)) * w.n * 8))
-            d.chan_counters = self._p(self._chan_counters[self._sidx])
+            d.chan_counters = self._p(self._counter_set(self._chan_counters, 4096))
         d.rowvec = self._p(rowvec)
         d.residual, d.residual2 = self._p(residual), self._p(residual2)
         d.ldr = ldr if ldr is not None else w.n_out
@@ -393,7 +407,7 @@ class HipOps:
             ws = workspace if workspace is not None else self.workspace("splitk", split_k * m * w.n * 4)
             d.workspace = self._p(ws)
             if inkernel:
-                d.counters = self._p(self._counters[self._sidx])
+                d.counters = self._p(self._counter_set(self._counters, L.SPLITK_MAX_TILES))
         elif workspace is not None:  # (development probes pass a buffer through)
             d.workspace = self._p(workspace)
         if _desc_only:
@@ -403,34 +417,63 @@ class HipOps:
     # ---- several independent convs as ONE launch (include/vsd.h vsd_conv_gemm_group)
     GROUP_FORMS = [(L.TILE_64x64, 3), (L.TILE_64x64, 5), (L.TILE_64x128, 3), (L.TILE_64x128, 5), (L.TILE_128x64, 3), (L.TILE_128x64, 5),
                    (L.TILE_128x128, 3), (L.TILE_128x128, 5)]
+    GROUP_ALONE = -1  # tile field of a group's table entry: "these members are faster as launches of their own"
 
-    def group_key(self, calls):
+    def group_key(self, calls, split=None):
         k = ["group"]
         for a, kw in calls:
             k += [a[2].m, a[3].n, a[3].kp]
+        if split is not None:  # (a twin pair: the members' own split over K is part of the problem, see `pair`)
+            k += ["split", int(split)]
         return tuple(k) + (int(self.tune_mode),)
 
-    def conv_group(self, calls, form=None):
-        """calls: [(args, kwargs), ...] as for `conv` (1 x 1 / 3 x 3 layers on the buffer-load path, no split-K): ONE launch for all
-        of them, every member in the same kernel form (tile, pipeline) -- `form`, else this group's entry of the tuning table
-        (`tune_group`), else 64 x 64 tiles on the 3-stage ring.  Same bits as the members launched one by one in that form."""
+    def conv_group(self, calls, form=None, split=None, default=None):
+        """calls: [(args, kwargs), ...] as for `conv` (1 x 1 / 3 x 3 layers on the buffer-load path): ONE launch for all of them
+        (plus one reducer launch for the members that leave split-K slabs), every member in the same kernel form
+        (tile, split_k, reduce in the launch, pipeline) -- `form`, else this group's entry of the tuning table (`tune_group`), else
+        64 x 64 tiles on the 3-stage ring, unsplit (`split`: split that many times -- the table entry is then looked up for that
+        split).  Member i works in scratch set i (split-K slabs, counters).  Same bits as the members launched one by one at the
+        same split_k, whatever their tile and pipeline (a conv's bits depend on the split alone: scripts/conv_bits_probe.py).  A
+        table entry may also say that the members are better off alone."""
         if not 1 <= len(calls) <= L.CONV_GROUP_MAX:
             raise ValueError(f"conv_group: {len(calls)} members (1..{L.CONV_GROUP_MAX})")
         if form is None:
-            ent = self.tile_override.get(self.group_key(calls))
+            ent = self.tile_override.get(self.group_key(calls, split))
             if ent is None and self.tune_mode == 1:
-                ent = self.tile_override.get(self.group_key(calls)[:-1] + (0,))
-            form = (ent[0], ent[3]) if ent is not None else (L.TILE_64x64, 3)
+                ent = self.tile_override.get(self.group_key(calls, split)[:-1] + (0,))
+            form = ent if ent is not None else (default or (L.TILE_64x64, split or 1, True, 3))
+        tile, split_k, inkernel, pipeline = form
+        if tile == self.GROUP_ALONE:
+            for a, kw in calls:
+                self.conv(*a, **kw)
+            return
         descs = (L.ConvDesc * len(calls))()
-        for i, (a, kw) in enumerate(calls):
-            kw = {k: v for k, v in kw.items() if k not in ("tile", "split_k", "pipeline")}
-            descs[i] = self.conv(*a, tile=form[0], split_k=1, pipeline=form[1], _desc_only=True, **kw)
+        saved = self.inkernel_splitk
+        self.inkernel_splitk = bool(inkernel)
+        try:
+            for i, (a, kw) in enumerate(calls):
+                kw = {k: v for k, v in kw.items() if k not in ("tile", "split_k", "pipeline")}
+                self._widx = i
+                descs[i] = self.conv(*a, tile=tile, split_k=split_k, pipeline=pipeline, _desc_only=True, **kw)
+        finally:
+            self._widx = None
+            self.inkernel_splitk = saved
         self.ctx.call("vsd_conv_gemm_group", descs, len(calls), self.s)
 
-    def tune_group(self, calls, reps: int = 12):
-        """time the kernel forms a group may take (GROUP_FORMS) back to back on this stream; remember the fastest"""
+    def group_candidates(self, calls, split=None):
+        """the kernel forms `tune_group` times: GROUP_FORMS at the given split over K (slabs reduced by one more launch for the group,
+        or in the launch), and the members as launches of their own"""
+        sp = split or 1
+        stats = any(kw.get("rowstat_out") is not None or kw.get("chanstat_out") is not None or a[3].tile128 for a, kw in calls)
+        cands = [(t, sp, True, pl) for t, pl in self.GROUP_FORMS]
+        if sp > 1 and not stats:
+            cands += [(t, sp, False, pl) for t, pl in self.GROUP_FORMS]
+        return cands + [(self.GROUP_ALONE, 1, True, 0)]
+
+    def tune_group(self, calls, reps: int = 12, split=None):
+        """time the forms a group may take (`group_candidates`) back to back on this stream; remember the fastest"""
         table = []
-        for form in self.GROUP_FORMS:
+        for form in self.group_candidates(calls, split):
             try:
                 for _ in range(2):
                     self.conv_group(calls, form=form)
@@ -443,15 +486,62 @@ class HipOps:
                     e1.record(self.stream)
                     e1.synchronize()
                     best = min(best, e0.elapsed_time(e1) / reps * 1e3)
-                table.append((best, form[0], 1, True, form[1]))
+                table.append((best,) + tuple(form))
             except RuntimeError:
                 continue
         if not table:
             raise RuntimeError("tune_group: no kernel form ran for this group")
         table.sort()
         b = table[0]
-        self.tile_override[self.group_key(calls)] = (b[1], b[2], b[3], b[4])
+        self.tile_override[self.group_key(calls, split)] = (b[1], b[2], bool(b[3]), b[4])
         return b, table
+
+    # ---- two independent calls of one op as ONE grid per kernel (include/vsd.h vsd_pair_begin): the twin layers of the UNet and
+    #      the ControlNet encoder.  a, b: recorded calls (bound method, args, kwargs).  b works in scratch set 1.
+    def pair(self, a, b):
+        (fa, aa, ka), (fb, ab, kb) = a, b
+        if fa.__name__ == "conv" and fb.__name__ == "conv":
+            sp = self.pair_split(aa, ka, ab, kb)
+            if sp is not None:  # (no table entry for the pair: the form its first member has alone)
+                return self.conv_group([(aa, ka), (ab, kb)], split=sp, default=self._pair_default)
+            fa(*aa, **ka)
+            self._widx = 1
+            try:
+                fb(*ab, **kb)
+            finally:
+                self._widx = None
+            return
+        self.ctx.call("vsd_pair_begin")
+        done = False
+        try:
+            fa(*aa, **ka)
+            self.ctx.call("vsd_pair_join")
+            self._widx = 1
+            fb(*ab, **kb)
+            done = True
+        finally:
+            self._widx = None
+            rc = self.ctx.lib.vsd_pair_end(self.ctx.h, None)  # (always closes the pair; held launches go out alone)
+            if done:
+                self.ctx.check(rc, "vsd_pair_end")
+
+    def pair_split(self, aa, ka, ab, kb):
+        """Two twin convs share a grid when both are on the buffer-load operand path (what vsd_conv_gemm_group takes) and the forms
+        they have as launches of their own sum over K in the SAME order -- the same split_k, neither in the halo-patch form (its K
+        order is channel block outer, tap inner).  Then the pair at that split gives the bits the two launches give, and a frame
+        does not depend on which form of the program ran it.  -> that split_k, or None (launch them one by one)."""
+        sp = None
+        for a, k in ((aa, ka), (ab, kb)):
+            g, w = a[2], a[3]
+            if w.cin % 64 or (k.get("c1", 0) or 0) % 64 or (g.hi, g.wi) != (g.hs, g.ws) or g.ksize * g.ksize > 32:
+                return None
+            d = self.conv(*a, _desc_only=True, **k)
+            if d.pipeline == 7 or d.tile in (L.TILE_256x128, L.TILE_256x64) or (sp is not None and d.split_k != sp):
+                return None
+            if sp is None:
+                self._pair_default = (int(d.tile), int(d.split_k), bool(d.counters) or d.split_k <= 1, 5 if d.pipeline == 5 else 3)
+            sp = int(d.split_k)
+        return sp
 
     @staticmethod
     def _halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part) -> bool:
@@ -711,7 +801,7 @@ class HipOps:
             key = tuple(bool(x) if isinstance(x, bool) else x for x in k)
             if isinstance(key[-1], bool):
                 continue  # a round-3 table (last field: "has a statistics output"): its entries name no epilogue class
-            if len(key) == 9:
+            if len(key) == 9 and key[0] != "group":
                 key = key + (0,)  # (a table written before the tuning mode joined the key: timed alone)
             if key not in self.tile_override:
                 self.tile_override[key] = (int(v[0]), int(v[1]), bool(v[2]), int(v[3]))
