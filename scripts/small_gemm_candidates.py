@@ -22,7 +22,8 @@ eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
 eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half())
 eng.prepare(512, 512, 4, 0.6, use_controlnet=True, use_graph=False, batch=1)
 EPI = ["plain", "ln", "rowstat", "ln+rowstat", "softmax", "general", "plain+act"]
-want = {(256, 1280, 1280), (64, 1280, 1280), (256, 1024, 1280), (64, 1024, 1280), (256, 3840, 1280), (64, 1280, 2560), (256, 1280, 5120)}
+want = {(256, 1280, 1280), (64, 1280, 1280), (256, 1024, 1280), (64, 1024, 1280), (256, 3840, 1280), (64, 1280, 2560), (256, 1280, 5120),
+        (256, 1280, 1024), (64, 1280, 1024), (1024, 640, 640), (1024, 640, 1024), (4096, 320, 320)}
 seen = set()
 print("one-frame program (512x512, 4 steps, ControlNet), M <= 256 1x1 GEMMs: us per launch, alone, back to back (12 launches, best of 2)")
 for fn, a, k in Engine.flat_calls(eng.program.calls):
@@ -38,12 +39,13 @@ for fn, a, k in Engine.flat_calls(eng.program.calls):
     best, table = ops.tune_conv(a, k)
     rows = {}
     for us, t, sp, ink, pl in table:
-        kk = (t, sp, ink)
+        kk = (t, sp, ink if pl != 8 else "lean")
         if kk not in rows or us < rows[kk][0]:
             rows[kk] = (us, pl)
     print(f"\nM={g.m} N={w.n} K={w.k} epilogue={EPI[key[-2]]} x{count} per frame; table choice {chosen}; this run's best "
           f"(tile {best[1]}, split {best[2]}, {'in-launch' if best[3] else 'reducer'}, pipeline {best[4]}) {best[0]:.1f} us")
     for (t, sp, ink), (us, pl) in sorted(rows.items(), key=lambda kv: kv[1][0])[:14]:
         bm, bn = L.TILE_DIMS[t]
-        wgs = -(-g.m // bm) * -(-w.n // bn) * sp
-        print(f"   {us:7.1f} us  tile {bm}x{bn} split {sp:2d} {'in-launch' if ink else ('reducer  ' if sp > 1 else '-        ')} pipeline {pl}  ({wgs} workgroups)")
+        wgs = -(-g.m // bm) * -(-w.n // bn) * (1 if ink == "lean" else sp)  # (the lean form's parts of K are the waves of ONE workgroup)
+        how = "in-WG    " if ink == "lean" else ("in-launch" if ink else ("reducer  " if sp > 1 else "-        "))
+        print(f"   {us:7.1f} us  tile {bm}x{bn} split {sp:2d} {how} pipeline {pl}  ({wgs} workgroups)")

@@ -70,7 +70,7 @@ class FakeOps:
         """[b*h*w][>=c] buffer (possibly a strided view) -> NCHW fp32"""
         return t[:, :c].float().reshape(b, h, w, c).permute(0, 3, 1, 2)
 
-    def conv_group(self, calls, form=None):
+    def conv_group(self, calls, form=None, split=None, default=None):
         for a, kw in calls:
             self.conv(*a, **kw)
 

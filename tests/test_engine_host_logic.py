@@ -297,6 +297,53 @@ def _packed_convs(net):
     return out
 
 
+def test_shortcut_convs_share_conv1s_grid_in_every_form_of_the_program(mini):
+    """A ResnetBlock's shortcut conv depends on the block's input only (ResnetBlock2D.conv_shortcut): it is recorded as a member of
+    conv1's grouped launch (ops.conv_group, every member at its own split), in the two-stream and in the lock-step form alike,
+    one group per ResnetBlock that has a shortcut; VSD_NO_GROUP_SHORTCUT-style engines record it as a launch of its own and give
+    the same frame."""
+    wu, wc, wv, text = mini
+    steps = 2
+
+    def build(group):
+        eng = Engine(FakeOps(), C.MINI_UNET, C.MINI_CONTROLNET, C.TAESD, wu, wc, wv)
+        eng.set_text_embeds(text)
+        eng.group_shortcuts = group
+        eng.prepare(64, 64, steps, 0.6, use_controlnet=True, use_graph=False)
+        return eng
+
+    eng = build(True)
+    n_sc = sum(1 for net in (eng.unet, eng.cn) for rw in _resnets(net) if rw.shortcut is not None)
+    for prog in (eng.program, eng.program_serial):
+        groups = [(a, k) for fn, a, k in prog.calls if fn.__name__ == "conv_group" and k.get("split") == "own"]
+        assert len(groups) == n_sc * steps
+        for a, k in groups:
+            (a1, k1), (a2, k2) = a[0]
+            assert a1[2].ksize == 3 and "rowvec" in k1 and a2[2].ksize == 1 and a1[3].n == a2[3].n  # conv1 + the 1x1 shortcut
+        sc_w = {id(rw.shortcut) for net in (eng.unet, eng.cn) for rw in _resnets(net) if rw.shortcut is not None}
+        assert not any(fn.__name__ == "conv" and id(a[3]) in sc_w for fn, a, k in prog.calls)
+    frame = np.random.default_rng(6).integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    assert np.array_equal(eng.infer_u8(frame), build(False).infer_u8(frame))
+
+
+def _resnets(net):
+    out, stack, seen = [], [net], set()
+    while stack:
+        o = stack.pop()
+        if id(o) in seen:
+            continue
+        seen.add(id(o))
+        if type(o).__name__ == "ResnetW":
+            out.append(o)
+        elif isinstance(o, (list, tuple)):
+            stack += list(o)
+        elif isinstance(o, dict):
+            stack += list(o.values())
+        elif hasattr(o, "__dict__") and not isinstance(o, (torch.Tensor, type)):
+            stack += list(vars(o).values())
+    return out
+
+
 def test_captured_program_is_a_sequence_of_single_branch_graphs_and_event_edges(mini):
     """Engine._capture: every run of kernel calls on one stream is one graph, every fork / join / signal / wait an event edge
     (record on the producing stream, wait on the consuming one), in program order; without a second stream the frame is ONE

@@ -206,6 +206,104 @@ def test_conv_group_equals_its_members_launched_one_by_one(ops):
         ops.conv_group([((x8.cuda(), None, Geom.linear(64), p8, torch.zeros(64, 64, dtype=torch.float16, device="cuda")), {})])
 
 
+def test_group_members_at_their_own_splits_and_scaled_residuals_in_every_reduction_form(ops):
+    """(1) conv_group(split=OWN_SPLIT) -- a ResnetBlock's conv1 (3x3, time vector, split over K at the deep levels) and its shortcut conv
+    (1x1 over the concat of two sources, unsplit) in ONE grid, every member at the split its own table entry has: bit for bit the two
+    launches, in every form the tuner may pick for the group, against fp32 too; a member whose own form is the halo patch sends
+    the members out alone.  (2) A scaled layer with a residual (the ControlNet merges: out_scale_dev + the UNet tensor) has the
+    same bits behind the reducer kernel, the in-launch tail and unsplit-tile walks: scale and residual are ONE fused multiply-add
+    everywhere (round 5: the reducer's epilogue rounded twice)."""
+    from videosd_amd import lib as L
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv, pack_linear
+
+    h = w = 8
+    c0, c1, n = 1280, 1280, 1280
+    x, skip = rnd(1, c0, h, w, seed=100), rnd(1, c1, h, w, seed=101)
+    t1 = rnd(1, c0 + c1, h, w, seed=102)
+    w1, rv = rnd(n, c0 + c1, 3, 3, seed=103, scale=(9 * (c0 + c1)) ** -0.5), rnd(n, seed=104, scale=0.1)
+    ws, bs = rnd(n, c0 + c1, seed=105, scale=(c0 + c1) ** -0.5), rnd(n, seed=106, scale=0.1)
+    p1, ps = ops.to_device_pack(pack_conv(w1, None)), ops.to_device_pack(pack_linear(ws, bs))
+    o1 = torch.zeros(h * w, n, dtype=torch.float16, device="cuda")
+    o2 = torch.zeros(h * w, n, dtype=torch.float16, device="cuda")
+    members = [((to_nhwc(t1).cuda(), None, Geom.conv(h, w), p1, o1), dict(rowvec=rv.cuda())),
+               ((to_nhwc(x).cuda(), to_nhwc(skip).cuda(), Geom.linear(h * w), ps, o2), dict(c0=c0, c1=c1))]
+    refs = [to_nhwc(F.conv2d(t1.float(), w1.float(), None, padding=1) + rv.float()[None, :, None, None]),
+            F.linear(torch.cat([to_nhwc(x).float(), to_nhwc(skip).float()], 1), ws.float(), bs.float())]
+    k1 = ops.conv_key_of(members[0][0][2], p1, members[0][1])
+    k2 = ops.conv_key_of(members[1][0][2], ps, members[1][1])
+    saved = {k: ops.tile_override.get(k) for k in (k1, k2)}
+    try:
+        ops.tile_override[k1] = (L.TILE_64x128, 12, False, 5)   # conv1: split 12 + reducer, as the table has it at 8 x 8
+        ops.tile_override[k2] = (L.TILE_64x64, 1, False, 5)     # the shortcut: unsplit
+        assert ops.own_splits(members) == [12, 1]
+        alone = []
+        for a, kw in members:
+            a[4].zero_()
+            ops.conv(*a, **kw)
+            ops.synchronize()
+            alone.append(a[4].clone())
+        cands = ops.group_candidates(members, split=ops.OWN_SPLIT)
+        assert all(f[1] == 0 for f in cands if f[0] != ops.GROUP_ALONE) and any(not f[2] for f in cands) and cands[-1][0] == ops.GROUP_ALONE
+        for form in cands:
+            for a, kw in members:
+                a[4].zero_()
+            for _ in range(2):
+                ops.conv_group(members, form=form, split=ops.OWN_SPLIT)
+            ops.synchronize()
+            for (a, kw), al, ref in zip(members, alone, refs):
+                check(a[4], ref, f"own-split group form {form}")
+                assert torch.equal(a[4], al), f"own-split group form {form}: bits differ from the member's own launch"
+        best, table = ops.tune_group(members, split=ops.OWN_SPLIT)
+        assert ops.group_key(members, ops.OWN_SPLIT) in ops.tile_override and len(table) == len(cands)
+        for a, kw in members:
+            a[4].zero_()
+        ops.conv_group(members, split=ops.OWN_SPLIT)  # (the remembered form)
+        ops.synchronize()
+        assert all(torch.equal(a[4], al) for (a, kw), al in zip(members, alone))
+        ops.tile_override[k1] = (L.TILE_128x64, 1, True, 7)   # conv1 in the halo-patch form: another K order -> no shared grid
+        assert ops.own_splits(members) is None
+        for a, kw in members:
+            a[4].zero_()
+        ops.conv_group(members, split=ops.OWN_SPLIT)
+        ops.synchronize()
+        for (a, kw), ref in zip(members, refs):
+            check(a[4], ref, "members sent out alone")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                ops.tile_override.pop(k, None)
+            else:
+                ops.tile_override[k] = v
+        ops.tile_override.pop(ops.group_key(members, ops.OWN_SPLIT), None)
+    # (2) scale + residual
+    m, c, n = 256, 1280, 1280
+    xs, res = rnd(m, c, seed=110), rnd(m, n, seed=111)
+    wt, b = rnd(n, c, seed=112, scale=c ** -0.5), rnd(n, seed=113, scale=0.1)
+    pw = ops.to_device_pack(pack_linear(wt, b))
+    scale = torch.tensor([0.3162], dtype=torch.float32, device="cuda")
+    ref = F.linear(xs.float(), wt.float(), b.float()) * 0.3162 + res.float()
+    outs = []
+    for tile, sp, ink, pl in [(L.TILE_64x64, 4, True, 3), (L.TILE_64x128, 4, False, 5), (L.TILE_128x64, 4, True, 5), (L.TILE_64x64, 4, False, 0)]:
+        ops.inkernel_splitk = ink
+        o = torch.zeros(m, n, dtype=torch.float16, device="cuda")
+        ops.conv(xs.cuda(), None, Geom.linear(m), pw, o, out_scale_dev=scale, residual=res.cuda(), ldr=n, tile=tile, split_k=sp, pipeline=pl)
+        ops.synchronize()
+        check(o, ref, f"scaled residual, tile {tile} split {sp} inkernel {ink}")
+        outs.append(o)
+    ops.inkernel_splitk = True
+    assert all(torch.equal(outs[0], o) for o in outs[1:]), "a scaled layer with a residual: the reduction forms differ in their bits"
+    o1 = torch.zeros(m, n, dtype=torch.float16, device="cuda")
+    ops.conv(xs.cuda(), None, Geom.linear(m), pw, o1, out_scale=0.3162, residual=res.cuda(), ldr=n, residual2=res.cuda(), tile=L.TILE_64x64, split_k=1)
+    o2 = torch.zeros(m, n, dtype=torch.float16, device="cuda")
+    ops.inkernel_splitk = False
+    ops.conv(xs.cuda(), None, Geom.linear(m), pw, o2, out_scale=0.3162, residual=res.cuda(), ldr=n, residual2=res.cuda(), tile=L.TILE_64x64, split_k=1,
+             pipeline=0)
+    ops.inkernel_splitk = True
+    ops.synchronize()
+    assert torch.equal(o1, o2)
+
+
 def test_twin_convs_split_over_k_share_a_grid_and_a_reducer(ops):
     """A group whose members are split over K (round 5: the twin layers of the UNet and the ControlNet encoder, one shape, two weight
     sets): slabs reduced by ONE more launch for the group, or by the last workgroup of each tile in the launch -- every member with a

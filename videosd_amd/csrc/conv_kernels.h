@@ -188,15 +188,15 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i]);
   }
-  if (p.out_scale_dev) {
-    const float sc = *p.out_scale_dev;  // uniform address: a scalar load
+  // scale and first residual as ONE fused multiply-add wherever both exist -- here, in the straight-line walks of conv_epilogue.inc
+  // and therefore behind the reducer kernel and the in-launch split-K tails alike.  (Round 5: this function multiplied inside a
+  // branch and added later -- two roundings -- while the walks' `x *= sc; x += r` was contracted by the compiler: a scaled layer
+  // with a residual, the ControlNet merges, differed in the last bit between its reducer form and its in-launch form.)  x * 1.0f
+  // and fma(x, 1.0f, r) are exact: unscaled layers keep their bits.
+  const float sc = p.out_scale_dev ? *p.out_scale_dev : p.out_scale;  // (uniform address: a scalar load)
+  if (p.out_t && n >= p.t_col0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= sc;
-  } else if (p.out_scale != 1.0f) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] *= p.out_scale;
-  }
-  if (p.out_t && n >= p.t_col0) {
     int col = m;
     if (p.batch > 1) {
       const int b = m / p.hw_out;
@@ -212,7 +212,10 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
       half8 r = res_val;
       if (!has_res) r = *reinterpret_cast<const half8*>(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] += (float)r[i];
+      for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaf(v[i], sc, (float)r[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= sc;
     }
     if (p.residual2) {
       half8 r = *reinterpret_cast<const half8*>(p.residual2 + (size_t)m * p.ldr + n);
@@ -243,8 +246,7 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (n + i >= p.N) continue;
-      float x = v[i];
-      if (p.residual) x += (float)p.residual[(size_t)m * p.ldr + n + i];
+      float x = p.residual ? __builtin_fmaf(v[i], sc, (float)p.residual[(size_t)m * p.ldr + n + i]) : v[i] * sc;
       if (p.residual2) x += (float)p.residual2[(size_t)m * p.ldr + n + i];
       if (post) x = apply_act(x);
       p.out[(size_t)m * p.ldo + n + i] = (half_t)x;

@@ -475,6 +475,7 @@ class Engine:
         # the one-stream form of the program runs the UNet and the ControlNet encoder of a step in lock step, twin layers as one
         # grid (`prepare`: both forms are recorded, `launch` picks)
         self.twin_encoders = not __import__("os").environ.get("VSD_NO_TWIN")
+        self.group_shortcuts = not __import__("os").environ.get("VSD_NO_GROUP_SHORTCUT")  # (a ResnetBlock's shortcut conv in conv1's grid)
         self.tail_b_min_rows = 1024         # ... the feed-forward chain from this many tokens per launch on (see _transformer)
 
     def make_slot(self, share_plan: bool = True, lane: Optional[int] = None) -> "Engine":
@@ -621,14 +622,23 @@ class Engine:
         self._gn(r, x, x2, c0, c1, hw, cfg.groups, 1e-5, rw.n1[0], rw.n1[1], True, t1)
         h = a.alloc(rows, rw.cout)
         tv = (self._temb(net) if temb is None else temb)[step, rw.temb_off:rw.temb_off + rw.cout]
-        r.conv(t1, None, geom, rw.conv1, h, rowvec=tv)
+        sc = x
+        # The shortcut conv (ResnetBlock2D.conv_shortcut: 16 per denoising step with the ControlNet) depends on the block's INPUT only:
+        # it shares conv1's grid (vsd_conv_gemm_group, every member at the split it has as a launch of its own: same bits) instead of
+        # being one more dependent launch between norm2 and conv2 -- 64 launches of a 4-step frame less.
+        grouped = (rw.shortcut is not None and self.group_shortcuts and hasattr(self.ops, "conv_group") and
+                   cin % 64 == 0 and c0 % 64 == 0 and c1 % 64 == 0 and rw.cout % 64 == 0 and (geom.hi, geom.wi) == (geom.hs, geom.ws))
+        if grouped:
+            sc = a.alloc(rows, rw.cout)
+            r.conv_group([((t1, None, geom, rw.conv1, h), dict(rowvec=tv)),
+                          ((x, x2, Geom.linear(rows), rw.shortcut, sc), dict(c0=c0, c1=c1))], split="own")
+        else:
+            r.conv(t1, None, geom, rw.conv1, h, rowvec=tv)
         t2 = a.alloc(rows, rw.cout)
         self._gn(r, h, None, rw.cout, 0, hw, cfg.groups, 1e-5, rw.n2[0], rw.n2[1], True, t2)
-        if rw.shortcut is not None:
+        if rw.shortcut is not None and not grouped:
             sc = a.alloc(rows, rw.cout)
             r.conv(x, x2, Geom.linear(rows), rw.shortcut, sc, c0=c0, c1=c1)
-        else:
-            sc = x
         out = out if out is not None else a.alloc(rows, rw.cout)
         r.conv(t2, None, geom, rw.conv2, out, residual=sc, residual2=residual2, out2=out2, add2=add2,
                chanstat_out=stat_out)
@@ -1010,7 +1020,12 @@ class Engine:
             for fn, a, k in calls:
                 if fn.__name__ in ("conv_group", "pair") and hasattr(ops, "tune_group"):
                     ops.tune_mode = mode if online else 0  # (a group's form is timed alone either way; see ops.tune_group)
-                    members, split = a[0], None
+                    members, split = a[0], k.get("split")
+                    if split == getattr(ops, "OWN_SPLIT", None):  # (members at their own splits: their own forms first)
+                        for aa, kk in members:
+                            mk = ops.conv_key_of(aa[2], aa[3], kk)
+                            if mk not in ops.tile_override and kk.get("tile") is None:
+                                seen[mk] = ops.tune_conv(aa, kk)[0]
                     if fn.__name__ == "pair":
                         if a[0][0].__name__ != "conv" or a[1][0].__name__ != "conv":
                             continue
@@ -1306,10 +1321,22 @@ class Engine:
                 else:
                     count("pair_" + op)
                 continue
-            count(name)
             if name == "conv_group":
+                split = k.get("split")
+                own = ops.own_splits(a[0]) if split == getattr(ops, "OWN_SPLIT", None) and hasattr(ops, "own_splits") else None
+                ent = table(ops.group_key(a[0], split)) if hasattr(ops, "group_key") else None
+                if (split is not None and own is None) or (ent is not None and ent[0] == ops.GROUP_ALONE):
+                    for aa, kk in a[0]:  # (a group whose table entry -- or a member's own form -- sends the members out alone)
+                        count("conv")
+                        count("splitk_reduce", conv_reducer(aa, kk))
+                    continue
+                count(name)
                 count("convs_in_groups", len(a[0]))
-            elif name == "conv":
+                if ent is not None and not ent[2] and ((own and max(own) > 1) or (not own and ent[1] > 1)):
+                    count("group_splitk_reduce")
+                continue
+            count(name)
+            if name == "conv":
                 count("splitk_reduce", conv_reducer(a, k))
             elif name == "groupnorm":
                 count("gn_second", gn_launches(a) - 1)

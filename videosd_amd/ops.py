@@ -418,13 +418,27 @@ class HipOps:
     GROUP_FORMS = [(L.TILE_64x64, 3), (L.TILE_64x64, 5), (L.TILE_64x128, 3), (L.TILE_64x128, 5), (L.TILE_128x64, 3), (L.TILE_128x64, 5),
                    (L.TILE_128x128, 3), (L.TILE_128x128, 5)]
     GROUP_ALONE = -1  # tile field of a group's table entry: "these members are faster as launches of their own"
+    OWN_SPLIT = "own"  # conv_group(split=...): every member at the split ITS OWN table entry has (split field 0 in the group's entry)
+
+    def own_splits(self, calls):
+        """the split over K each member has as a launch of its own (its table entry / default form), or None when a member's own
+        form sums over K in another order than the buffer-load ring does (the halo-patch form, the 256-row tiles' callers keep
+        their form) -- then the group's bits would differ from the launches' and the members go out alone"""
+        out = []
+        for a, kw in calls:
+            kw = {k: v for k, v in kw.items() if k not in ("tile", "split_k", "pipeline")}
+            d = self.conv(*a, _desc_only=True, **kw)
+            if d.pipeline == 7 or d.tile in (L.TILE_256x128, L.TILE_256x64):
+                return None
+            out.append(int(d.split_k))
+        return out
 
     def group_key(self, calls, split=None):
         k = ["group"]
         for a, kw in calls:
             k += [a[2].m, a[3].n, a[3].kp]
-        if split is not None:  # (a twin pair: the members' own split over K is part of the problem, see `pair`)
-            k += ["split", int(split)]
+        if split is not None:  # (a twin pair: the members' own split over K is part of the problem, see `pair`; "own": OWN_SPLIT)
+            k += ["split", 0 if split == self.OWN_SPLIT else int(split)]
         return tuple(k) + (int(self.tune_mode),)
 
     def conv_group(self, calls, form=None, split=None, default=None):
@@ -432,16 +446,23 @@ class HipOps:
         (plus one reducer launch for the members that leave split-K slabs), every member in the same kernel form
         (tile, split_k, reduce in the launch, pipeline) -- `form`, else this group's entry of the tuning table (`tune_group`), else
         64 x 64 tiles on the 3-stage ring, unsplit (`split`: split that many times -- the table entry is then looked up for that
-        split).  Member i works in scratch set i (split-K slabs, counters).  Same bits as the members launched one by one at the
+        split).  Member i works in a scratch set of its own (split-K slabs, counters).  Same bits as the members launched one by one at the
         same split_k, whatever their tile and pipeline (a conv's bits depend on the split alone: scripts/conv_bits_probe.py).  A
-        table entry may also say that the members are better off alone."""
+        table entry may also say that the members are better off alone.  split = OWN_SPLIT: members of DIFFERENT shapes that also
+        exist as launches of their own in another form of the program (a ResnetBlock's conv1 and its shortcut conv) -- every member
+        at the split its own table entry has (own_splits), the group's entry (split field 0) names tile / reduction form / pipeline."""
         if not 1 <= len(calls) <= L.CONV_GROUP_MAX:
             raise ValueError(f"conv_group: {len(calls)} members (1..{L.CONV_GROUP_MAX})")
+        own = None
+        if split == self.OWN_SPLIT:
+            own = self.own_splits(calls)
+            if own is None:
+                form = (self.GROUP_ALONE, 1, True, 0)
         if form is None:
             ent = self.tile_override.get(self.group_key(calls, split))
             if ent is None and self.tune_mode == 1:
                 ent = self.tile_override.get(self.group_key(calls, split)[:-1] + (0,))
-            form = ent if ent is not None else (default or (L.TILE_64x64, split or 1, True, 3))
+            form = ent if ent is not None else (default or (L.TILE_64x64, (0 if own else split) or 1, True, 3))
         tile, split_k, inkernel, pipeline = form
         if tile == self.GROUP_ALONE:
             for a, kw in calls:
@@ -453,8 +474,12 @@ class HipOps:
         try:
             for i, (a, kw) in enumerate(calls):
                 kw = {k: v for k, v in kw.items() if k not in ("tile", "split_k", "pipeline")}
-                self._widx = i
-                descs[i] = self.conv(*a, tile=tile, split_k=split_k, pipeline=pipeline, _desc_only=True, **kw)
+                # scratch set of member i on stream s: 2 i + s -- member 0 works in its stream's own set, the others in sets no launch of
+                # EITHER stream uses (a group on the side stream beside split-K layers on the main one: the shortcut groups of the
+                # two encoders.  With `i` alone the ControlNet's conv1 shared slabs and tickets with the UNet encoder's layers: wrong
+                # frames from the captured two-stream form, found by the mini-pipeline parity tests)
+                self._widx = 2 * i + self._sidx
+                descs[i] = self.conv(*a, tile=tile, split_k=own[i] if own else split_k, pipeline=pipeline, _desc_only=True, **kw)
         finally:
             self._widx = None
             self.inkernel_splitk = saved
@@ -463,10 +488,17 @@ class HipOps:
     def group_candidates(self, calls, split=None):
         """the kernel forms `tune_group` times: GROUP_FORMS at the given split over K (slabs reduced by one more launch for the group,
         or in the launch), and the members as launches of their own"""
-        sp = split or 1
         stats = any(kw.get("rowstat_out") is not None or kw.get("chanstat_out") is not None or a[3].tile128 for a, kw in calls)
+        if split == self.OWN_SPLIT:  # (entry's split field 0 = every member at its own)
+            own = self.own_splits(calls)
+            if own is None:
+                return [(self.GROUP_ALONE, 1, True, 0)]
+            sp, any_split = 0, max(own) > 1
+        else:
+            sp = split or 1
+            any_split = sp > 1
         cands = [(t, sp, True, pl) for t, pl in self.GROUP_FORMS]
-        if sp > 1 and not stats:
+        if any_split and not stats:
             cands += [(t, sp, False, pl) for t, pl in self.GROUP_FORMS]
         return cands + [(self.GROUP_ALONE, 1, True, 0)]
 
@@ -476,13 +508,13 @@ class HipOps:
         for form in self.group_candidates(calls, split):
             try:
                 for _ in range(2):
-                    self.conv_group(calls, form=form)
+                    self.conv_group(calls, form=form, split=split if split == self.OWN_SPLIT else None)
                 best = 1e30
                 for _trial in range(2):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self.stream)
                     for _ in range(reps):
-                        self.conv_group(calls, form=form)
+                        self.conv_group(calls, form=form, split=split if split == self.OWN_SPLIT else None)
                     e1.record(self.stream)
                     e1.synchronize()
                     best = min(best, e0.elapsed_time(e1) / reps * 1e3)
