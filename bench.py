@@ -373,6 +373,7 @@ def run_rank(args):
     eng.tune_for_lanes = args.slots >= 3 and B > 1 and not os.environ.get("VSD_NO_LANE_TUNING")
     t_prep = time.perf_counter()
     plan = eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=B)
+    launches_B = {"two_stream_form": eng.launches_by_kind()[0], "one_stream_form": eng.launches_by_kind(serial=True)[0]}
     prepare_ms = (time.perf_counter() - t_prep) * 1e3
     # a slider step (strength / controlnet_scale): device constants only, same captured graph
     t_upd = time.perf_counter()
@@ -487,6 +488,7 @@ def run_rank(args):
     # (the launch sequence the drop-in class uses for a lone frame: ControlNet encoder on the lane's side stream, nothing else
     #  there -- `use_side_stream` measures level since the launch streams own their pipes: 47.8 vs 47.6 launches/s)
     plan1 = eng.prepare(H, W, LCM_STEPS, STRENGTH, controlnet_scale=1.0, use_controlnet=True, batch=1)
+    launches_1 = {"two_stream_form": eng.launches_by_kind()[0], "one_stream_form": eng.launches_by_kind(serial=True)[0]}
     lat = []
     got0 = None
     for i in range(min(30, max(5, args.steps))):
@@ -582,7 +584,7 @@ def run_rank(args):
     #      forms): the sum of workgroup lives per family under captured-graph replay on all lanes, from the instrumented build
     #      (scripts/wg_cu_time.py; a constant of the committed profile, not measured in this run -- like `traffic`)
     in_situ = None
-    cut = os.path.join(ROOT, "profiles", "round5_wg_cu_time_5x4.txt")
+    cut = os.path.join(ROOT, "profiles", "round5f_wg_cu_time_5x4.txt")
     if os.path.exists(cut):
         try:
             runs = json.loads(open(cut).read().strip().splitlines()[-1])["runs"]
@@ -590,7 +592,7 @@ def run_rank(args):
             alone = next(r for r in runs if r["mode"] == 0 and r["lanes"] == 1)
             per_cu_peak = MFMA_PEAK_TFLOPS / 256.0
             fams = [f for f, v in timed["families"].items() if v["wg_ms_per_frame"] > 0]
-            in_situ = {"source": "profiles/round5_wg_cu_time_5x4.txt (scripts/wg_cu_time.py with the -DVSD_WG_TIMELINE build: every workgroup adds its life to a per-family "
+            in_situ = {"source": "profiles/round5f_wg_cu_time_5x4.txt (scripts/wg_cu_time.py with the -DVSD_WG_TIMELINE build: every workgroup adds its life to a per-family "
                                  "counter; a constant of the committed profile)",
                        "program": f"{timed['frames_per_launch']} frames per launch x {timed['lanes']} lanes, throughput-mode kernel forms, captured graphs",
                        "wg_ms_per_frame": {f: timed["families"][f]["wg_ms_per_frame"] for f in fams},
@@ -627,8 +629,13 @@ def run_rank(args):
                                "runs ControlNet); frames of the stream are coalesced frames_per_launch at a time",
                    "frames_per_rank": args.steps, "sharding": f"round-robin frames over {world} GPU(s)",
                    "frames_per_launch": B, "launches_in_flight_per_gpu": len(engines),
-                   "timesteps": plan["timesteps"], "kernel_launches_per_graph_replay": plan["n_ops"],
-                   "kernel_launches_per_single_frame_graph": plan1["n_ops"]},
+                   "timesteps": plan["timesteps"],
+                   # kernels one replay issues (Engine.launches_by_kind: reducers and second GroupNorm kernels counted, a pair / group of
+                   # calls sharing a grid once): the timed program runs the one-stream form (lanes >= 3), a lone frame the two-stream form
+                   "kernel_launches_per_graph_replay": launches_B["one_stream_form" if len(engines) >= 3 else "two_stream_form"],
+                   "kernel_launches_per_single_frame_graph": launches_1["one_stream_form"],
+                   "kernel_launches_by_form": {"frames_per_launch_%d" % B: launches_B, "one_frame": launches_1},
+                   "recorded_ops": {"frames_per_launch_%d" % B: plan["n_ops"], "one_frame": plan1["n_ops"]}},
         "p50_latency_ms": round(p50, 3),
         "p50_latency_ms_under_load": round(statistics.median(lat_loaded), 3) if lat_loaded else None,
         "fps_one_frame_per_launch": round(fps_b1, 3) if fps_b1 else None,

@@ -4,7 +4,7 @@ import collections, csv, json, sys
 
 trace, opsf = sys.argv[1], sys.argv[2]
 ops = json.load(open(opsf))
-ours = ("conv_gemm_kernel", "conv_halo_kernel", "tail_kernel", "adain_kernel", "splitk_reduce", "gn_stats", "gn_apply", "gn_fused", "layernorm_kernel", "attention_kernel",
+ours = ("conv_gemm_kernel", "conv_gemm_group_kernel", "conv_halo_kernel", "tail_kernel", "adain_kernel", "splitk_reduce", "gn_stats", "gn_apply", "gn_fused", "layernorm_kernel", "attention_kernel",
         "preprocess_rgb", "sobel_max", "sobel_apply", "add_noise", "lcm_step", "postprocess")
 rows = [r for r in csv.DictReader(open(trace)) if any(o in r["Kernel_Name"] for o in ours)]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -17,7 +17,7 @@ busy = 0
 total = 0
 for m in ops:
     n = {"groupnorm": 2, "sobel_control": 2}.get(m["op"], 1)
-    if m["op"] == "conv" and pos + 1 < len(last) and "splitk_reduce" in last[pos + 1]["Kernel_Name"]:
+    if m["op"] in ("conv", "conv_group") and pos + 1 < len(last) and "splitk_reduce" in last[pos + 1]["Kernel_Name"]:
         n = 2
     if m["op"] == "groupnorm" and "gn_stats" not in last[pos]["Kernel_Name"]:
         n = 1  # one-launch form (small images), or statistics fused into the producer

@@ -36,7 +36,10 @@ for name, H, Wd, steps, cn, scale in [("config1 256x256 1-step +CN", 256, 256, 1
     for i in range(n): slots[i % 4].launch()
     for e in slots: e.ops.synchronize()
     fps4 = n / (time.perf_counter() - t)
-    row = {"config": name, "p50_latency_ms_1_in_flight": round(sorted(lat)[6], 2), "fps_4_lanes": round(fps4, 1)}
+    # (arena: the activation memory ONE engine -- one program x frames per launch x lane -- owns; a worker's plan cache holds
+    #  lanes x batch sizes x programs of them under `memory_budget`)
+    row = {"config": name, "p50_latency_ms_1_in_flight": round(sorted(lat)[6], 2), "fps_4_lanes": round(fps4, 1),
+           "arena_gb_per_engine_one_frame_per_launch": round(eng.plan["arena_bytes"] / 2 ** 30, 2)}
     out.append(row)
     print(json.dumps(row), flush=True)
 

@@ -6,6 +6,8 @@ lanes, with the launch count of the one-frame program split by kind.
 --retune         time every conv shape of the one-frame program again (the table's entries for them are ignored)
 --save-tuning    merge this run's choices into the table at PATH
 --lanes          also 1 x 3 and 1 x 4 (one-frame launches on three / four lanes)
+--mode1          the one-frame program in THROUGHPUT-mode kernel forms (every candidate timed with four lanes busy, online: minutes) --
+                 what one-frame launches would cost on busy lanes if they were tuned like the coalesced ones
 Prints one JSON line (and appends it to gpurun_out/lone_frame.jsonl)."""
 import json
 import os
@@ -37,7 +39,9 @@ wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda")
 eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
 eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half())
 eng.overlap_launch = True
-eng.tune_for_lanes = False
+mode1 = "--mode1" in argv
+eng.tune_for_lanes = mode1
+ops.tune_lanes_online = mode1
 if retune:
     # record the one-frame program once without tuning to learn its conv keys, drop them from the table, prepare again
     eng.prepare(512, 512, 4, 0.6, use_controlnet=use_cn, batch=1, autotune=False, use_graph=False)
@@ -82,7 +86,7 @@ if "--lanes" in argv:
         while len(pool) < s:
             sl = eng.make_slot()
             sl.overlap_launch = False
-            sl.tune_for_lanes = False
+            sl.tune_for_lanes = mode1
             sl.prepare(512, 512, 4, 0.6, use_controlnet=use_cn, batch=1)
             sl.infer_u8(frames[0])
             pool.append(sl)

@@ -24,29 +24,40 @@ eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_see
 ops.load_tuning(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tuning_mi355x.json"))
 eng.overlap_controlnet = False
 eng.twin_encoders = False  # (a table of LAYERS: the two encoders' twin layers as launches of their own)
+eng.group_shortcuts = False  # (... and a ResnetBlock's shortcut conv beside its conv1, not in its grid)
 eng.prepare(size, size, 4, 0.6, use_controlnet=cn, use_graph=False, batch=batch)
 meta = []
+
+
+def conv_meta(a, k):
+    g, w = a[2], a[3]
+    tile, split = k.get("tile"), k.get("split_k")
+    if tile is None:
+        tile, sk = choose_tile(g.m, w.n, w.kp, w.geglu, k.get("t_col0", 0) if k.get("out_t") is not None else 0)
+        split = sk if split is None else split
+    key = ops.conv_key_of(g, w, k)
+    ink = True
+    if k.get("tile") is None and key in ops.tile_override:
+        tile, split, ink, _pl = ops.tile_override[key]
+    split = split or 1
+    kt = w.kp // 64
+    split = min(split, kt); per = -(-kt // split); split = -(-kt // per)
+    return dict(op="conv", M=g.m, N=w.n, K=w.k, ks=g.ksize, stride=g.stride, resize=(g.hi != g.hs), tile=tile, split=split if not ink else -split,
+                flops=2.0 * g.m * w.n * w.k, wbytes=2 * w.n * w.kp, geglu=w.geglu)
+
+
 for fn, a, k in eng.program.calls:
     name = fn.__name__
     if name in ("fork", "join", "use_stream", "signal", "wait"):
         continue
     m = {"op": name}
     if name == "conv":
-        g, w = a[2], a[3]
-        tile, split = k.get("tile"), k.get("split_k")
-        if tile is None:
-            tile, sk = choose_tile(g.m, w.n, w.kp, w.geglu, k.get("t_col0", 0) if k.get("out_t") is not None else 0)
-            split = sk if split is None else split
-        key = ops.conv_key_of(g, w, k)
-        ink = True
-        if k.get("tile") is None and key in ops.tile_override:
-            tile, split, ink, _pl = ops.tile_override[key]
-        split = split or 1
-        kt = w.kp // 64
-        split = min(split, kt); per = -(-kt // split); split = -(-kt // per)
-        m.update(M=g.m, N=w.n, K=w.k, ks=g.ksize, stride=g.stride, resize=(g.hi != g.hs), tile=tile, split=split if not ink else -split,
-                 flops=2.0 * g.m * w.n * w.k, wbytes=2 * w.n * w.kp, geglu=w.geglu)
+        m = conv_meta(a, k)
     elif name == "conv_group":  # several independent convs in one grid (the ControlNet merges): one kernel, the members' sums
+        ent = ops.tile_override.get(ops.group_key(a[0], k.get("split")))
+        if ent is not None and ent[0] == ops.GROUP_ALONE:  # (the table sends this group's members out as launches of their own)
+            meta.extend(conv_meta(aa, kk) for aa, kk in a[0])
+            continue
         mem = [aa for aa, _kk in a[0]]
         m.update(members=len(mem), M=sum(aa[2].m for aa in mem), flops=sum(2.0 * aa[2].m * aa[3].n * aa[3].k for aa in mem),
                  wbytes=sum(2 * aa[3].n * aa[3].kp for aa in mem))

@@ -1,11 +1,14 @@
-"""The autotuner's candidate table for one conv shape: python scripts/tune_conv_shape.py B H W CIN COUT [KSIZE=3] [act]"""
+"""The autotuner's candidate table for one conv shape: python scripts/tune_conv_shape.py B H W CIN COUT [KSIZE=3] [--mode1]
+(--mode1: the throughput-mode choice -- the shortlist timed with four copies in flight on the four launch lanes)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videosd_amd.ops import HipOps, Geom
 from videosd_amd.packing import pack_conv
-a = [int(x) for x in sys.argv[1:7]] + [3] * (6 - len(sys.argv[1:7]))
+argv = [x for x in sys.argv[1:] if not x.startswith('--')]
+a = [int(x) for x in argv[:6]] + [3] * (6 - len(argv[:6]))
 B, H, W, cin, cout, ks = a[:6]
 ops = HipOps(0)
+ops.tune_mode = 1 if '--mode1' in sys.argv else 0
 g_ = torch.Generator().manual_seed(0)
 r = lambda *s: (torch.randn(*s, generator=g_) * 0.05).half()
 pw = ops.to_device_pack(pack_conv(r(cout, cin, ks, ks), r(cout)))

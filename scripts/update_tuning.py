@@ -1,6 +1,7 @@
-"""Add the missing per-shape kernel configurations to profiles/tuning_mi355x.json: prepares the 512x512 4-step program
-for 1-4 frames per launch (with and without ControlNet), 768x768 8-step and the UI's 768x432, lets `Engine.autotune`
-time the candidates of every conv shape that is not in the table yet (GPU box), and writes the merged table back.
+"""Add the missing per-shape kernel configurations to profiles/tuning_mi355x.json: prepares every plan scripts/retune_all.py prepares
+(512x512 4-step at 1-8 frames per launch in both tuning modes, 768x768 8-step, the UI's 768x432, the small test sizes), lets
+`Engine.autotune` time the candidates of every conv shape / group / pair that is not in the table yet (GPU box), and writes the merged
+table back.
 usage: python scripts/update_tuning.py [out.json]"""
 import os, sys, time
 import torch
@@ -19,11 +20,21 @@ wc = W.synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", device="cuda")
 wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda")
 eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
 eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half())
-plans = [(512, 512, 4, b, cn) for b in (1, 2, 3, 4) for cn in (True, False)] + [(768, 768, 8, 1, True), (432, 768, 4, 1, True),
-                                                                                   (256, 256, 1, 1, True)]
+# (the plan list of scripts/retune_all.py: what the bench, the API leg, the tests and scripts/bench_configs.py prepare)
+plans = ([(512, 512, 4, b, True) for b in (5, 1, 2, 3, 4, 8, 6)] + [(512, 512, 4, b, False) for b in (5, 1)] +
+         [(768, 768, 8, 1, True), (432, 768, 4, 1, True), (256, 256, 1, 1, True), (192, 256, 2, 1, True), (192, 256, 2, 3, True)])
 for (h, w, steps, b, cn) in plans:
     t0 = time.time()
     eng.prepare(h, w, steps, 0.6, use_controlnet=cn, use_graph=False, batch=b)
     print(f"{h}x{w} steps={steps} batch={b} cn={cn}: table {len(ops.tile_override)} entries ({time.time() - t0:.1f} s)", flush=True)
+# ... and the coalesced plans in throughput mode (key's last field 1: candidates timed with four lanes busy; groups / pairs are timed
+# alone in either mode) -- only what the table lacks, e.g. the group entries of the lock-step encoders and the shortcut groups
+eng.tune_for_lanes = True
+ops.tune_lanes_online = True
+for (h, w, steps, b, cn) in [(512, 512, 4, b, True) for b in (5, 2, 3, 4, 8, 6)] + [(512, 512, 4, 5, False)]:
+    t0 = time.time()
+    eng.prepare(h, w, steps, 0.6, use_controlnet=cn, use_graph=False, batch=b)
+    print(f"[four lanes busy] {h}x{w} steps={steps} batch={b} cn={cn}: table {len(ops.tile_override)} entries ({time.time() - t0:.1f} s)", flush=True)
+eng.tune_for_lanes = False
 ops.save_tuning(out)
 print(f"loaded {n0}, now {len(ops.tile_override)} entries -> {out}")

@@ -23,9 +23,11 @@ __device__ __forceinline__ void splitk_reduce_body(const ConvParams& p) {
     const bool transposed = p.out_t && n >= p.t_col0;
     // the epilogue's operands of these 8 columns, fetched beside the slabs
     const bool pre_res = full && p.residual != nullptr && !transposed;
-    // (bias and time vector stay with epilogue_store8: it adds them one after the other, as the halo kernel's in-launch
-    //  epilogue does -- the two forms of a split halo conv must give the same bits -- and they are L2-resident row vectors)
+    // (bias and time vector are added one after the other by epilogue_store8, as the halo kernel's in-launch epilogue does -- the
+    //  two forms of a split halo conv must give the same bits --, from the raw values fetched HERE, beside the slabs: loaded
+    //  inside epilogue_store8 they were one more dependent round trip behind the slab sums in each of a lone frame's ~280 reducers)
     const bool pre_brv = false;
+    const bool pre_raw = full && !p.ln_part;
     half8 rres = (half8){0, 0, 0, 0, 0, 0, 0, 0}, braw = rres, rvraw = rres;
     if (full) {
       constexpr int NB = 8;
@@ -37,8 +39,8 @@ __device__ __forceinline__ void splitk_reduce_body(const ConvParams& p) {
         hi[k] = *reinterpret_cast<const f32x4*>(s + kk * slab + 4);
       }
       if (pre_res) rres = *reinterpret_cast<const half8*>(p.residual + (size_t)m * p.ldr + n);
-      if (pre_brv && p.bias) braw = *reinterpret_cast<const half8*>(p.bias + n);
-      if (pre_brv && p.rowvec) rvraw = *reinterpret_cast<const half8*>(p.rowvec + n);
+      if (pre_raw && p.bias) braw = *reinterpret_cast<const half8*>(p.bias + n);
+      if (pre_raw && p.rowvec) rvraw = *reinterpret_cast<const half8*>(p.rowvec + n);
 #pragma unroll
       for (int k = 0; k < NB; ++k)
         if (k < p.split_k) {
@@ -78,13 +80,8 @@ __device__ __forceinline__ void splitk_reduce_body(const ConvParams& p) {
       ln_transform8(p, n, mean, rstd, v);
     }
     float rs = 0.f, rq = 0.f;
-    f32x4 blo, bhi;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      blo[i] = (float)braw[i] + (float)rvraw[i];
-      bhi[i] = (float)braw[4 + i] + (float)rvraw[4 + i];
-    }
-    epilogue_store8(p, m, n, v, rs, rq, pre_res, rres, pre_brv, blo, bhi);
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    epilogue_store8(p, m, n, v, rs, rq, pre_res, rres, pre_brv, z4, z4, pre_raw, braw, rvraw);
   }
 }
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) { splitk_reduce_body(p); }

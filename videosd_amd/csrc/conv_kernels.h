@@ -142,14 +142,27 @@ namespace {
 // from scratch inside the walk; found with scripts/wg_timeline.py: half of a short-K workgroup's life was its epilogue).
 __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int n, float (&v)[8], float& rsum, float& rsq,
                                                 const bool has_res, const half8 res_val, const bool has_brv, const f32x4 brv_lo,
-                                                const f32x4 brv_hi) {
+                                                const f32x4 brv_hi, const bool has_raw = false,
+                                                const half8 bias_raw = (half8){0, 0, 0, 0, 0, 0, 0, 0},
+                                                const half8 rowvec_raw = (half8){0, 0, 0, 0, 0, 0, 0, 0}) {
   // n is a multiple of 8; handles n + 8 > N by scalar fallback
+  // has_raw: bias / time vector of these 8 columns as the caller fetched them beside its other operands (the reducer kernel: its
+  // own loads here sat behind the slab sums, one more dependent round trip per launch); added one after the other, as below
   const bool full = (n + 8 <= p.N);
   if (has_brv) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       v[i] += brv_lo[i];
       v[4 + i] += brv_hi[i];
+    }
+  } else if (has_raw) {
+    if (p.bias) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += (float)bias_raw[i];
+    }
+    if (p.rowvec) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += (float)rowvec_raw[i];
     }
   } else {
   if (p.bias) {

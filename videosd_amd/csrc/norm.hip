@@ -216,7 +216,7 @@ __global__ void gn_apply_pair_kernel(const Pair<GnParams> g) { gn_apply_body(g.p
 // NV = vectors per row piece (cpg / VW), RMAX rows per thread.
 // GPW = groups per workgroup (1 in every shipped instantiation).  Round 5 measured 2 groups of 20 channels / 4 of 10 per workgroup
 // (80-byte row pieces, 16-byte vectors, half the workgroups) at 32 x 32 x 640: 9.6 against 8.3 us for one image, 12.5 against 13.2 for
-// five (scripts/gn_bench.py) -- the kernel is launch + two dependent round trips, not line traffic: not used.
+// five (scripts/gn_bench.py) -- the kernel is launch + dependent round trips, not line traffic: not used.
 template <int VW, int NV, int RMAX, int GPW = 1>
 __device__ __forceinline__ void gn_fused_body(const GnParams& p) {
   VSD_CUT(VSD_CUT_GROUPNORM, p.cut)
@@ -242,6 +242,14 @@ __device__ __forceinline__ void gn_fused_body(const GnParams& p) {
         x[r][v] = *reinterpret_cast<const vec_t*>(src);
       }
     }
+  }
+  // gamma / beta do not depend on the statistics: fetched with the rows (behind the barriers below their loads were a second,
+  // dependent memory round trip in every one-launch GroupNorm)
+  vec_t gav[NV], bev[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    gav[v] = *reinterpret_cast<const vec_t*>(p.gamma + ch0 + v * VW);
+    bev[v] = *reinterpret_cast<const vec_t*>(p.beta + ch0 + v * VW);
   }
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) {
@@ -289,8 +297,7 @@ __device__ __forceinline__ void gn_fused_body(const GnParams& p) {
   float a[NV][VW], b[NV][VW];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const vec_t ga = *reinterpret_cast<const vec_t*>(p.gamma + ch0 + v * VW);
-    const vec_t be = *reinterpret_cast<const vec_t*>(p.beta + ch0 + v * VW);
+    const vec_t ga = gav[v], be = bev[v];
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
       const int g = (v * VW + i) / CPG;

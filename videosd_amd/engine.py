@@ -1080,6 +1080,11 @@ class Engine:
         if batch < 1:
             raise ValueError("batch must be >= 1")
         self.batch = batch
+        # The lock-step encoders are the one-stream form of ONE-FRAME programs only: a pair fills the chip where a lone small layer does
+        # not (1 x 4: 83 -> 89 frames/s), but at five frames per launch the grids are full already and a pair's form is chosen by launch
+        # latency, not by the workgroup-time it occupies -- same box, 5 x 4: 136.4 with pairs / 137.2 without on the table's forms,
+        # 115 / 140 with the pairs in their members' throughput-mode forms (profiles/round5f_pairs_at_5x4.txt).
+        self._twin_now = self.twin_encoders and batch == 1
         if hasattr(self.ops, "tune_mode"):
             self.ops.tune_mode = 1 if self.tune_for_lanes else 0
         if H % 8 or W % 8:
@@ -1207,7 +1212,7 @@ class Engine:
                 two.calls += ru_.calls
                 if self.overlap_controlnet:
                     two.join()
-                if self.twin_encoders and hasattr(ops, "pair"):
+                if self._twin_now and hasattr(ops, "pair"):
                     twin = Recorder(ops)
                     self._zip_pairs(twin, ru_.calls, rc_.calls)
                     r.variants(two.calls, twin.calls)
@@ -1233,8 +1238,8 @@ class Engine:
         r.postprocess_rgb(dec_out, 8, B * H * W, out_b)
         # program: what a lone launch runs (the ControlNet encoder on the side stream when `overlap_controlnet`);
         # program_serial: everything on the lane's own stream (the encoders in lock step when `twin_encoders`)
-        self.program = r.flavor(0 if self.overlap_controlnet or not self.twin_encoders else 1)
-        self.program_serial = r.flavor(1) if self.twin_encoders and self.overlap_controlnet and use_controlnet else self.program
+        self.program = r.flavor(0 if self.overlap_controlnet or not self._twin_now else 1)
+        self.program_serial = r.flavor(1) if self._twin_now and self.overlap_controlnet and use_controlnet else self.program
         self.plan = dict(H=H, W=W, steps=steps, strength=strength, cn_scale=controlnet_scale, cn=use_controlnet, n=n, batch=B,
                          ref_mode=bool(ref_mode), tuned_for_lanes=bool(self.tune_for_lanes),
                          sizes=sizes, timesteps=sched.timesteps, n_ops=len(self.program.calls), arena_bytes=a.peak)
