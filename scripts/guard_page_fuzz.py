@@ -120,6 +120,61 @@ def one_conv():
     return "ok"
 
 
+def one_group():
+    """2-4 independent convs / linear layers as ONE grid (vsd_conv_gemm_group): ragged members of different shapes, one kernel form,
+    split over K with the slabs reduced in the launch or by the group's reducer -- every operand AND the members' split-K workspaces
+    (HipOps.allocator hook) between unmapped pages; the result must be bit for bit what the members give launched one by one."""
+    n = int(rng.integers(2, 5))
+    tile, pipeline = int(rng.choice([0, 1, 2, 3])), int(rng.choice([3, 5]))
+    split, inkernel = int(rng.choice([1, 1, 2, 3, 6])), bool(rng.random() < 0.5)
+    members, refs, descs = [], [], []
+    for i in range(n):
+        ks = int(rng.choice([1, 1, 3]))
+        h, w, b = int(rng.integers(1, 28)), int(rng.integers(1, 28)), int(rng.choice([1, 1, 2]))
+        cin, cout = int(rng.choice([64, 128, 320])), int(rng.choice([8, 24, 64, 72, 136, 200, 320]))
+        c1 = 64 if (cin > 64 and rng.random() < 0.3) else 0
+        act, use_res = int(rng.choice([0, 1, 2])), bool(rng.random() < 0.5)
+        g = Geom.conv(h, w, ksize=ks, batch=b)
+        descs.append(f"{b}x{h}x{w} {cin - c1}+{c1}->{cout} ks{ks} act {act} res {use_res}")
+        x = rnd(b, cin, h, w)
+        wt, bias = rnd(cout, cin, ks, ks, scale=(cin * ks * ks) ** -0.5), rnd(cout, scale=0.1)
+        pw = gpack(pack_conv(wt, bias))
+        rows = x.permute(0, 2, 3, 1).reshape(-1, cin)
+        s0, s1 = guarded(rows[:, :cin - c1]), (guarded(rows[:, cin - c1:]) if c1 else None)
+        ldo = (cout + 7) // 8 * 8
+        res = rnd(g.m, ldo) if use_res else None
+        kw = dict(ldo=ldo, act=act, c0=cin - c1, c1=c1)
+        if res is not None:
+            kw.update(residual=guarded(res), ldr=ldo)
+        members.append(((s0, s1, g, pw, guarded(shape=(g.m, ldo))), kw))
+        ref = {0: lambda v: v, 1: F.relu, 2: F.silu}[act](F.conv2d(x.float(), wt.float(), bias.float(), padding=ks // 2))
+        ref = ref.permute(0, 2, 3, 1).reshape(g.m, cout)
+        refs.append((ref + res[:, :cout].float() if res is not None else ref, cout))
+    desc = f"group of {n}: tile {tile} pipeline {pipeline} split {split} inkernel {inkernel} | " + " | ".join(descs)
+    print(desc, flush=True)
+    ops.allocator = lambda nbytes: guarded(shape=(int(nbytes),), dtype=torch.uint8)
+    try:
+        ops.conv_group(members, form=(tile, split, inkernel, pipeline))
+        ops.synchronize()
+        got = [a[4].clone() for a, kw in members]
+        ops.inkernel_splitk = inkernel
+        for (a, kw), g_, (ref, cout) in zip(members, got, refs):
+            close(g_[:, :cout], ref, desc)
+            a[4].zero_()
+            ops.conv(*a, tile=tile, split_k=split, pipeline=pipeline, **kw)
+            ops.synchronize()
+            assert torch.equal(a[4], g_), "a member launched alone differs from the group: " + desc
+    except RuntimeError as e:
+        if "failed" in str(e) and "conv_gemm" in str(e):
+            return "refused"
+        raise
+    finally:
+        ops.allocator = None
+        ops._ws.clear()
+        ops.inkernel_splitk = True
+    return "ok"
+
+
 def one_qkv():
     b, hw, c = int(rng.choice([1, 2, 3])), int(rng.integers(1, 300)), int(rng.choice([64, 128, 320]))
     tile = int(rng.choice([0, 1, 2, 3]))
@@ -301,7 +356,7 @@ if "selftest" in sys.argv:
     print(float(big.sum()), "NO FAULT: the guard pages do not work here", flush=True)
     sys.exit(3)
 
-kinds = [one_conv, one_conv, one_conv, one_qkv, one_xattn, one_groupnorm, one_attention, one_layernorm, one_pixels, one_tail, one_geglu]
+kinds = [one_conv, one_conv, one_conv, one_group, one_group, one_qkv, one_xattn, one_groupnorm, one_attention, one_layernorm, one_pixels, one_tail, one_geglu]
 count = {}
 t_end = time.time() + seconds
 while time.time() < t_end:
