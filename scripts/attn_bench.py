@@ -7,7 +7,7 @@ if os.environ.get("ATTN_BENCH_LIB"):  # an experimental build of the library (de
     _lib.LIB_PATH = os.path.abspath(os.environ["ATTN_BENCH_LIB"])
 from videosd_amd.ops import HipOps
 ops = HipOps(0)
-shapes = [(4096, 4096, 8, 40, 5), (4096, 4096, 8, 40, 3), (1024, 1024, 8, 80, 5), (256, 256, 8, 160, 5), (20480, 77, 8, 40, 1)] if os.environ.get("ATTN_BENCH_SHORT") else [(4096, 4096, 8, 40, 1), (1024, 1024, 8, 80, 1), (256, 256, 8, 160, 1), (4096, 77, 8, 40, 1), (1024, 77, 8, 80, 1),
+shapes = [(4096, 4096, 8, 40, 5), (4096, 4096, 8, 40, 3), (4096, 4096, 8, 40, 2), (4096, 4096, 8, 40, 1), (1024, 1024, 8, 80, 5), (1000, 1000, 8, 80, 3), (3000, 2999, 8, 40, 2), (256, 256, 8, 160, 5), (20480, 77, 8, 40, 1)] if os.environ.get("ATTN_BENCH_SHORT") else [(4096, 4096, 8, 40, 1), (1024, 1024, 8, 80, 1), (256, 256, 8, 160, 1), (4096, 77, 8, 40, 1), (1024, 77, 8, 80, 1),
           (4096, 4096, 10, 64, 1), (1024, 1024, 20, 64, 1), (4096, 4096, 8, 40, 2), (4096, 4096, 8, 40, 3), (1024, 1024, 8, 80, 3),
           (256, 256, 8, 160, 3), (9216, 9216, 8, 40, 1)]
 variants = ["auto", "4,1,1", "4,1,2", "2,1,1", "2,1,2"] if os.environ.get("ATTN_BENCH_SHORT") else ["auto", "4,1,1", "4,1,2", "2,1,1"]
