@@ -282,6 +282,55 @@ def test_a_dead_group_member_does_not_stall_a_prompt_change():
             w.close()
 
 
+def test_the_group_is_reformed_once_a_dead_members_replacement_is_up():
+    """VERDICT r4, missing #6: once a member died the process group was gone for good and every later prompt was encoded by every
+    worker.  Now the dispatcher re-forms it: the replacement starts stand-alone, and when every member is alive again all of them
+    rendezvous in a NEW group (`__join_group__`: fresh port, ranks = positions) -- the next new prompt is encoded ONCE, on rank 0,
+    and reaches the others (the replacement included) by broadcast; rank 0's kernel choices go to the newcomer too."""
+    import time
+
+    ws = spawn_workers(2, factory=SESSION, backend="gloo", model="m", controlnet="c", delay=0.01, call_timeout=20.0, sync_timeout=3.0,
+                       crash_on=66)
+    try:
+        async def go():
+            d = FrameDispatcher(ws, depth=4, respawn=True, warm_options=dict(OPTS))
+            for k in range(2):
+                d.submit(_img(10 + k), prompt="a red fox", **OPTS)
+            first = [await asyncio.wait_for(d.next_result(), timeout=60) for _ in range(2)]
+            assert all(not isinstance(r[1], Exception) for r in first) and d.prompt_syncs == 1 and d.group_ok
+            d.submit(_img(12), prompt="a red fox", **OPTS)   # frame 2 -> worker 0
+            d.submit(_img(66), prompt="a red fox", **OPTS)   # frame 3 -> worker 1: dies
+            died = [await asyncio.wait_for(d.next_result(), timeout=60) for _ in range(2)]
+            assert isinstance(died[1][1], WorkerDied) and not d.group_ok
+            t0 = time.time()
+            while (d.respawns < 1 or not d.group_ok) and time.time() - t0 < 120:
+                await asyncio.sleep(0.2)
+            assert d.respawns == 1 and d.regroups == 1 and d.group_ok and d.regroup_failures == 0, (d.respawns, d.regroups, d.regroup_failures)
+            assert all(getattr(p, "group", None) and p.group["world"] == 2 for p in d.pipelines)
+            syncs = d.prompt_syncs
+            tickets = [d.submit(_img(20 + k), prompt="a blue whale", **OPTS) for k in range(4)]
+            n = sum(1 for t in tickets if t is not None)
+            res = [await asyncio.wait_for(d.next_result(), timeout=60) for _ in range(n)]
+            assert n >= 2 and all(not isinstance(r[1], Exception) for r in res), res
+            assert d.prompt_syncs == syncs + 1 and d.local_prompt_requests == 0 and d.group_ok
+            st = [await p.method("session_state").remote() for p in d.pipelines]
+            m = await d.metrics()
+            return st, m, d.pipelines
+
+        st, m, pipes = asyncio.run(go())
+        # "a blue whale" was encoded ONCE (on rank 0) and installed on both; the replacement never encoded it itself
+        assert all("a blue whale" in s["prompts"] for s in st), st
+        assert st[1]["encodes"] == 0 and st[0]["encodes"] == 2, [s["encodes"] for s in st]
+        assert m["regroups"] == 1 and m["group_ok"] is True
+        # rank 0's table entry reached the replacement with the regroup's tuning sync
+        assert all(st[1]["tuning"].get(k) == v for k, v in st[0]["tuning"].items() if k[0] != "warmed" or v == ("by", 0))
+    finally:
+        for w in ws:
+            w.close()
+        for w in locals().get("pipes", []) or []:
+            w.close()
+
+
 def test_rank0_tuning_choices_reach_every_rank():
     """shapes missing from the shipped table used to be tuned per worker -- two ranks could pick different
     tiles / split-K and return different bits for the same frame.  `spawn_workers(warm_options=...)`: rank 0 warms up first,
