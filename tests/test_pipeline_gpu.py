@@ -361,7 +361,7 @@ def test_side_stream_and_single_stream_sequences_give_the_same_bits(mini_setup):
     not depend on which of the two a launch takes -- nor on another lane running beside it."""
     eng, orc, text = mini_setup
     eng.overlap_controlnet = True
-    eng.prepare(128, 128, 4, 0.6, controlnet_scale=1.5, use_controlnet=True)
+    eng.prepare(128, 128, 4, 0.6, controlnet_scale=1.5, use_controlnet=True, use_graph=True)  # (the fixture's engine may come from an eager test)
     assert eng.plan["edges"] == 2 * 4 and eng.plan["graphs"] == 1 + 3 * 4 and eng.graph_serial is not eng.graph
     assert eng.ops.seq_count(eng.graph_serial) == (1, 0)
     n2, k2 = eng.launches_by_kind()

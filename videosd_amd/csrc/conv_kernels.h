@@ -17,6 +17,7 @@
 // Algorithmic work per launch: 2*M*N*K FLOP, fp16 bytes: N*Kp (weights) + M*Cin (input) + M*N (output).
 #pragma once
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -468,14 +469,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 
 template <int BM, int BN, bool GENERIC, int STAGES, bool ILV, bool FAST>
 __global__ __launch_bounds__(256) void conv_gemm_group_kernel(const ConvGroup g) {
-  int prob = 0;
+  int prob = 0, first = 0;
 #pragma unroll
   for (int i = 1; i < VSD_GROUP_MAX; ++i)
-    if (i < g.n && (int)blockIdx.x >= g.start[i]) prob = i;
-  const ConvParams& p = g.p[prob];
+    if (i < g.n && (int)blockIdx.x >= g.start[i]) {
+      prob = i;
+      first = g.start[i];
+    }
+  // This problem's argument block, read from the KERNEL-ARGUMENT SEGMENT at a uniform offset (scalar loads).  `g.p[prob]` -- a
+  // runtime index into a by-value struct -- made the compiler copy all eight blocks to scratch memory in the 128 x 128 and two more
+  // instantiations (3.5 KB per lane, every later p.field a scratch load: scripts/kernel_resources.py, round 5).
+  typedef const __attribute__((address_space(4))) ConvParams* kparams_t;
+  typedef const __attribute__((address_space(4))) char* kbytes_t;
+  const kparams_t kp = (kparams_t)((kbytes_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ConvGroup, p)) +
+                       __builtin_amdgcn_readfirstlane(prob);
+  const ConvParams p = *(const ConvParams*)kp;  // (the copy is by scalar loads: the compiler sees through the cast to the constant address space)
   VSD_CUT(VSD_CUT_CONV_GEMM, p.cut)
   WGTL_START()
-  const int conv_bid = (int)blockIdx.x - g.start[prob];
+  const int conv_bid = (int)blockIdx.x - first;
 #define CONV_BID conv_bid
 #include "conv_gemm_body.inc"
 #undef CONV_BID

@@ -324,12 +324,14 @@ __device__ __forceinline__ void gn_fused_body(const GnParams& p) {
   }
 }
 
+// (groups of more than 20 channels run on images of at most 256 pixels -- gn_try_fused -- i.e. at most 256 threads: said here,
+//  the 40-channel form keeps its row, gamma and beta in registers; under the default 1024-thread bound it had 128 and spilled 18)
 template <int VW, int NV, int RMAX>
-__global__ void gn_fused_kernel(const GnParams p) {
+__global__ __launch_bounds__(VW * NV > 20 ? 256 : 1024) void gn_fused_kernel(const GnParams p) {
   gn_fused_body<VW, NV, RMAX>(p);
 }
 template <int VW, int NV, int RMAX>
-__global__ void gn_fused_pair_kernel(const Pair<GnParams> g) {
+__global__ __launch_bounds__(VW * NV > 20 ? 256 : 1024) void gn_fused_pair_kernel(const Pair<GnParams> g) {
   gn_fused_body<VW, NV, RMAX>(g.p[blockIdx.z]);
 }
 
