@@ -1029,6 +1029,8 @@ class Engine:
                     if fn.__name__ == "pair":
                         if a[0][0].__name__ != "conv" or a[1][0].__name__ != "conv":
                             continue
+                        if mode == 1:  # (throughput mode: a pair runs in its members' own form, ops.pair -- nothing to time)
+                            continue
                         members = [(a[0][1], a[0][2]), (a[1][1], a[1][2])]
                         for aa, kk in members:  # (a pair the one-stream form alone holds: its members' own forms first)
                             mk = ops.conv_key_of(aa[2], aa[3], kk)
@@ -1080,11 +1082,12 @@ class Engine:
         if batch < 1:
             raise ValueError("batch must be >= 1")
         self.batch = batch
-        # The lock-step encoders are the one-stream form of ONE-FRAME programs only: a pair fills the chip where a lone small layer does
-        # not (1 x 4: 83 -> 89 frames/s), but at five frames per launch the grids are full already and a pair's form is chosen by launch
-        # latency, not by the workgroup-time it occupies -- same box, 5 x 4: 136.4 with pairs / 137.2 without on the table's forms,
-        # 115 / 140 with the pairs in their members' throughput-mode forms (profiles/round5f_pairs_at_5x4.txt).
-        self._twin_now = self.twin_encoders and batch == 1
+        # The lock-step encoders are the one-stream form of EVERY program.  What a pair's grid looks like depends on the mode: a one-frame
+        # program (latency mode) takes the pair's own table entry, timed alone; a coalesced launch on busy lanes (throughput mode) runs
+        # the pair in the form its members have as launches of their own -- a latency-chosen form there occupies more workgroup-time
+        # than the two launches (profiles/round5f_pairs_at_5x4.txt).  Measured on one box with / without pairs: 1 x 4 89.7 / 83.5,
+        # 2 x 4 122.2 / 118.8, 3 x 4 133.8 / 131.3, 3 x 3 127.7 / 123.0, 4 x 4 138.8 / 138.3, 5 x 4 140.2 / 140.4 frames/s.
+        self._twin_now = self.twin_encoders
         if hasattr(self.ops, "tune_mode"):
             self.ops.tune_mode = 1 if self.tune_for_lanes else 0
         if H % 8 or W % 8:
@@ -1312,6 +1315,8 @@ class Engine:
                 if op == "conv":
                     sp = ops.pair_split(aa, ka, ab, kb)
                     ent = table(ops.group_key([(aa, ka), (ab, kb)], sp)) if sp is not None else (ops.GROUP_ALONE,)
+                    if sp is not None and getattr(ops, "tune_mode", 0) == 1:  # (throughput mode: the members' own form, ops.pair)
+                        ent = ops._pair_default
                     if ent is None:
                         ent = (0, sp, True, 3)
                     if ent[0] != ops.GROUP_ALONE:

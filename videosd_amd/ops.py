@@ -534,8 +534,14 @@ class HipOps:
         (fa, aa, ka), (fb, ab, kb) = a, b
         if fa.__name__ == "conv" and fb.__name__ == "conv":
             sp = self.pair_split(aa, ka, ab, kb)
-            if sp is not None:  # (no table entry for the pair: the form its first member has alone)
-                return self.conv_group([(aa, ka), (ab, kb)], split=sp, default=self._pair_default)
+            if sp is not None:
+                # Latency mode (one-frame programs): the pair's table entry (`tune_group`, timed alone), else the form its first member
+                # has alone.  Throughput mode (coalesced launches on busy lanes): ALWAYS the members' own form -- a group's entry is
+                # chosen by launch latency, and in such a form a pair of the 5-frame program's layers occupied 14 % more workgroup-time
+                # than the two launches (profiles/round5f_pairs_at_5x4.txt); in their own form the pair costs what they cost and
+                # saves the launch.
+                own_form = self._pair_default if self.tune_mode == 1 else None
+                return self.conv_group([(aa, ka), (ab, kb)], form=own_form, split=sp, default=self._pair_default)
             fa(*aa, **ka)
             self._widx = 1
             try:
