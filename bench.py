@@ -469,20 +469,23 @@ def run_rank(args):
 
     # ---- p50 per-frame latency: host u8 in -> host u8 out (PCIe inclusive), (a) one frame in flight,
     #      (b) under the benchmark's load (`slots` frames in flight): submit -> that frame's u8 on the host
-    lat_loaded = []
-    if len(engines) > 1:
-        t_sub = {}
-        nl = 6 * len(engines)
-        for i in range(nl + len(engines)):
-            e = engines[i % len(engines)]
-            if i >= len(engines):  # the frame submitted len(engines) iterations ago on this slot
+    def loaded_latency(pool, nb):
+        """ms from submit (host u8) to that frame's u8 on the host with len(pool) launches of nb frames kept in flight"""
+        out_ms, t_sub = [], {}
+        nl = 6 * len(pool)
+        for i in range(nl + len(pool)):
+            e = pool[i % len(pool)]
+            if i >= len(pool):  # the frame submitted len(pool) iterations ago on this slot
                 e.ops.download(e.out_u8)
-                lat_loaded.append((time.perf_counter() - t_sub[i - len(engines)]) * 1e3)
+                out_ms.append((time.perf_counter() - t_sub[i - len(pool)]) * 1e3)
             if i < nl:
                 t_sub[i] = time.perf_counter()
-                e.ops.upload(e.frame_u8, torch.from_numpy(frames_host[:B]))
+                e.ops.upload(e.frame_u8, torch.from_numpy(frames_host[:nb] if nb > 1 else frames_host[0]).view_as(e.frame_u8))
                 e.launch()
-        sync_all()
+        sync_all(pool)
+        return out_ms
+
+    lat_loaded = loaded_latency(engines, B) if len(engines) > 1 else []
     eng.overlap_launch = True
     eng.tune_for_lanes = False
     # (the launch sequence the drop-in class uses for a lone frame: ControlNet encoder on the lane's side stream, nothing else
@@ -503,8 +506,9 @@ def run_rank(args):
     #      3 (x2: round 1's final / round 2's earlier headline) and 8 (x2): throughput against frames in flight
     fps_b1 = None
     fps_by_b = {}
+    lat_loaded_1x4 = []
     if extras:
-        def throughput_at(b, nslots, overlap=False):
+        def throughput_at(b, nslots, overlap=False, loaded=None):
             pool = [eng] + list(engines[1:nslots])
             while len(pool) < nslots:
                 pool.append(eng.make_slot())
@@ -526,12 +530,15 @@ def run_rank(args):
             for i in range(nn):
                 one_frame(i, pool)
             sync_all(pool)
-            return nn * b / (time.perf_counter() - t1)
+            got = nn * b / (time.perf_counter() - t1)
+            if loaded is not None:
+                loaded.extend(loaded_latency(pool, b))
+            return got
 
         # one frame per launch (BASELINE configs[1] as worded): 3 lanes (rounds 1-3) and 4 -- the four launch streams are four
         # hardware queues on four command-processor pipes (ops.HipOps), so four independent frames run side by side
         fps_b1_3 = throughput_at(1, 3)
-        fps_b1_4 = throughput_at(1, 4)
+        fps_b1_4 = throughput_at(1, 4, loaded=lat_loaded_1x4)
         fps_b1 = max(fps_b1_3, fps_b1_4)
         fps_by_b = {"1x3": round(fps_b1_3, 2), "1x4": round(fps_b1_4, 2)}
         for b in (3, 8):
@@ -606,9 +613,25 @@ def run_rank(args):
                        "fps_of_the_instrumented_run": timed["fps"]}
         except Exception as e:  # reporting only
             in_situ = {"error": f"{type(e).__name__}: {e}"}
+    # ---- the same fraction from the committed rocprofv3 kernel trace of one eager single-stream pass, every layer a launch of its
+    #      own (scripts/layer_table.sh): sum of the conv family's FLOP / sum of its kernel nanoseconds, reducers included -- a
+    #      constant of the committed profile, reproducible from profiles/ alone
+    frac_trace = trace_src = None
+    for name in ("round6_layer_table_batch%d.txt" % B, "round5f_layer_table_batch%d.txt" % B):
+        lt = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(lt):
+            try:
+                import ast
+
+                conv_ms = float(ast.literal_eval(open(lt).read().splitlines()[1])["conv"])
+                frac_trace = round(cg["flops"] / (conv_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+                trace_src = f"profiles/{name}: conv family {conv_ms} ms of kernels per pass (rocprofv3 --kernel-trace, reducers included)"
+                break
+            except Exception:
+                pass
     roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv/linear, all shapes of one frame)",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "frac_trace": frac_trace, "frac_trace_source": trace_src, "traffic": traffic,
                 "traffic_source": "profiles/pmc_conv_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/collect_profiles.sh; "
                                   "a constant of the committed profile, not measured in this run)",
                 "launches_per_pass": cg["launches"], "frames_per_pass": B, "avg_launch_us": round(cg_ms * 1e3 / max(cg["launches"], 1), 2),
@@ -624,20 +647,23 @@ def run_rank(args):
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "value_long": round(fps_long, 3), "value_long_seconds": round(dt_long, 2),
         "vs_baseline": None, "dtype": "f16 (fp32 accumulate)", "data": "synthetic", "ranks_seen": ranks_seen,
-        "config": {"workload": "SD1.5 512x512 LCM 4-step img2img, batch=1 per frame (each frame denoised independently), "
-                               "ControlNet-canny + TAESD (BASELINE configs[1], reference-faithful: the reference always "
-                               "runs ControlNet); frames of the stream are coalesced frames_per_launch at a time",
+        "config": {"workload": f"{B} frames per launch x {len(engines)} launch lanes in flight (a stream's independent frames coalesced along GEMM M; "
+                               "the batch=1-per-launch figures of the same run are fps_one_frame_per_launch and p50_latency_ms) of "
+                               "SD1.5 512x512 LCM 4-step img2img, every frame denoised independently, ControlNet-canny + TAESD "
+                               "(BASELINE configs[1], reference-faithful: the reference always runs ControlNet)",
                    "frames_per_rank": args.steps, "sharding": f"round-robin frames over {world} GPU(s)",
                    "frames_per_launch": B, "launches_in_flight_per_gpu": len(engines),
                    "timesteps": plan["timesteps"],
                    # kernels one replay issues (Engine.launches_by_kind: reducers and second GroupNorm kernels counted, a pair / group of
                    # calls sharing a grid once): the timed program runs the one-stream form (lanes >= 3), a lone frame the two-stream form
                    "kernel_launches_per_graph_replay": launches_B["one_stream_form" if len(engines) >= 3 else "two_stream_form"],
-                   "kernel_launches_per_single_frame_graph": launches_1["one_stream_form"],
+                   # (p50_latency_ms is a lone frame in the two-stream form; 1 x 4 runs the one-stream form: kernel_launches_by_form)
+                   "kernel_launches_per_single_frame_graph": launches_1["two_stream_form"],
                    "kernel_launches_by_form": {"frames_per_launch_%d" % B: launches_B, "one_frame": launches_1},
                    "recorded_ops": {"frames_per_launch_%d" % B: plan["n_ops"], "one_frame": plan1["n_ops"]}},
         "p50_latency_ms": round(p50, 3),
         "p50_latency_ms_under_load": round(statistics.median(lat_loaded), 3) if lat_loaded else None,
+        "p50_latency_ms_under_load_one_frame_per_launch_x4": round(statistics.median(lat_loaded_1x4), 3) if lat_loaded_1x4 else None,
         "fps_one_frame_per_launch": round(fps_b1, 3) if fps_b1 else None,
         "fps_by_frames_per_launch_x_launches_in_flight": fps_by_b or None,
         "fps_end_to_end": round(fps_e2e, 3) if fps_e2e else None,

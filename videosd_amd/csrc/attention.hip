@@ -71,7 +71,7 @@ __device__ __forceinline__ float xhalf_max(float x) {  // max over the two half-
 }
 
 // (Round 4's two experiment bodies -- the PV MFMAs woven into the exponentials, -DVSD_ATTN_WEAVE, and a forced fourth wave per SIMD,
-//  -DVSD_ATTN_WAVES -- measured -2 ... -5 % / +60 % and left this file in round 5: scripts/attic/attention_weave.inc keeps the woven
+//  -DVSD_ATTN_WAVES -- measured -2 ... -5 % / +60 % and left this file in round 5: docs/dropped_experiments.patch (attention_weave.inc) keeps the woven
 //  body, profiles/round4_attention_weave.txt the ISA listing and the numbers.  Round 5 looked at the VALU stream itself
 //  (profiles/round5_attention_valu.txt): per 64-key tile a wave issues 33 v_sub + 33 v_exp + 17 v_max3 + 16 v_cvt_pk; the scale is
 //  already folded into Q, the row sums already come out of the PV MFMA (the ones row below), O is already rescaled only when a

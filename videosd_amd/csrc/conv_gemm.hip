@@ -97,7 +97,10 @@ static int conv_setup(vsd_ctx* ctx, const vsd_conv_desc* d, ConvLaunch& cl, bool
   p.ln_t = (const float*)d->ln_t;
   VSD_CUT_SET(p)
   const int stages = d->pipeline;
-  if (stages != 0 && (stages < 3 || stages > 7)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..7)", stages);
+  if (stages != 0 && (stages < 3 || stages > 9)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..9)", stages);
+  if (stages >= 8 && !p.fast)
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the eight-wave forms (pipelines 8, 9) exist for the buffer-load path only (Cin %% 64 == 0 per "
+                    "source, no resize)");
   const bool halo = stages == 7;
 
   if (!p.src0 || !p.w || !p.out) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: null src/weight/out");
@@ -144,9 +147,11 @@ static int conv_setup(vsd_ctx* ctx, const vsd_conv_desc* d, ConvLaunch& cl, bool
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the halo-patch form (pipeline 7) needs a 3x3 stride-1 conv, Cin %% 64 == 0 per "
                       "source, a 128- or 256-row tile and the plain epilogue");
   }
-  if (!halo && BM == 256 && (BN != 128 || !p.fast || (stages != 3 && stages != 5)))
+  if (!halo && BM == 256 && (BN != 128 || !p.fast || (stages != 3 && stages != 5 && stages < 8)))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 256x128 tile exists for the buffer-load path (Cin %% 64 == 0, no resize) "
-                    "with the 3-stage ring (pipeline 3 or 5) only");
+                    "with the 3-stage ring (pipeline 3, 5, 8 or 9) only");
+  if (stages >= 8 && BM * BN < 128 * 128)
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the eight-wave forms (pipelines 8, 9) exist for tiles of 128 x 128 and larger");
   if ((p.act & 0xff) == VSD_ACT_GEGLU) {
     if (BN != 128 || p.N % 128 || p.split_k != 1 || (!p.bias && !p.ln_part) || p.out_t)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: GEGLU needs BN=128, N %% 128 == 0, bias, no split-K");
@@ -261,8 +266,8 @@ extern "C" int vsd_conv_gemm_group(vsd_ctx* ctx, const vsd_conv_desc* descs, int
     ConvLaunch cl;
     int rc = conv_setup(ctx, &descs[i], cl, true);
     if (rc != VSD_OK) return rc;
-    if (cl.halo || cl.BM == 256 || !cl.p.fast || cl.p.generic || (cl.stages != 3 && cl.stages != 5))
-      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm_group: member %d needs a 64- / 128-row tile, pipeline 3 or 5 and the buffer-load operand "
+    if (cl.halo || cl.BM == 256 || !cl.p.fast || cl.p.generic || (cl.stages != 3 && cl.stages != 5 && cl.stages < 8))
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm_group: member %d needs a 64- / 128-row tile, pipeline 3, 5, 8 or 9 and the buffer-load operand "
                       "path (Cin %% 64 == 0 per source, no resize)", i);
     if (cl.p.split_k > 1 && !cl.p.counters) {
       size_t total = (size_t)cl.p.M * ((cl.p.N + 7) / 8);

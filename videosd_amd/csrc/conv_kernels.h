@@ -450,8 +450,24 @@ __device__ __forceinline__ void block_to_tile(const ConvParams& p, int bid, int&
 //   channel displacement is ONE scalar (the instruction's soffset, kept by an incremental scalar cursor instead of a
 //   division), an out-of-image tap turns the lane's offset into an out-of-range one (the buffer unit then writes
 //   zeros into LDS: the conv's zero padding), and the weight rows need no vector instruction at all.
-template <int BM, int BN, bool GENERIC, int STAGES, bool ILV, bool FAST>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+// NW = waves per workgroup: 4 (2 x 2, one wave per SIMD) or 8 (4 x 2, two waves per SIMD: the same tile with half the accumulators
+//   and half the LDS-DMA instructions per wave -- one wave's DMA issue / LDS wait beside its SIMD partner's MFMAs; round 6).
+template <int BM, int BN, bool GENERIC, int STAGES, bool ILV, bool FAST, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_gemm_kernel(const ConvParams p) {
+  VSD_CUT(VSD_CUT_CONV_GEMM, p.cut)
+  prefetch_kernargs();
+  WGTL_START()
+#define CONV_BID blockIdx.x
+#include "conv_gemm_body.inc"
+#undef CONV_BID
+}
+
+// the eight-wave form as a kernel of its own: two waves per SIMD is ALL it is launched for, so the register allocator may use the
+// 256 registers per lane that leaves (without the attribute it aimed lower and spilled 64 registers of the 256 x 128 tile)
+template <int BM, int BN, int STAGES, bool ILV>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_gemm8_kernel(const ConvParams p) {
+  constexpr bool GENERIC = false, FAST = true;
+  constexpr int NW = 8;
   VSD_CUT(VSD_CUT_CONV_GEMM, p.cut)
   prefetch_kernargs();
   WGTL_START()
@@ -467,8 +483,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 // not depend on each other -- the ControlNet's 13 zero-conv merges per denoising step (lcm_controlnet.py:558-577's
 // down_block_additional_residuals): 11.5 us of a lone frame each as launches of their own, measured by leaving them out.
 
-template <int BM, int BN, bool GENERIC, int STAGES, bool ILV, bool FAST>
-__global__ __launch_bounds__(256) void conv_gemm_group_kernel(const ConvGroup g) {
+template <int BM, int BN, bool GENERIC, int STAGES, bool ILV, bool FAST, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_gemm_group_kernel(const ConvGroup g) {
   int prob = 0, first = 0;
 #pragma unroll
   for (int i = 1; i < VSD_GROUP_MAX; ++i)
@@ -496,7 +512,12 @@ template <int BM, int BN>
 void launch_group(const ConvGroup& g, int grid, int stages, hipStream_t s) {
   // (buffer-load path only: every member has Cin % 64 == 0 per source and no resize; pipelines 3 / 5 = the 3-stage ring, plain /
   //  interleaved)
-  if (stages == 5) hipLaunchKernelGGL((conv_gemm_group_kernel<BM, BN, false, 3, true, true>), dim3(grid), dim3(256), 0, s, g);
+  if (stages >= 8) {
+    if constexpr (BM * BN >= 128 * 128) {
+      if (stages == 8) hipLaunchKernelGGL((conv_gemm_group_kernel<BM, BN, false, 3, false, true, 8>), dim3(grid), dim3(512), 0, s, g);
+      else hipLaunchKernelGGL((conv_gemm_group_kernel<BM, BN, false, 3, true, true, 8>), dim3(grid), dim3(512), 0, s, g);
+    }
+  } else if (stages == 5) hipLaunchKernelGGL((conv_gemm_group_kernel<BM, BN, false, 3, true, true>), dim3(grid), dim3(256), 0, s, g);
   else hipLaunchKernelGGL((conv_gemm_group_kernel<BM, BN, false, 3, false, true>), dim3(grid), dim3(256), 0, s, g);
 }
 
@@ -520,9 +541,17 @@ void launch2(const ConvParams& p, int grid, hipStream_t s) {
   else if (STAGES >= 3 && p.fast) FastLaunch<BM, BN, STAGES, ILV>::go(p, grid, s);
   else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, false, STAGES, ILV, false>), dim3(grid), dim3(256), 0, s, p);
 }
+// pipelines 8 / 9: the 3-stage ring (plain / interleaved) on EIGHT waves, buffer-load path only
+template <int BM, int BN, int STAGES = 3>
+void launch8(const ConvParams& p, int grid, int stages, hipStream_t s) {
+  if (stages == 8) hipLaunchKernelGGL((conv_gemm8_kernel<BM, BN, STAGES, false>), dim3(grid), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((conv_gemm8_kernel<BM, BN, STAGES, true>), dim3(grid), dim3(512), 0, s, p);
+}
 template <int BM, int BN>
 void launch(const ConvParams& p, int grid, int stages, hipStream_t s) {
-  if (stages == 0) launch2<BM, BN, 0, false>(p, grid, s);
+  if (stages >= 8) {
+    if constexpr (BM * BN >= 128 * 128) launch8<BM, BN>(p, grid, stages, s);  // (smaller tiles: refused by the host, conv_gemm.hip)
+  } else if (stages == 0) launch2<BM, BN, 0, false>(p, grid, s);
   else if (stages == 3) launch2<BM, BN, 3, false>(p, grid, s);
   else if (stages == 4) launch2<BM, BN, 4, false>(p, grid, s);
   else if (stages == 5) launch2<BM, BN, 3, true>(p, grid, s);

@@ -88,8 +88,6 @@ def broadcast_prompt(embeds: Optional[torch.Tensor], header: Optional[Dict[str, 
     One small header broadcast + one 118 KB payload broadcast; the only collective on the path.
     timeout (seconds): give up with a RuntimeError when a broadcast has not completed by then -- a member that died leaves
     the others here, and a prompt change must not hold their frames for the process group's own timeout (minutes)."""
-    import datetime
-
     import torch.distributed as dist
 
     keys = PROMPT_HEADER_KEYS
@@ -104,14 +102,31 @@ def broadcast_prompt(embeds: Optional[torch.Tensor], header: Optional[Dict[str, 
         if timeout is None:
             dist.broadcast(t, src=src)
         else:
-            work = dist.broadcast(t, src=src, async_op=True)
-            try:
-                done = work.wait(datetime.timedelta(seconds=float(timeout)))
-            except Exception as e:  # gloo raises on the deadline; RCCL may too
-                raise RuntimeError(f"prompt broadcast failed or timed out after {timeout} s: {e}") from None
-            if done is False:
-                raise RuntimeError(f"prompt broadcast timed out after {timeout} s")
+            _wait_with_deadline(dist.broadcast(t, src=src, async_op=True), float(timeout))
     return buf, {k: float(v) for k, v in zip(keys, hdr.tolist())}
+
+
+def _wait_with_deadline(work, timeout: float, poll_s: float = 0.0005):
+    """Wait for an async collective against a HOST clock.  `Work.wait(timedelta)` is not a deadline on every backend: gloo raises
+    when it passes, ProcessGroupNCCL (RCCL) only makes the current stream wait for the collective's stream unless blocking-wait
+    mode is on -- the call returns at once and a broadcast whose peer is gone would surface at the next device synchronisation,
+    minutes later.  `is_completed()` is an event query on RCCL and a flag on gloo: poll it, give up with a
+    RuntimeError at the deadline (the caller abandons the group), and only then `wait()` -- which now returns at once and leaves the
+    stream ordered after the collective (RCCL) / rethrows the collective's own error (gloo)."""
+    t_end = time.monotonic() + timeout
+    while True:
+        try:
+            if work.is_completed():
+                break
+        except Exception as e:  # a failed collective: the backend raises from the query
+            raise RuntimeError(f"prompt broadcast failed: {e}") from None
+        if time.monotonic() >= t_end:
+            raise RuntimeError(f"prompt broadcast timed out after {timeout} s")
+        time.sleep(poll_s)
+    try:
+        work.wait()
+    except Exception as e:
+        raise RuntimeError(f"prompt broadcast failed: {e}") from None
 
 
 def prompt_key(prompt):
@@ -339,7 +354,9 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
         nonlocal epoch
         epoch += 1
         key = prompt_key(prompt)
-        if dist is None or world == 1 or not collective:
+        if dist is None or (world == 1 and not (group or {}).get("collective_at_world_1")) or not collective:
+            # (a group of ONE has nobody to broadcast to; `collective_at_world_1` runs the broadcast anyway: the one-GPU box's test of
+            #  the RCCL path -- communicator, device buffers, deadline wait -- tests/test_rccl_one_gpu.py)
             emb = pipe.encode_prompt(prompt)
             pipe.set_prompt_embeds(emb, key=key)
             return {"epoch": epoch, "rank": rank, "via": "local"}
@@ -381,10 +398,11 @@ def _worker_main(conn, factory: str, config: Dict[str, Any], max_batch: int = 1,
             why = f"{type(e).__name__}: {e}"
         abandon_note.update(aborted=aborted, why=None if aborted else why)
         if dev.type == "cuda" and not aborted:
-            # The abandoned broadcast stays queued and the backend's watchdog would take THIS (healthy) worker down when the group
-            # timeout passes: with no abort available the only safeguard left is to tell the watchdog not to (read when the
-            # watchdog fires, so setting it now is in time), and to say what happened.
-            os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"] = "0"
+            # The abandoned broadcast stays queued and the backend's watchdog will take THIS worker down when the group timeout
+            # passes (ProcessGroupNCCL reads TORCH_NCCL_ASYNC_ERROR_HANDLING once, in its constructor: nothing set here could stand
+            # it down -- ADVICE r5).  Say so: the note travels with the failed sync's reply and the dispatcher's metrics, and the
+            # worker's death at the group timeout is then an ordinary worker fault (respawn + regroup).
+            abandon_note["watchdog"] = "will fire at the group timeout"
             print(json.dumps({"kind": "worker", "rank": rank, "event": "abandon_group_without_abort", "why": why}), file=sys.stderr, flush=True)
         try:
             d.destroy_process_group()
@@ -961,7 +979,7 @@ class RemotePipeline:
 
 def spawn_workers(n: int, factory: str = "videosd_amd.pipeline:VideoSDPipeline", backend: Optional[str] = "auto",
                   devices: Optional[List[int]] = None, sync_timeout: float = 5.0, warm_options: Optional[Dict[str, Any]] = None,
-                  group_timeout: float = 120.0, **kwargs) -> List[RemotePipeline]:
+                  group_timeout: float = 120.0, collective_at_world_1: bool = False, **kwargs) -> List[RemotePipeline]:
     """The reference's `for i in range(gpu_num): pipelines[i] = VideoSDPipeline.remote(**config)` (server.py:317-321):
     N worker processes, worker i on GPU `devices[i]` (default i), all in ONE process group so that a new prompt is one
     RCCL broadcast from rank 0 (`backend` "nccl" = RCCL over xGMI on the GPU box; "gloo" for CPU tests; None: no group,
@@ -973,15 +991,16 @@ def spawn_workers(n: int, factory: str = "videosd_amd.pipeline:VideoSDPipeline",
     frame's bits do not depend on the rank it lands on; no frame of the stream pays for a `prepare`."""
     if backend == "auto":
         backend = "nccl" if torch.cuda.device_count() >= n and n > 1 else None
-    if n == 1:
-        backend = None
+    if n == 1 and not collective_at_world_1:
+        backend = None  # (a group of one has nobody to broadcast to; collective_at_world_1: form it and broadcast anyway -- the
+        #                  one-GPU box's way to run the RCCL path: tests/test_rccl_one_gpu.py)
     port = free_port() if backend else None
     devices = devices if devices is not None else list(range(n))
     ws = []
     try:
         for i in range(n):
             grp = {"rank": i, "world": n, "port": port, "backend": backend, "sync_timeout": float(sync_timeout),
-                   "timeout": float(group_timeout)} if backend else None
+                   "timeout": float(group_timeout), "collective_at_world_1": bool(collective_at_world_1)} if backend else None
             ws.append(RemotePipeline(factory=factory, group=grp, wait=False, device=devices[i], **kwargs))
         for w in ws:
             w.wait_ready()

@@ -159,6 +159,7 @@ class HipOps:
         self.one_launch_bias_us = float(_os.environ.get("VSD_ONE_LAUNCH_BIAS_US", "0.5"))  # tune_conv: see there
         self.no_halo = bool(__import__("os").environ.get("VSD_NO_HALO"))  # debugging: run halo-tuned shapes on the generic ring
         self.default_pipeline = 3
+        self.no_w8 = bool(_os.environ.get("VSD_NO_W8"))  # (development: keep the eight-wave conv forms out of the tuner)
         with torch.cuda.stream(self.stream):
             self._counters = [torch.zeros(L.SPLITK_MAX_TILES, dtype=torch.int32, device=self.device) for _ in range(2)]
         with torch.cuda.stream(self.stream):
@@ -416,7 +417,7 @@ class HipOps:
 
     # ---- several independent convs as ONE launch (include/vsd.h vsd_conv_gemm_group)
     GROUP_FORMS = [(L.TILE_64x64, 3), (L.TILE_64x64, 5), (L.TILE_64x128, 3), (L.TILE_64x128, 5), (L.TILE_128x64, 3), (L.TILE_128x64, 5),
-                   (L.TILE_128x128, 3), (L.TILE_128x128, 5)]
+                   (L.TILE_128x128, 3), (L.TILE_128x128, 5), (L.TILE_128x128, 8), (L.TILE_128x128, 9)]
     GROUP_ALONE = -1  # tile field of a group's table entry: "these members are faster as launches of their own"
     OWN_SPLIT = "own"  # conv_group(split=...): every member at the split ITS OWN table entry has (split field 0 in the group's entry)
 
@@ -577,7 +578,7 @@ class HipOps:
             if d.pipeline == 7 or d.tile in (L.TILE_256x128, L.TILE_256x64) or (sp is not None and d.split_k != sp):
                 return None
             if sp is None:
-                self._pair_default = (int(d.tile), int(d.split_k), bool(d.counters) or d.split_k <= 1, 5 if d.pipeline == 5 else 3)
+                self._pair_default = (int(d.tile), int(d.split_k), bool(d.counters) or d.split_k <= 1, int(d.pipeline) if d.pipeline in (5, 8, 9) else 3)
             sp = int(d.split_k)
         return sp
 
@@ -628,7 +629,8 @@ class HipOps:
         wide = w.geglu or w.tile128  # epilogues that need whole 128-column tiles and no split-K
         tiles = [L.TILE_128x128, L.TILE_64x128] if wide else [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64]
         # the 256x128 tile (buffer-load path only: Cin % 64 == 0, no resize) pays when M is large (batched frames, TAESD)
-        big_ok = w.cin % 64 == 0 and (g.hi, g.wi) == (g.hs, g.ws) and g.m >= 1024
+        big_path = w.cin % 64 == 0 and (kwargs.get("c1", 0) or 0) % 64 == 0 and (g.hi, g.wi) == (g.hs, g.ws) and not self.no_w8
+        big_ok = big_path and g.m >= 1024
         if big_ok:
             tiles = tiles + [L.TILE_256x128]
 
@@ -643,7 +645,9 @@ class HipOps:
             if kwargs.get("out_t") is not None and t_col0 % bn:
                 continue
             blocks = -(-g.m // bm) * -(-w.n // bn)
-            for pl in ((3, 5) if t == L.TILE_256x128 else (0, 3, 4, 5, 6)):
+            # pipelines 8 / 9: the 3-stage ring on eight waves (two per SIMD), buffer-load path, tiles of 128 x 128 and larger
+            w8 = (8, 9) if big_path and bm * bn >= 128 * 128 else ()
+            for pl in ((3, 5) if t == L.TILE_256x128 else (0, 3, 4, 5, 6)) + w8:
                 cands.append((t, 1, False, pl))
             if halo_ok and bm == 128:  # LDS halo patch (pipeline 7); split-K (over channel blocks) = the two-kernel form
                 hblocks = g.batch * -(-g.ho // 8) * -(-g.wo // 16) * -(-w.n // bn)
@@ -658,7 +662,7 @@ class HipOps:
             for sp in (2, 3, 4, 6, 8, 12, 16, 24):
                 if sp > kt // 2 or blocks * sp > 1536:
                     break
-                for pl in ((3, 5) if t == L.TILE_256x128 else (0, 3, 5)):
+                for pl in ((3, 5) if t == L.TILE_256x128 else (0, 3, 5)) + w8:
                     if kwargs.get("rowstat_out") is None and kwargs.get("chanstat_out") is None and not w.tile128:
                         cands.append((t, sp, False, pl))
                     cands.append((t, sp, True, pl))
