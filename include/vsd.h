@@ -42,7 +42,8 @@ enum vsd_act { VSD_ACT_NONE = 0, VSD_ACT_RELU = 1, VSD_ACT_SILU = 2, VSD_ACT_GEG
 /* tile shapes of the implicit-GEMM kernel (BM x BN output tile per 256-thread workgroup) */
 enum vsd_tile { VSD_TILE_128x128 = 0, VSD_TILE_128x64 = 1, VSD_TILE_64x64 = 2, VSD_TILE_64x128 = 3,
                 VSD_TILE_256x128 = 4 /* Cin % 64 == 0, no resize, pipeline 3, 5 or 7 only */,
-                VSD_TILE_256x64 = 5 /* pipeline 7 (halo patch) only */ };
+                VSD_TILE_256x64 = 5 /* pipeline 7 (halo patch) only */,
+                VSD_TILE_256x256 = 6 /* eight waves (pipeline 8 or 9), Cin % 64 == 0, no resize, unsplit, no chanstat_out */ };
 
 /* kernel families for vsd_stage_times */
 enum vsd_family {

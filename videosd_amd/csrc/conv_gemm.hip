@@ -136,6 +136,7 @@ static int conv_setup(vsd_ctx* ctx, const vsd_conv_desc* d, ConvLaunch& cl, bool
     case VSD_TILE_64x128: BM = 64; BN = 128; break;
     case VSD_TILE_256x128: BM = 256; BN = 128; break;
     case VSD_TILE_256x64: BM = 256; BN = 64; break;
+    case VSD_TILE_256x256: BM = 256; BN = 256; break;
     default: return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: tile %d", d->tile);
   }
   if (halo) {
@@ -147,14 +148,17 @@ static int conv_setup(vsd_ctx* ctx, const vsd_conv_desc* d, ConvLaunch& cl, bool
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the halo-patch form (pipeline 7) needs a 3x3 stride-1 conv, Cin %% 64 == 0 per "
                       "source, a 128- or 256-row tile and the plain epilogue");
   }
-  if (!halo && BM == 256 && (BN != 128 || !p.fast || (stages != 3 && stages != 5 && stages < 8)))
+  if (BN == 256 && (stages < 8 || p.split_k != 1 || p.chanstat_out))
+    return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 256x256 tile exists on eight waves (pipeline 8 or 9), unsplit and without fused channel "
+                    "statistics (its epilogue runs in row bands)");
+  if (!halo && BM == 256 && BN != 256 && (BN != 128 || !p.fast || (stages != 3 && stages != 5 && stages < 8)))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 256x128 tile exists for the buffer-load path (Cin %% 64 == 0, no resize) "
                     "with the 3-stage ring (pipeline 3, 5, 8 or 9) only");
   if (stages >= 8 && BM * BN < 128 * 128)
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the eight-wave forms (pipelines 8, 9) exist for tiles of 128 x 128 and larger");
   if ((p.act & 0xff) == VSD_ACT_GEGLU) {
-    if (BN != 128 || p.N % 128 || p.split_k != 1 || (!p.bias && !p.ln_part) || p.out_t)
-      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: GEGLU needs BN=128, N %% 128 == 0, bias, no split-K");
+    if (BN % 128 || p.N % 128 || p.split_k != 1 || (!p.bias && !p.ln_part) || p.out_t)
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: GEGLU needs BN=128 or 256, N %% 128 == 0, bias, no split-K");
   }
   if ((p.act & 0xff) == VSD_ACT_SOFTMAX) {
     if (BN != 128 || halo || p.N % 128 || (p.split_k != 1 && !d->counters) || p.out_t || p.out2 || p.residual || p.rowstat_out || p.chanstat_out ||
@@ -230,6 +234,7 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   {
     LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
     if (halo) vsd_launch_conv_halo(p, BM, BN, grid, s);
+    else if (BM == 256 && BN == 256) vsd_launch_conv_256x256(p, grid, stages, s);
     else if (BM == 256) vsd_launch_conv_256x128(p, grid, stages, s);
     else if (BM == 128 && BN == 128) vsd_launch_conv_128x128(p, grid, stages, s);
     else if (BM == 128 && BN == 64) vsd_launch_conv_128x64(p, grid, stages, s);

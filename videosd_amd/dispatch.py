@@ -648,7 +648,9 @@ class _ReplyHub:
                 except (EOFError, OSError, ValueError):
                     with self._lock:
                         self._conns.pop(c, None)
-                    p._on_eof()
+                    # (reaping waits up to 5 s for a process that lingers in GPU teardown: on a thread of its own, so that the
+                    #  replies of every OTHER worker keep flowing through this one -- ADVICE r5)
+                    threading.Thread(target=p._on_eof, name="vsd-reap", daemon=True).start()
             for loop, setters in batch.items():
                 try:
                     loop.call_soon_threadsafe(_run_setters, setters)  # one wake-up of the loop for the whole batch
@@ -953,11 +955,12 @@ class RemotePipeline:
         except Exception:
             pass
         try:
-            if self._proc.is_alive():
-                self._proc.join(timeout=5)
-            if self._proc.is_alive():
-                self._proc.terminate()
-                self._proc.join(timeout=5)
+            with self._proc_lock:  # (the reply hub's reaper may be joining the same process: one waitpid at a time)
+                if self._proc.is_alive():
+                    self._proc.join(timeout=5)
+                if self._proc.is_alive():
+                    self._proc.terminate()
+                    self._proc.join(timeout=5)
         except Exception:
             pass
         self.dead = True

@@ -882,7 +882,10 @@ class Engine:
         # needs them, each followed by a named event the consuming ResnetBlock waits for.
         side = self.overlap_controlnet and self.use_side_stream
         merged = [None] * len(cn_skips)
-        if not side and self.group_merges and hasattr(self.ops, "conv_group"):
+        # (a grouped launch exists for the buffer-load operand path only: every merge's channel count a multiple of 64 -- the shipped
+        #  SD1.5 / SDXL / MINI configs; a ControlNet of other widths takes the one-by-one merges below: ADVICE r5)
+        groupable = all(c % 64 == 0 for (_s, c, _l) in cn_skips) and net.cfg.block_out_channels[-1] % 64 == 0
+        if not side and self.group_merges and groupable and hasattr(self.ops, "conv_group"):
             # The 13 merges do not depend on each other and are small (11.5 us of a lone frame each as launches of their own: leaving
             # the 12 skip merges out of a 4-step frame takes 0.55 ms off it): ONE grid per group of up to eight of them
             # (vsd_conv_gemm_group) -- first the mid block's and the deepest skips' (what the decoder needs first), then the rest.

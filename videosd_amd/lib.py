@@ -13,9 +13,9 @@ ACT_POST = 256
 SPLITK_MAX_TILES = 16384
 POOL_STREAMS = 4  # include/vsd.h VSD_POOL_STREAMS
 CONV_GROUP_MAX = 8  # include/vsd.h VSD_CONV_GROUP_MAX
-TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128, TILE_256x128, TILE_256x64 = range(6)
+TILE_128x128, TILE_128x64, TILE_64x64, TILE_64x128, TILE_256x128, TILE_256x64, TILE_256x256 = range(7)
 TILE_DIMS = {TILE_128x128: (128, 128), TILE_128x64: (128, 64), TILE_64x64: (64, 64), TILE_64x128: (64, 128),
-             TILE_256x128: (256, 128), TILE_256x64: (256, 64)}
+             TILE_256x128: (256, 128), TILE_256x64: (256, 64), TILE_256x256: (256, 256)}
 FAMILIES = ["conv_gemm", "splitk_reduce", "groupnorm", "layernorm", "attention", "elementwise"]
 
 

@@ -429,7 +429,7 @@ class HipOps:
         for a, kw in calls:
             kw = {k: v for k, v in kw.items() if k not in ("tile", "split_k", "pipeline")}
             d = self.conv(*a, _desc_only=True, **kw)
-            if d.pipeline == 7 or d.tile in (L.TILE_256x128, L.TILE_256x64):
+            if d.pipeline == 7 or d.tile in (L.TILE_256x128, L.TILE_256x64, L.TILE_256x256):
                 return None
             out.append(int(d.split_k))
         return out
@@ -575,7 +575,7 @@ class HipOps:
             if w.cin % 64 or (k.get("c1", 0) or 0) % 64 or (g.hi, g.wi) != (g.hs, g.ws) or g.ksize * g.ksize > 32:
                 return None
             d = self.conv(*a, _desc_only=True, **k)
-            if d.pipeline == 7 or d.tile in (L.TILE_256x128, L.TILE_256x64) or (sp is not None and d.split_k != sp):
+            if d.pipeline == 7 or d.tile in (L.TILE_256x128, L.TILE_256x64, L.TILE_256x256) or (sp is not None and d.split_k != sp):
                 return None
             if sp is None:
                 self._pair_default = (int(d.tile), int(d.split_k), bool(d.counters) or d.split_k <= 1, int(d.pipeline) if d.pipeline in (5, 8, 9) else 3)
@@ -629,24 +629,30 @@ class HipOps:
         wide = w.geglu or w.tile128  # epilogues that need whole 128-column tiles and no split-K
         tiles = [L.TILE_128x128, L.TILE_64x128] if wide else [L.TILE_128x128, L.TILE_128x64, L.TILE_64x128, L.TILE_64x64]
         # the 256x128 tile (buffer-load path only: Cin % 64 == 0, no resize) pays when M is large (batched frames, TAESD)
-        big_path = w.cin % 64 == 0 and (kwargs.get("c1", 0) or 0) % 64 == 0 and (g.hi, g.wi) == (g.hs, g.ws) and not self.no_w8
+        big_path = w.cin % 64 == 0 and (kwargs.get("c1", 0) or 0) % 64 == 0 and (g.hi, g.wi) == (g.hs, g.ws)
         big_ok = big_path and g.m >= 1024
         if big_ok:
             tiles = tiles + [L.TILE_256x128]
+        # the 256x256 tile (eight waves, unsplit, row-banded epilogue): least L2 -> LDS fill per FLOP; for layers with enough of both
+        # M and N to give the chip's lanes something to do (a softmax / transposed-output tile is 128 columns: not for those)
+        huge_ok = (big_path and g.m >= 1024 and w.n >= 512 and not w.tile128 and kwargs.get("out_t") is None and
+                   kwargs.get("chanstat_out") is None and not self.no_w8 and self.tune_mode == 1)
+        # (both only among the throughput-mode candidates: alone on an idle chip the eight-wave forms measure 0-40 % slower than
+        #  the four-wave ones, with four lanes busy 7-18 % faster on the wide 1 x 1 layers -- profiles/round6_w8_probe_*.txt)
 
         plain_epi = all(kwargs.get(k) is None for k in ("out2", "residual2", "out_t", "rowstat_out", "chanstat_out", "ln_part"))
         act = kwargs.get("act", L.ACT_NONE)
         halo_ok = (not wide and g.ksize == 3 and g.stride == 1 and w.cin % 64 == 0 and
                    (kwargs.get("c1", 0) or 0) % 64 == 0 and w.n % 8 == 0 and plain_epi and
                    kwargs.get("out_scale", 1.0) == 1.0 and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_SILU, L.ACT_RELU | L.ACT_POST))
-        cands = []
+        cands = [(L.TILE_256x256, 1, False, pl) for pl in (8, 9)] if huge_ok else []
         for t in tiles:
             bm, bn = L.TILE_DIMS[t]
             if kwargs.get("out_t") is not None and t_col0 % bn:
                 continue
             blocks = -(-g.m // bm) * -(-w.n // bn)
             # pipelines 8 / 9: the 3-stage ring on eight waves (two per SIMD), buffer-load path, tiles of 128 x 128 and larger
-            w8 = (8, 9) if big_path and bm * bn >= 128 * 128 else ()
+            w8 = (8, 9) if big_path and bm * bn >= 128 * 128 and not self.no_w8 and self.tune_mode == 1 else ()
             for pl in ((3, 5) if t == L.TILE_256x128 else (0, 3, 4, 5, 6)) + w8:
                 cands.append((t, 1, False, pl))
             if halo_ok and bm == 128:  # LDS halo patch (pipeline 7); split-K (over channel blocks) = the two-kernel form
@@ -690,7 +696,9 @@ class HipOps:
             if not alone:
                 raise RuntimeError("tune_conv: no candidate ran")
             cut = 2.5 * alone[0][0]
-            short = [(t, sp, ink, pl) for (us, t, sp, ink, pl) in alone if us <= cut]
+            # (the 256 x 256 tile always makes the shortlist: a handful of workgroups is slow ALONE by construction -- 2-5 x on an idle
+            #  chip -- and what it is for is the shared one)
+            short = [(t, sp, ink, pl) for (us, t, sp, ink, pl) in alone if us <= cut or (t == L.TILE_256x256 and us <= 6.0 * alone[0][0])]
             table = self._time_candidates_on_lanes(args, kw, short, reps) or alone
             self.inkernel_splitk = True
             best = table[0]
