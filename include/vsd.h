@@ -107,9 +107,13 @@ typedef struct vsd_conv_desc {
                              DMA issues interleaved between the MFMAs (single-basic-block iterations); 7 = halo patch:
                              3x3 stride-1 convs only (Cin % 64 == 0 per source, tile 128x128, 128x64, 256x128 or
                              256x64, plain epilogue): the (8+2)x(16+2) input patch of a 64-channel block is
-                             staged in LDS once and serves all nine taps.  (Round 2's forms 8 / 9 / 10 -- an 8-stage ring, a weight-streaming form
-                             for M <= 192 and a weights-resident persistent conv -- measured at parity or behind these and were removed
-                             in round 3; DESIGN.md keeps the findings.) */
+                             staged in LDS once and serves all nine taps; 8 / 9 = the 3-stage ring (plain / interleaved)
+                             on eight waves (tiles of 128x128 and larger, buffer-load path); 10 = the persistent form for
+                             3x3 stride-1 convs with Cin = Cout = 64 from one source (every conv of a TAESD block; tile
+                             256x64, unsplit, plain epilogue): weights resident in registers / LDS, one workgroup per CU
+                             walking over 16x16-pixel patches, double-buffered patch fetch, register epilogue (round 6;
+                             csrc/conv_c64.hip.  Round 2's one-wave-per-SIMD form of it measured -7 % and was removed in
+                             round 3, as were an 8-stage ring and a weight-streaming form for M <= 192). */
   void* rowstat_out;      /* optional fp32 [M][n/64][2]: per output row, (sum, sum of squares) of the fp16 outputs over
                              each 64-column group -- the LayerNorm statistics of the NEXT layer, for free */
   void* chanstat_out;     /* optional fp32 [n][2]: per output CHANNEL, (sum, sum of squares) of the fp16 outputs over all M

@@ -15,7 +15,7 @@ from videosd_amd.ops import HipOps  # noqa: E402
 
 pts = [a for a in sys.argv[1:] if "x" in a] or ["5x2", "5x3"]
 ops = HipOps(0)
-ops.load_tuning(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tuning_mi355x.json"))
+ops.load_tuning(os.environ.get("VSD_TUNING") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "tuning_mi355x.json"))
 wu = W.synthesize(W.unet_spec(C.SD15_UNET), "unet.", device="cuda")
 wc = W.synthesize(W.controlnet_spec(C.SD15_CONTROLNET), "cn.", device="cuda")
 wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda")

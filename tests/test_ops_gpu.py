@@ -1393,6 +1393,65 @@ def test_conv3x3_halo_patch(ops, h, w, c0, c1, cout, tile, split, act):
         assert int(ops._counters[0].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("B,hs,ws,up,act,res", [(1, 64, 64, None, 1, False), (1, 64, 64, None, 1 | 256, True), (3, 32, 48, None, 0, True),
+                                                 (2, 27, 45, None, 2, False), (1, 16, 16, (32, 32), 0, False), (2, 14, 24, (27, 48), 1, False),
+                                                 (5, 128, 128, None, 1 | 256, True), (1, 7, 5, None, 1, True)])
+def test_persistent_64_channel_conv_matches_fp32_and_the_halo_forms_bits(ops, B, hs, ws, up, act, res):
+    """pipeline 10 (csrc/conv_c64.hip): every conv of a TAESD block (3x3, 64 -> 64 channels; lcm_controlnet.py:299, 594) as one
+    persistent launch -- weights resident, 16x16-pixel patches through two LDS buffers, register epilogue.  Against fp32 torch at the
+    plain tolerances and bit for bit against the halo-patch form (same sums in the same order); patches hanging over the image edge,
+    several images per launch (a workgroup walks from one image into the next), the folded 2x nearest upsample of the decoder,
+    bias / ReLU / SiLU / residual / ReLU after the residual, more patches than workgroups (5 x 128 x 128: 320 patches on 256 CUs)."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    c = 64
+    xs = rnd(B, c, hs, ws, seed=1)
+    wt = rnd(c, c, 3, 3, seed=2, scale=(c * 9) ** -0.5)
+    bias = rnd(c, seed=3, scale=0.1)
+    pw = ops.to_device_pack(pack_conv(wt, bias))
+    g = Geom.conv(hs, ws, up_to=up, batch=B)
+    x = xs.permute(0, 2, 3, 1).reshape(B * hs * ws, c).contiguous().cuda()
+    r = rnd(g.m, c, seed=5) if res else None
+    outs = []
+    for pipeline in (10, 7):
+        out = torch.full((g.m + 16, c), 7.0, dtype=torch.float16, device="cuda")  # (rows past M: must stay as they are)
+        ops.conv(x, None, g, pw, out[:g.m], residual=None if r is None else r.cuda(), act=act, tile=5, split_k=1, pipeline=pipeline)
+        ops.synchronize()
+        assert bool((out[g.m:] == 7.0).all())
+        outs.append(out[:g.m].cpu())
+    xin = xs.float() if up is None else F.interpolate(xs.float(), size=up, mode="nearest")
+    ref = F.conv2d(xin, wt.float(), bias.float(), padding=1)
+    if (act & 255) == 1 and not act & 256:
+        ref = F.relu(ref)
+    if (act & 255) == 2:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1).reshape(g.m, c)
+    if res:
+        ref = ref + r.float()
+    if act & 256:
+        ref = F.relu(ref)
+    check(outs[0], ref, f"persistent 64-channel conv B={B} {hs}x{ws} up={up} act={act}")
+    assert torch.equal(outs[0], outs[1]), "pipeline 10 differs from the halo-patch form"
+
+
+def test_persistent_64_channel_form_is_refused_for_other_layers(ops):
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    pw = ops.to_device_pack(pack_conv(rnd(128, 64, 3, 3, seed=1, scale=0.05), rnd(128, seed=2)))
+    x = rnd(256, 64, seed=3).cuda()
+    out = torch.zeros(256, 128, dtype=torch.float16, device="cuda")
+    # through HipOps the call falls back to the halo-patch form (the safety net for shared table entries) ...
+    ops.conv(x, None, Geom.conv(16, 16), pw, out, tile=5, split_k=1, pipeline=10)
+    ops.synchronize()
+    # ... the C entry point itself refuses it
+    d = ops.conv(x, None, Geom.conv(16, 16), pw, out, tile=5, split_k=1, pipeline=7, _desc_only=True)
+    d.pipeline = 10
+    with pytest.raises(RuntimeError, match="pipeline 10"):
+        ops.ctx.call("vsd_conv_gemm", __import__("ctypes").byref(d), ops.s)
+
+
 @pytest.mark.parametrize("hs,ws,up,tile,split", [(8, 8, (16, 16), 1, 1), (14, 24, (27, 48), 5, 2), (16, 16, (32, 32), 0, 1)])
 def test_conv3x3_halo_patch_with_folded_upsample(ops, hs, ws, up, tile, split):
     cin, cout = 128, 64

@@ -19,7 +19,7 @@ extern "C" void vsd_cut_set(void* buf) { g_cut = (unsigned long long*)buf; }
 struct ConvLaunch {
   ConvParams p;
   int BM, BN, grid, stages;
-  bool halo;
+  bool halo, c64;
 };
 
 // argument checks + everything the host derives from a descriptor (shared by vsd_conv_gemm and vsd_conv_gemm_group)
@@ -97,11 +97,12 @@ static int conv_setup(vsd_ctx* ctx, const vsd_conv_desc* d, ConvLaunch& cl, bool
   p.ln_t = (const float*)d->ln_t;
   VSD_CUT_SET(p)
   const int stages = d->pipeline;
-  if (stages != 0 && (stages < 3 || stages > 9)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..9)", stages);
+  if (stages != 0 && (stages < 3 || stages > 10)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..10)", stages);
   if (stages >= 8 && !p.fast)
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the eight-wave forms (pipelines 8, 9) exist for the buffer-load path only (Cin %% 64 == 0 per "
                     "source, no resize)");
-  const bool halo = stages == 7;
+  const bool c64 = stages == 10;  // the persistent 64 -> 64 channel form (conv_c64.hip): patches as the halo form's 16 x 16
+  const bool halo = stages == 7 || c64;
 
   if (!p.src0 || !p.w || !p.out) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: null src/weight/out");
   if (p.M <= 0 || p.N <= 0) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: empty problem M=%d N=%d", p.M, p.N);
@@ -147,6 +148,11 @@ static int conv_setup(vsd_ctx* ctx, const vsd_conv_desc* d, ConvLaunch& cl, bool
     if (!p.halo_ok || p.ksize != 3 || p.stride != 1 || p.pad != 1 || BM < 128 || p.N % 8 || p.c0 % 64 || p.c1 % 64 || !simple_epi)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the halo-patch form (pipeline 7) needs a 3x3 stride-1 conv, Cin %% 64 == 0 per "
                       "source, a 128- or 256-row tile and the plain epilogue");
+  }
+  if (c64) {
+    if (p.N != 64 || p.cin != 64 || p.c1 != 0 || BM != 256 || BN != 64 || p.split_k != 1 || p.ldo % 8 || (size_t)p.M * p.ldo * 2 >= 0x7fffffffull)
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the persistent 64-channel form (pipeline 10) needs Cin = Cout = 64 from one source, tile "
+                      "256x64, no split over K and an output below 2 GB");
   }
   if (BN == 256 && (stages < 8 || p.split_k != 1 || p.chanstat_out))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 256x256 tile exists on eight waves (pipeline 8 or 9), unsplit and without fused channel "
@@ -219,6 +225,8 @@ static int conv_setup(vsd_ctx* ctx, const vsd_conv_desc* d, ConvLaunch& cl, bool
   cl.grid = grid;
   cl.stages = stages;
   cl.halo = halo;
+  cl.c64 = c64;
+  if (c64 && cl.grid > ctx->num_cus) cl.grid = ctx->num_cus;  // persistent: a workgroup per CU walks over the patches
   return VSD_OK;
 }
 
@@ -233,7 +241,8 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
   const bool halo = cl.halo;
   {
     LaunchScope ls(ctx, s, VSD_FAM_CONV_GEMM, 2.0 * p.M * (double)p.N * p.K);
-    if (halo) vsd_launch_conv_halo(p, BM, BN, grid, s);
+    if (cl.c64) vsd_launch_conv_c64(p, grid, s);
+    else if (halo) vsd_launch_conv_halo(p, BM, BN, grid, s);
     else if (BM == 256 && BN == 256) vsd_launch_conv_256x256(p, grid, stages, s);
     else if (BM == 256) vsd_launch_conv_256x128(p, grid, stages, s);
     else if (BM == 128 && BN == 128) vsd_launch_conv_128x128(p, grid, stages, s);
@@ -271,7 +280,7 @@ extern "C" int vsd_conv_gemm_group(vsd_ctx* ctx, const vsd_conv_desc* descs, int
     ConvLaunch cl;
     int rc = conv_setup(ctx, &descs[i], cl, true);
     if (rc != VSD_OK) return rc;
-    if (cl.halo || cl.BM == 256 || !cl.p.fast || cl.p.generic || (cl.stages != 3 && cl.stages != 5 && cl.stages < 8))
+    if (cl.halo || cl.c64 || cl.BM == 256 || !cl.p.fast || cl.p.generic || (cl.stages != 3 && cl.stages != 5 && cl.stages < 8))
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm_group: member %d needs a 64- / 128-row tile, pipeline 3, 5, 8 or 9 and the buffer-load operand "
                       "path (Cin %% 64 == 0 per source, no resize)", i);
     if (cl.p.split_k > 1 && !cl.p.counters) {

@@ -126,6 +126,7 @@ void vsd_launch_conv_64x128(const ConvParams& p, int grid, int stages, hipStream
 void vsd_launch_conv_256x128(const ConvParams& p, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_256x256(const ConvParams& p, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_halo(const ConvParams& p, int bm, int bn, int grid, hipStream_t s);
+void vsd_launch_conv_c64(const ConvParams& p, int grid, hipStream_t s);  // conv_c64.hip: pipeline 10
 void vsd_launch_conv_group_64x64(const ConvGroup& g, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_group_64x128(const ConvGroup& g, int grid, int stages, hipStream_t s);
 void vsd_launch_conv_group_128x64(const ConvGroup& g, int grid, int stages, hipStream_t s);

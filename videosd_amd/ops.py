@@ -159,6 +159,7 @@ class HipOps:
         self.one_launch_bias_us = float(_os.environ.get("VSD_ONE_LAUNCH_BIAS_US", "0.5"))  # tune_conv: see there
         self.no_halo = bool(__import__("os").environ.get("VSD_NO_HALO"))  # debugging: run halo-tuned shapes on the generic ring
         self.default_pipeline = 3
+        self.no_c64 = bool(_os.environ.get("VSD_NO_C64"))  # (development: keep the persistent 64-channel conv form out of the tuner / the plans)
         self.no_w8 = bool(_os.environ.get("VSD_NO_W8"))  # (development: keep the eight-wave conv forms out of the tuner)
         with torch.cuda.stream(self.stream):
             self._counters = [torch.zeros(L.SPLITK_MAX_TILES, dtype=torch.int32, device=self.device) for _ in range(2)]
@@ -365,6 +366,9 @@ class HipOps:
         split_k = split_k or 1
         if w.tile128:
             inkernel = True  # (the tile softmax runs in the reducing workgroup's epilogue)
+        if pipeline == 10 and (self.no_c64 or out_scale_dev is not None or w.n != 64 or w.cin != 64 or c1 or
+                               not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part)):
+            pipeline, tile, split_k = 7, L.TILE_256x64, 1  # (safety net, as below: an entry shared by a call the persistent form cannot take)
         if pipeline == 7 and (self.no_halo or out_scale_dev is not None or
                               not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out,
                                                      chanstat_out, ln_part)):
@@ -682,6 +686,9 @@ class HipOps:
                     cands.append((t, sp, False, 7))
                     if sp > 1 and hblocks <= L.SPLITK_MAX_TILES:
                         cands.append((t, sp, True, 7))
+        # the persistent 64 -> 64 channel form (csrc/conv_c64.hip, pipeline 10): TAESD's block convs
+        if halo_ok and w.n == 64 and w.cin == 64 and not (kwargs.get("c1", 0) or 0) and not self.no_c64:
+            cands.append((L.TILE_256x64, 1, False, 10))
         kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline")}
         table = []
         saved = self.tile_override.pop(key, None)
