@@ -51,10 +51,10 @@ enum vsd_family {
   VSD_FAM_ATTENTION = 4, VSD_FAM_ELEMENTWISE = 5, VSD_FAM_COUNT = 6
 };
 
-/* Version of this interface (bumped whenever a struct grows or an entry point is added; round 3 = 3, round 4 = 4, round 5 = 5: pipeline 8 -- the stream-K form -- left the library) and the size in
+/* Version of this interface (bumped whenever a struct grows or an entry point is added; round 3 = 3, round 4 = 4, round 5 = 5: pipeline 8 -- the stream-K form -- left the library; round 6 = 6: pipelines 8 / 9 / 10, vsd_groupnorm_launches) and the size in
  * bytes of vsd_conv_desc as the LIBRARY was built: a caller compares both with its own header before the first call
  * (videosd_amd/lib.py does) instead of passing a short struct to a stale libvsd.so. */
-#define VSD_VERSION 5
+#define VSD_VERSION 6
 int vsd_version(void);
 int vsd_conv_desc_size(void);
 
@@ -189,6 +189,9 @@ int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int 
 int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int batch, int groups,
                           float eps, const void* gamma, const void* beta, int silu, void* out, void* workspace,
                           void* stream);
+/* kernel launches vsd_groupnorm_batched issues for a shape: 1 (one workgroup per (image, group): small images) or 2 (statistics +
+ * apply); 0 for a shape it refuses.  For launch accounting (Engine.launches_by_kind): the library's own decision, not a restatement. */
+int vsd_groupnorm_launches(int c0, int c1, int hw, int batch, int groups);
 /* ---- LayerNorm over the last dimension (BasicTransformerBlock.norm1/2/3, CLIP layer norms) -------- */
 int vsd_layernorm(vsd_ctx* ctx, const void* x, int rows, int c, const void* gamma, const void* beta, float eps,
                   void* out, void* stream);

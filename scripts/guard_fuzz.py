@@ -53,11 +53,14 @@ def one_conv():
     cin = int(rng.choice([64, 128, 192, 320, 640]))
     cout = int(rng.choice([8, 24, 64, 72, 136, 200, 320]))
     tile = int(rng.choice([0, 1, 2, 3, 4, 5]))
-    pipeline = int(rng.choice([0, 3, 4, 5, 6, 7, 8]))
+    pipeline = int(rng.choice([0, 3, 4, 5, 6, 7, 8, 10]))
     split = int(rng.choice([1, 1, 2, 3, 5]))
     inkernel = bool(rng.random() < 0.5)
     act = int(rng.choice([0, 1, 2, 4, 6]))
     use_res = bool(rng.random() < 0.5)
+    if pipeline == 10:  # the persistent 64 -> 64 channel form (csrc/conv_c64.hip): the layer it exists for, on ragged images
+        ks, stride, cin, cout, tile, split, act = 3, 1, 64, 64, 5, 1, int(rng.choice([0, 1, 2]))
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 70))
     x = rnd(b, cin, h, w)
     wt = rnd(cout, cin, ks, ks, scale=(cin * ks * ks) ** -0.5)
     bias = rnd(cout, scale=0.1)

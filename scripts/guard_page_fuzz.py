@@ -85,10 +85,13 @@ def one_conv():
     b = int(rng.choice([1, 1, 2, 3]))
     cin = int(rng.choice([64, 128, 192, 320, 640]))
     cout = int(rng.choice([8, 24, 64, 72, 136, 200, 320]))
-    tile, pipeline = int(rng.choice([0, 1, 2, 3, 4, 5])), int(rng.choice([0, 3, 4, 5, 6, 7, 8]))
+    tile, pipeline = int(rng.choice([0, 1, 2, 3, 4, 5])), int(rng.choice([0, 3, 4, 5, 6, 7, 8, 10]))
     split, inkernel = int(rng.choice([1, 1, 2, 3, 5])), bool(rng.random() < 0.5)
     act, use_res = int(rng.choice([0, 1, 2, 4, 6])), bool(rng.random() < 0.5)
-    up = ks == 3 and stride == 1 and rng.random() < 0.2
+    if pipeline == 10:  # the persistent 64 -> 64 channel form (csrc/conv_c64.hip): the layer it exists for, on ragged images
+        ks, stride, cin, cout, tile, split, act = 3, 1, 64, 64, 5, 1, int(rng.choice([0, 1, 2]))
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+    up = ks == 3 and stride == 1 and rng.random() < (0.4 if pipeline == 10 else 0.2)
     g = Geom.conv(h, w, ksize=ks, stride=stride, batch=b, up_to=(2 * h, 2 * w) if up else None)
     split = min(split, (cin * ks * ks + 63) // 64)
     desc = f"conv {b}x{h}x{w} up {up} {cin}->{cout} ks{ks} s{stride} tile {tile} pipeline {pipeline} split {split} inkernel {inkernel} act {act} res {use_res}"

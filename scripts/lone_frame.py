@@ -29,7 +29,7 @@ retune = "--retune" in argv
 use_cn = "--no-cn" not in argv
 tag = argv[argv.index("--tag") + 1] if "--tag" in argv else ""
 save = argv[argv.index("--save-tuning") + 1] if "--save-tuning" in argv else None
-table = os.path.join(ROOT, "profiles", "tuning_mi355x.json")
+table = os.environ.get("VSD_TUNING") or os.path.join(ROOT, "profiles", "tuning_mi355x.json")
 
 ops = HipOps(0)
 n_loaded = ops.load_tuning(table)

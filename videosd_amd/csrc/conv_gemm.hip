@@ -98,7 +98,7 @@ static int conv_setup(vsd_ctx* ctx, const vsd_conv_desc* d, ConvLaunch& cl, bool
   VSD_CUT_SET(p)
   const int stages = d->pipeline;
   if (stages != 0 && (stages < 3 || stages > 10)) return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: pipeline %d (0, 3..10)", stages);
-  if (stages >= 8 && !p.fast)
+  if ((stages == 8 || stages == 9) && !p.fast)
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the eight-wave forms (pipelines 8, 9) exist for the buffer-load path only (Cin %% 64 == 0 per "
                     "source, no resize)");
   const bool c64 = stages == 10;  // the persistent 64 -> 64 channel form (conv_c64.hip): patches as the halo form's 16 x 16
@@ -160,7 +160,7 @@ static int conv_setup(vsd_ctx* ctx, const vsd_conv_desc* d, ConvLaunch& cl, bool
   if (!halo && BM == 256 && BN != 256 && (BN != 128 || !p.fast || (stages != 3 && stages != 5 && stages < 8)))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 256x128 tile exists for the buffer-load path (Cin %% 64 == 0, no resize) "
                     "with the 3-stage ring (pipeline 3, 5, 8 or 9) only");
-  if (stages >= 8 && BM * BN < 128 * 128)
+  if ((stages == 8 || stages == 9) && BM * BN < 128 * 128)
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the eight-wave forms (pipelines 8, 9) exist for tiles of 128 x 128 and larger");
   if ((p.act & 0xff) == VSD_ACT_GEGLU) {
     if (BN % 128 || p.N % 128 || p.split_k != 1 || (!p.bias && !p.ln_part) || p.out_t)

@@ -423,6 +423,16 @@ extern "C" int64_t vsd_groupnorm_workspace_bytes(int hw, int c, int groups) {
   return (int64_t)GN_MAX_PART * groups * 2 * sizeof(float);
 }
 
+// kernel launches vsd_groupnorm_batched issues for this shape (1: one workgroup per (image, group); 2: statistics + apply)
+extern "C" int vsd_groupnorm_launches(int c0, int c1, int hw, int batch, int groups) {
+  GnParams p;
+  memset(&p, 0, sizeof p);
+  p.c0 = c0; p.c1 = c1; p.c = c0 + c1;
+  if (hw <= 0 || groups <= 0 || batch < 1 || p.c0 % 8 || p.c1 % 8 || p.c % groups) return 0;
+  p.c8 = p.c / 8; p.hw = hw; p.groups = groups; p.cpg = p.c / groups; p.batch = batch;
+  return gn_try_fused(nullptr, p, batch, nullptr, true) ? 1 : 2;
+}
+
 extern "C" int vsd_groupnorm(vsd_ctx* ctx, const void* src0, const void* src1, int c0, int c1, int hw, int groups,
                              float eps, const void* gamma, const void* beta, int silu, void* out, void* workspace,
                              void* stream) {

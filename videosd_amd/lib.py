@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # VSD_LIB: another build of the same sources (development: the instrumented libvsd_tl.so of build.build_timeline)
 LIB_PATH = os.environ.get("VSD_LIB") or os.path.join(HERE, "libvsd.so")
 
-VERSION = 5  # include/vsd.h VSD_VERSION
+VERSION = 6  # include/vsd.h VSD_VERSION
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GEGLU, ACT_QUICKGELU, ACT_SOFTMAX, ACT_GELU = range(7)
 ACT_POST = 256
 SPLITK_MAX_TILES = 16384
@@ -77,6 +77,7 @@ SIGNATURES = {
                                         C.c_int, C.c_void_p]),
     "vsd_groupnorm_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsd_groupnorm_launches": (C.c_int, [C.c_int] * 5),
     "vsd_preprocess_rgb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vsd_sobel_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "vsd_sobel_control": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,

@@ -879,6 +879,10 @@ class HipOps:
                       self._p(ff1.weight_frag), self._p(ff1.ln_s), self._p(ff1.ln_t), ln_eps, self._p(ff2.weight_frag),
                       self._p(ff2.bias), self._p(proj.weight_frag), self._p(proj.bias), self._p(out), self.s)
 
+    def groupnorm_launches(self, c0, c1, hw, groups, batch=1) -> int:
+        """kernel launches one `groupnorm` call issues (the library's own decision: csrc/norm.hip)"""
+        return int(self.ctx.lib.vsd_groupnorm_launches(c0, c1, hw, max(1, batch), groups))
+
     def groupnorm(self, src0, src1, c0, c1, hw, groups, eps, gamma, beta, silu, out, batch=1):
         ws = self.workspace("gn", max(1, batch) * int(self.ctx.lib.vsd_groupnorm_workspace_bytes(hw, c0 + c1, groups)))
         if batch > 1:
