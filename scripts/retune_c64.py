@@ -19,7 +19,7 @@ out = sys.argv[1] if len(sys.argv) > 1 else path
 ops = HipOps(0)
 ops.load_tuning(path)
 old = dict(ops.tile_override)
-is_c64 = lambda k: k[0] != "group" and k[1] == 64 and k[2] == 576 and k[3] == 3 and k[4] == 1  # noqa: E731  (M, N, Kp, ksize, stride, ...)
+is_c64 = lambda k: k[0] != "group" and (k[1] == 64 or k[1] <= 8) and k[2] == 576 and k[3] == 3 and k[4] == 1  # noqa: E731  (M, N, Kp, ksize, stride, ...)
 drop = [k for k in ops.tile_override if is_c64(k)]
 for k in drop:
     del ops.tile_override[k]

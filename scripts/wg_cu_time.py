@@ -75,7 +75,7 @@ def family_flops(e):
         if name == "conv":
             g, w = a[2], a[3]
             ent = e.ops.tile_override.get(e.ops.conv_key_of(g, w, k))
-            halo = ent is not None and ent[3] == 7
+            halo = ent is not None and ent[3] in (7, 10)
             fl["conv_halo" if halo else "conv_gemm"] += 2.0 * g.m * w.n * w.k
         elif name == "attention":
             sq, sk, heads, d = a[8], a[9], a[10], a[11]

@@ -1435,6 +1435,38 @@ def test_persistent_64_channel_conv_matches_fp32_and_the_halo_forms_bits(ops, B,
     assert torch.equal(outs[0], outs[1]), "pipeline 10 differs from the halo-patch form"
 
 
+@pytest.mark.parametrize("B,h,w,n,act,up", [(1, 64, 64, 3, 0, None), (2, 37, 50, 4, 0, None), (5, 128, 128, 3, 0, None), (1, 16, 24, 8, 1, (32, 48)),
+                                            (1, 9, 9, 3, 2, None)])
+def test_persistent_64_channel_conv_with_a_thin_output(ops, B, h, w, n, act, up):
+    """pipeline 10's form for Cout <= 8 into 8-wide rows (TAESD's last decoder conv 64 -> 3 at full image size, the encoder's 64 -> 4
+    projection): against fp32 torch and bit for bit against the GEMM-form tile on the real channels; the padding channels of a row are
+    written as zeros, rows past M stay untouched."""
+    from videosd_amd.ops import Geom
+    from videosd_amd.packing import pack_conv
+
+    c = 64
+    xs = rnd(B, c, h, w, seed=1)
+    wt = rnd(n, c, 3, 3, seed=2, scale=(c * 9) ** -0.5)
+    bias = rnd(n, seed=3, scale=0.1)
+    pw = ops.to_device_pack(pack_conv(wt, bias))
+    g = Geom.conv(h, w, up_to=up, batch=B)
+    x = xs.permute(0, 2, 3, 1).reshape(B * h * w, c).contiguous().cuda()
+    outs = []
+    for tile, pipeline in ((5, 10), (2, 3)):
+        out = torch.full((g.m + 16, 8), 7.0, dtype=torch.float16, device="cuda")
+        ops.conv(x, None, g, pw, out[:g.m], ldo=8, act=act, tile=tile, split_k=1, pipeline=pipeline)
+        ops.synchronize()
+        assert bool((out[g.m:] == 7.0).all())
+        outs.append(out[:g.m].cpu())
+    assert bool((outs[0][:, n:] == 0).all())
+    xin = xs.float() if up is None else F.interpolate(xs.float(), size=up, mode="nearest")
+    ref = F.conv2d(xin, wt.float(), bias.float(), padding=1)
+    ref = F.relu(ref) if act == 1 else (F.silu(ref) if act == 2 else ref)
+    ref = ref.permute(0, 2, 3, 1).reshape(g.m, n)
+    check(outs[0][:, :n], ref, f"thin persistent conv B={B} {h}x{w} n={n} act={act} up={up}")
+    assert torch.equal(outs[0][:, :n], outs[1][:, :n]), "pipeline 10 (thin) differs from the GEMM-form tile"
+
+
 def test_persistent_64_channel_form_is_refused_for_other_layers(ops):
     from videosd_amd.ops import Geom
     from videosd_amd.packing import pack_conv

@@ -205,6 +205,122 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef C64_ISSUE
 }
 
+// ---- the same for Cout <= 8 (TAESD's last decoder conv, 64 -> 3 channels at full image size: lcm_controlnet.py:594; its encoder's
+// 64 -> 4 projection): HBM-bound on reading the 64-channel input once.  Eight waves of two patch rows each, ONE weight fragment (output
+// channels 0-15, rows past Cout zero) for all 18 K steps in 72 registers; lane (pixel, q) holds channels 4 q .. 4 q + 3 and lanes
+// q < 2 store 8 bytes: the output row is 8 halfs wide (ldo = 8), channels Cout .. 7 are written as zeros.  The GEMM-form tile ran
+// this layer at 17 TFLOP/s (258 us for five 512 x 512 frames): 64 of its 64 tile columns but three are padding.
+template <int ACT>
+__global__ __launch_bounds__(512) void conv_c64_thin_kernel(const ConvParams p) {
+  VSD_CUT(VSD_CUT_CONV_HALO, p.cut)
+  prefetch_kernargs();
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C64_A_HALFS * 2];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  constexpr int OOB = (int)0x80000000;
+  constexpr int NW = C64_NW, AI = C64_AI, HS = C64_HS, PW = C64_PW, PH = C64_PH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int fp = lane & 15, fq = lane >> 4;
+  half8 wreg[18];
+  {
+    const half8 z8 = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+    const half_t* wr = p.w + (size_t)(fp < p.N ? fp : 0) * p.Kp + 8 * fq;
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+      const half8 v = *reinterpret_cast<const half8*>(wr + 32 * s);
+      wreg[s] = fp < p.N ? v : z8;
+    }
+  }
+  const int ch0 = 4 * fq;  // this lane's four output channels
+  float brv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    brv[e] = 0.f;
+    if (p.bias && ch0 + e < p.N) brv[e] += (float)p.bias[ch0 + e];
+    if (p.rowvec && ch0 + e < p.N) brv[e] += (float)p.rowvec[ch0 + e];
+  }
+  const int alc = ((lane & 7) ^ (lane >> 3)) << 4;
+  const int hxl = lane >> 3;
+  const int anr0 = (int)((size_t)p.batch * p.img_in * p.c0 * 2);
+  const int ppr = (p.wo + PW - 1) / PW, tpi = ((p.ho + PH - 1) / PH) * ppr;
+#define C64_COORDS(T_, IMG_, Y0_, X0_)                         \
+  const int IMG_ = fdiv((T_), p.fd_tpi);                       \
+  const int trem_##IMG_ = (T_) - IMG_ * tpi;                   \
+  const int prow_##IMG_ = fdiv(trem_##IMG_, p.fd_ppr);         \
+  const int Y0_ = prow_##IMG_ * PH, X0_ = (trem_##IMG_ - prow_##IMG_ * ppr) * PW;
+#define C64_ISSUE(IMG_, Y0_, X0_, BUF_)                                                                              \
+  {                                                                                                                  \
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)p.src0, 0, anr0, 0x00020000);        \
+    half_t* dst_ = reinterpret_cast<half_t*>(smem) + (BUF_) * C64_A_HALFS;                                           \
+    const int pix0_ = (IMG_) * p.img_in;                                                                             \
+    _Pragma("unroll") for (int q = 0; q < AI; ++q) {                                                                 \
+      const int j = wave_s + NW * q;                                                                                 \
+      const int hy = j / 3, hx = 8 * (j - 3 * hy) + hxl;                                                             \
+      const int y = (Y0_) - 1 + hy, x = (X0_) - 1 + hx;                                                              \
+      const bool in = (unsigned)y < (unsigned)p.hi && (unsigned)x < (unsigned)p.wi && hx < PW + 2 && hy < PH + 2;    \
+      const int sy = (int)(((unsigned)y * p.rmul_y) >> p.rshift), sx = (int)(((unsigned)x * p.rmul_x) >> p.rshift);  \
+      const int vo_ = in ? (pix0_ + sy * p.ws + sx) * (BK * 2) + alc : OOB;                                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr_t)(dst_ + 8 * j * BK), 16, vo_, 0, 0, 0);               \
+    }                                                                                                                \
+  }
+  int fb[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) fb[kx] = ((2 * wave_s) * HS + fp + kx) * (BK * 2) + ((fq ^ ((fp + kx) & 7)) << 4);
+  const int ntiles = p.tiles_m;
+  int t = blockIdx.x;
+  if (t < ntiles) {
+    C64_COORDS(t, img, y0, x0)
+    C64_ISSUE(img, y0, x0, 0)
+  }
+  const int onr = (int)((size_t)p.M * p.ldo * 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int buf = 0;
+  for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+    C64_COORDS(t, img, y0, x0)
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // (all but the previous patch's two output stores: see conv_c64_kernel)
+    __builtin_amdgcn_s_barrier();
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) {
+      C64_COORDS(tn, img2, y2, x2)
+      C64_ISSUE(img2, y2, x2, buf ^ 1)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[2];
+    acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned char* a = smem + buf * (C64_A_HALFS * 2);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const half8 xf = *reinterpret_cast<const half8*>(a + (ks ? fb[kx] ^ 64 : fb[kx]) + (i + ky) * (HS * BK * 2));
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[2 * tap + ks], xf, acc[i], 0, 0, 0);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, onr, 0x00020000);
+    const int ox = x0 + fp;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int oy = y0 + 2 * wave_s + i;
+      const bool ok = oy < p.ho && ox < p.wo && fq < 2;
+      const int mrow = img * p.hw_out + oy * p.wo + ox;
+      half4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = acc[i][e] + brv[e];
+        if (ACT == 1) x = fmaxf(x, 0.f);
+        if (ACT == 2) x = silu_f(x);
+        o[e] = (half_t)x;
+      }
+      __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o), ors, ok ? (mrow * p.ldo + ch0) * 2 : OOB, 0, 0);
+    }
+  }
+#undef C64_COORDS
+#undef C64_ISSUE
+}
+
 }  // namespace
 
 template <int ACT>
@@ -214,6 +330,12 @@ static void c64_go(const ConvParams& p, int grid, hipStream_t s) {
 }
 void vsd_launch_conv_c64(const ConvParams& p, int grid, hipStream_t s) {
   const int act = p.act & 0xff;
+  if (p.N <= 8) {  // (host checks: ldo == 8, no residual, no activation after one)
+    if (act == VSD_ACT_RELU) hipLaunchKernelGGL((conv_c64_thin_kernel<1>), dim3(grid), dim3(512), 0, s, p);
+    else if (act == VSD_ACT_SILU) hipLaunchKernelGGL((conv_c64_thin_kernel<2>), dim3(grid), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((conv_c64_thin_kernel<0>), dim3(grid), dim3(512), 0, s, p);
+    return;
+  }
   if (act == VSD_ACT_RELU && (p.act & VSD_ACT_POST)) c64_go<3>(p, grid, s);
   else if (act == VSD_ACT_RELU) c64_go<1>(p, grid, s);
   else if (act == VSD_ACT_SILU) c64_go<2>(p, grid, s);

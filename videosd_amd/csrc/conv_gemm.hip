@@ -145,14 +145,15 @@ static int conv_setup(vsd_ctx* ctx, const vsd_conv_desc* d, ConvLaunch& cl, bool
                             p.out_scale == 1.0f && !p.out_scale_dev &&
                             ((p.act & 0xff) == VSD_ACT_NONE || (p.act & 0xff) == VSD_ACT_RELU || (p.act & 0xff) == VSD_ACT_SILU) &&
                             !((p.act & VSD_ACT_POST) && (p.act & 0xff) != VSD_ACT_RELU);
-    if (!p.halo_ok || p.ksize != 3 || p.stride != 1 || p.pad != 1 || BM < 128 || p.N % 8 || p.c0 % 64 || p.c1 % 64 || !simple_epi)
+    if (!p.halo_ok || p.ksize != 3 || p.stride != 1 || p.pad != 1 || BM < 128 || (p.N % 8 && !c64) || p.c0 % 64 || p.c1 % 64 || !simple_epi)
       return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the halo-patch form (pipeline 7) needs a 3x3 stride-1 conv, Cin %% 64 == 0 per "
                       "source, a 128- or 256-row tile and the plain epilogue");
   }
   if (c64) {
-    if (p.N != 64 || p.cin != 64 || p.c1 != 0 || BM != 256 || BN != 64 || p.split_k != 1 || p.ldo % 8 || (size_t)p.M * p.ldo * 2 >= 0x7fffffffull)
-      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the persistent 64-channel form (pipeline 10) needs Cin = Cout = 64 from one source, tile "
-                      "256x64, no split over K and an output below 2 GB");
+    const bool thin = p.N <= 8 && p.ldo == 8 && !p.residual && !(p.act & VSD_ACT_POST);  // (the 64 -> 3 / 64 -> 4 projections: conv_c64_thin_kernel)
+    if ((p.N != 64 && !thin) || p.cin != 64 || p.c1 != 0 || BM != 256 || BN != 64 || p.split_k != 1 || p.ldo % 8 || (size_t)p.M * p.ldo * 2 >= 0x7fffffffull)
+      return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the persistent 64-channel form (pipeline 10) needs Cin = 64 from one source, Cout = 64 (or Cout <= 8 "
+                      "with ldo = 8, no residual), tile 256x64, no split over K and an output below 2 GB");
   }
   if (BN == 256 && (stages < 8 || p.split_k != 1 || p.chanstat_out))
     return vsd_fail(ctx, VSD_ERR_ARG, "conv_gemm: the 256x256 tile exists on eight waves (pipeline 8 or 9), unsplit and without fused channel "

@@ -366,9 +366,11 @@ class HipOps:
         split_k = split_k or 1
         if w.tile128:
             inkernel = True  # (the tile softmax runs in the reducing workgroup's epilogue)
-        if pipeline == 10 and (self.no_c64 or out_scale_dev is not None or w.n != 64 or w.cin != 64 or c1 or
-                               not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part)):
-            pipeline, tile, split_k = 7, L.TILE_256x64, 1  # (safety net, as below: an entry shared by a call the persistent form cannot take)
+        if pipeline == 10 and (self.no_c64 or out_scale_dev is not None or
+                               not self._c64_call_ok(g, w, c1, act, out_scale, residual, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part,
+                                                     ldo if ldo is not None else w.n_out)):
+            # (safety net, as below: an entry shared by a call the persistent form cannot take)
+            pipeline, tile, split_k = (7, L.TILE_256x64, 1) if w.n % 8 == 0 else (3, L.TILE_64x64, 1)
         if pipeline == 7 and (self.no_halo or out_scale_dev is not None or
                               not self._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out,
                                                      chanstat_out, ln_part)):
@@ -593,6 +595,18 @@ class HipOps:
         return (plain and not w.geglu and g.ksize == 3 and g.stride == 1 and w.cin % 64 == 0 and (c1 or 0) % 64 == 0 and
                 w.n % 8 == 0 and out_scale == 1.0 and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_SILU, L.ACT_RELU | L.ACT_POST))
 
+    @classmethod
+    def _c64_call_ok(cls, g, w, c1, act, out_scale, residual, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part, ldo) -> bool:
+        """What the persistent 64-input-channel form (pipeline 10, csrc/conv_c64.hip) accepts: the halo form's layer with Cin = 64 from one
+        source and Cout = 64 -- or Cout <= 8 into 8-wide rows without a residual (TAESD's 64 -> 3 / 64 -> 4 projections)."""
+        if w.cin != 64 or c1:
+            return False
+        if w.n == 64:
+            return cls._halo_call_ok(g, w, c1, act, out_scale, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part)
+        plain = all(x is None for x in (residual, residual2, out2, out_t, rowstat_out, chanstat_out, ln_part))
+        return (w.n <= 8 and ldo == 8 and plain and not w.geglu and g.ksize == 3 and g.stride == 1 and out_scale == 1.0 and
+                act in (L.ACT_NONE, L.ACT_RELU, L.ACT_SILU))
+
     # Epilogue classes of the tuning key.  By scripts/wg_timeline.py the epilogue kind moves a workgroup's fixed cost from 1.0
     # to 4.6 us, and some classes exclude kernel forms (statistics outputs: no reducer kernel; softmax: 128-column tiles;
     # anything but the plain one: no halo-patch form) -- layers of one (M, N, K) with different epilogues get their own entry.
@@ -687,7 +701,10 @@ class HipOps:
                     if sp > 1 and hblocks <= L.SPLITK_MAX_TILES:
                         cands.append((t, sp, True, 7))
         # the persistent 64 -> 64 channel form (csrc/conv_c64.hip, pipeline 10): TAESD's block convs
-        if halo_ok and w.n == 64 and w.cin == 64 and not (kwargs.get("c1", 0) or 0) and not self.no_c64:
+        if not self.no_c64 and not wide and kwargs.get("out_scale_dev") is None and self._c64_call_ok(
+                g, w, kwargs.get("c1", 0) or 0, act, kwargs.get("out_scale", 1.0), kwargs.get("residual"), kwargs.get("residual2"), kwargs.get("out2"),
+                kwargs.get("out_t"), kwargs.get("rowstat_out"), kwargs.get("chanstat_out"), kwargs.get("ln_part"),
+                kwargs.get("ldo") if kwargs.get("ldo") is not None else w.n_out):
             cands.append((L.TILE_256x64, 1, False, 10))
         kw = {k: v for k, v in kwargs.items() if k not in ("tile", "split_k", "pipeline")}
         table = []
