@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-FAMILIES = (("conv_halo_kernel", "conv_halo"), ("conv_c64_kernel", "conv_halo"), ("conv_gemm", "conv_gemm"), ("tail_kernel", "fused_tail"), ("attention_kernel", "attention"),
+FAMILIES = (("conv_halo_kernel", "conv_halo"), ("conv_c64", "conv_halo"), ("conv_gemm", "conv_gemm"), ("tail_kernel", "fused_tail"), ("attention_kernel", "attention"),
             ("gn_", "groupnorm"), ("splitk", "splitk_reduce"), ("layernorm", "layernorm"))
 
 
@@ -47,7 +47,7 @@ n_conv = sum(1 for m in ops if m["op"] == "conv")
 alg = sum(m.get("wbytes", 0) + 2 * m["M"] * (m["K"] // (m["ks"] ** 2)) + 2 * m["M"] * m["N"] for m in ops if m["op"] == "conv")
 fetch, fname, fdur = per_dispatch(sys.argv[1], "FETCH_SIZE")
 write, wname, wdur = per_dispatch(sys.argv[2], "WRITE_SIZE")
-is_conv = lambda n: ("conv_gemm" in n and "group" not in n) or "conv_halo_kernel" in n or "conv_c64_kernel" in n  # noqa: E731
+is_conv = lambda n: ("conv_gemm" in n and "group" not in n) or "conv_halo_kernel" in n or "conv_c64" in n  # noqa: E731
 fc = [fetch[i] for i in sorted(fetch) if is_conv(fname[i])][-n_conv:]
 wc = [write[i] for i in sorted(write) if is_conv(wname[i])][-n_conv:]
 fetch_b = 2.0 * sum(fc) * 1024 / len(fc)

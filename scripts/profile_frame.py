@@ -1,6 +1,7 @@
 """Run under rocprofv3 --kernel-trace: executes eager frames of the 512x512 4-step program and writes the op
 list (shapes, tile, split) to gpurun_out/ops_<tag>.json so that scripts/analyze_trace.py can attribute
-kernel durations to layers."""
+kernel durations to layers.  --lanes: the THROUGHPUT-mode forms of every layer (what a coalesced launch on four busy lanes runs:
+the table's mode-1 entries -- larger tiles, the halo form, the eight-wave forms), here one launch at a time."""
 import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,7 +26,9 @@ ops.load_tuning(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__f
 eng.overlap_controlnet = False
 eng.twin_encoders = False  # (a table of LAYERS: the two encoders' twin layers as launches of their own)
 eng.group_shortcuts = False  # (... and a ResnetBlock's shortcut conv beside its conv1, not in its grid)
+eng.tune_for_lanes = "--lanes" in sys.argv
 eng.prepare(size, size, 4, 0.6, use_controlnet=cn, use_graph=False, batch=batch)
+ops.tune_mode = 1 if eng.tune_for_lanes else 0
 meta = []
 
 

@@ -32,9 +32,11 @@ for B, H, W, cin, cout, ks in SHAPES:
     best, table = ops.tune_conv((x, None, g, pw, out), dict(rowvec=rv))
     fl = 2.0 * g.m * cout * cin * ks * ks
     four = next((t for t in table if t[4] < 8), None)
-    eight = next((t for t in table if t[4] >= 8 and t[1] != 6), None)
+    eight = next((t for t in table if t[4] in (8, 9) and t[1] != 6), None)
+    x2 = next((t for t in table if t[4] in (11, 12)), None)
     huge = next((t for t in table if t[1] == 6), None)
     f = lambda t: "none" if t is None else f"{t[0]:7.1f} us {fl / t[0] / 1e6:5.0f} TF/s tile={t[1]} split={t[2]} ink={int(t[3])} pipe={t[4]}"  # noqa: E731
     print(f"M={g.m:6d} N={cout:5d} K={cin * ks * ks:5d} k{ks} mode{ops.tune_mode}: four {f(four)} | eight {f(eight)}"
-          f"  ({eight[0] / four[0]:.2f}) | 256x256 {f(huge)}" + (f" ({huge[0] / four[0]:.2f})" if huge else ""), flush=True)
+          f"  ({eight[0] / four[0]:.2f}) | 256x256 {f(huge)}" + (f" ({huge[0] / four[0]:.2f})" if huge else "") +
+          f" | two slots, two workgroups per CU {f(x2)}" + (f" ({x2[0] / four[0]:.2f})" if x2 else ""), flush=True)
     del pw, x, out
