@@ -51,7 +51,7 @@ enum vsd_family {
   VSD_FAM_ATTENTION = 4, VSD_FAM_ELEMENTWISE = 5, VSD_FAM_COUNT = 6
 };
 
-/* Version of this interface (bumped whenever a struct grows or an entry point is added; round 3 = 3, round 4 = 4, round 5 = 5: pipeline 8 -- the stream-K form -- left the library; round 6 = 6: pipelines 8 / 9 / 10, vsd_groupnorm_launches) and the size in
+/* Version of this interface (bumped whenever a struct grows or an entry point is added; round 3 = 3, round 4 = 4, round 5 = 5: pipeline 8 -- the stream-K form -- left the library; round 6 = 6: pipelines 8 / 9 / 10, vsd_groupnorm_launches, vsd_plan_*) and the size in
  * bytes of vsd_conv_desc as the LIBRARY was built: a caller compares both with its own header before the first call
  * (videosd_amd/lib.py does) instead of passing a short struct to a stale libvsd.so. */
 #define VSD_VERSION 6
@@ -294,6 +294,19 @@ int vsd_axpy(vsd_ctx* ctx, const void* a, const void* b, float scale, int64_t n,
 int vsd_pair_begin(vsd_ctx* ctx);
 int vsd_pair_join(vsd_ctx* ctx);
 int vsd_pair_end(vsd_ctx* ctx, int* joined_out);
+
+/* ---- a prepared frame program from a FILE (round 6; SURVEY.md section 8b's whole-frame entry points) ---------------------------
+ * The reference's seam is a Python class (videopipeline.py:75-128) and the sequencing of a frame lives in videosd_amd/engine.py; for a
+ * host without Python the engine's program is EXPORTED (videosd_amd/plan.py export_plan: every C-ABI call of the one-stream form with
+ * its arguments, device pointers as (region, offset), the bytes of weights / constants / prompt block) and replayed here.
+ * vsd_plan_load: allocate, upload, patch, replay under capture (one hipGraph); the plan is one (frame size, steps, strength, ControlNet
+ * scale, prompt, frames per launch).  vsd_plan_infer: frame(s) uint8 [batch][H][W][3] on the HOST in, the same shape out; synchronous.
+ * The result is bit for bit the Python engine's.  vsd_plan_info: dims[0..2] = H, W, frames per launch. */
+typedef struct vsd_plan vsd_plan;
+int vsd_plan_load(vsd_ctx* ctx, const char* path, vsd_plan** plan_out);
+int vsd_plan_info(vsd_ctx* ctx, vsd_plan* plan, int* dims);
+int vsd_plan_infer(vsd_ctx* ctx, vsd_plan* plan, const void* frame_u8_host, void* out_u8_host);
+void vsd_plan_free(vsd_ctx* ctx, vsd_plan* plan);
 
 /* ---- hipGraph capture / replay (reference intent: compile_model, videopipeline.py:35-47) ----------- */
 int vsd_graph_begin(vsd_ctx* ctx, void* stream);

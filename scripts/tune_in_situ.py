@@ -8,6 +8,10 @@ form Y?  For the shapes that carry the most time it tries the proxy's next-best 
 again, frames/s of a few dozen launches), keeps a change only if it is confirmed above the noise, and writes the table.
 
     python scripts/tune_in_situ.py [--batch 5] [--shapes 40] [--alts 3] [--seconds 1500] [out.json]
+
+--batch 1: the ONE-frame program (latency-mode entries, key's last field 0) on four busy lanes, with a guard: a change must also leave
+the LONE frame's latency (two-stream form, nothing else on the GPU) where it was (--guard-ms, default 0.05) -- forms that cost a
+busy chip less without costing the lone frame anything.
 """
 import json
 import os
@@ -30,6 +34,8 @@ def arg(name, default):
 
 B, NSHAPES, NALTS, BUDGET = arg("--batch", 5), arg("--shapes", 40), arg("--alts", 3), arg("--seconds", 1500.0)
 GAIN = arg("--gain", 1.004)  # a change must beat the incumbent by this factor, twice
+GUARD_MS = arg("--guard-ms", 0.05)
+LANES = B > 1  # (bench.py's and the drop-in class's rule: coalesced launches on three or four lanes run the throughput-mode forms)
 path = os.environ.get("VSD_TUNING") or os.path.join(ROOT, "profiles", "tuning_mi355x.json")
 out = next((a for a in sys.argv[1:] if a.endswith(".json")), path)
 S = 4
@@ -42,14 +48,14 @@ wv = W.synthesize(W.taesd_spec(C.TAESD), "vae.", device="cuda")
 eng = Engine(ops, C.SD15_UNET, C.SD15_CONTROLNET, C.TAESD, wu, wc, wv)
 eng.set_text_embeds((torch.randn(77, 768, generator=torch.Generator().manual_seed(7)) * 0.5).half())
 pool = [eng] + [eng.make_slot() for _ in range(S - 1)]
-frame = np.random.default_rng(0).integers(0, 256, (B, 512, 512, 3), dtype=np.uint8)
+frame = np.random.default_rng(0).integers(0, 256, (B, 512, 512, 3) if B > 1 else (512, 512, 3), dtype=np.uint8)
 
 
 def prepare_all():
     for e in pool:
         e.overlap_controlnet = True
         e.overlap_launch = False
-        e.tune_for_lanes = True
+        e.tune_for_lanes = LANES
         e.prepare(512, 512, 4, 0.6, use_controlnet=True, batch=B)
     for e in pool:
         e.infer_u8(frame)
@@ -70,13 +76,27 @@ def fps(reps=3):
     return float(np.median(res))
 
 
+def lone_ms(n=24):
+    """p50 of a lone frame on lane 0 (two-stream form), nothing else in flight"""
+    e = pool[0]
+    for o in pool:
+        o.ops.synchronize()
+    ts = []
+    for _ in range(n):
+        t = time.perf_counter()
+        e.launch(overlap=True)
+        e.ops.synchronize()
+        ts.append((time.perf_counter() - t) * 1e3)
+    return float(np.median(ts))
+
+
 t_all = time.time()
 prepare_all()
 base = fps(5)
 print(f"{B} x {S}: {base:.2f} frames/s with the table as loaded ({len(ops.tile_override)} entries)", flush=True)
 
 # the program's conv shapes (one-stream form: what four lanes replay), their launch counts and the proxy's candidate tables
-ops.tune_mode = 1
+ops.tune_mode = 1 if LANES else 0
 shapes = {}
 for fn, a, k in Engine.flat_calls(eng.program_serial.calls):
     if fn.__name__ != "conv" or k.get("tile") is not None:
@@ -104,6 +124,9 @@ order = sorted(shapes, key=lambda kk: -shapes[kk]["weight"])[:NSHAPES]
 print(f"candidates timed ({time.time() - t_all:.0f} s); trying the {len(order)} heaviest shapes in the running program", flush=True)
 
 best = fps(5)
+lone0 = lone_ms() if not LANES else 0.0
+if not LANES:
+    print(f"lone frame {lone0:.3f} ms", flush=True)
 changed = []
 for key in order:
     if time.time() - t_all > BUDGET:
@@ -119,6 +142,10 @@ for key in order:
             prepare_all()
             f1 = fps(3)
             ok = f1 > best * GAIN and fps(3) > best * GAIN
+            if ok and not LANES:
+                l1 = lone_ms()
+                ok = l1 <= lone0 + GUARD_MS
+                print(f"      lone frame {l1:.3f} ms against {lone0:.3f}", flush=True)
         except RuntimeError as e:
             print("   ", key[:4], alt, "refused:", str(e)[:80], flush=True)
             f1, ok = 0.0, False

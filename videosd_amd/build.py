@@ -8,9 +8,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvsd.so")
 # the implicit-GEMM conv kernel is a template with ~60 instantiations: one translation unit per tile family, so that
 # the families compile in parallel (as one file the library took 4.5 minutes to build)
-SOURCES = ["api.hip", "conv_gemm.hip", "conv_t128x128.hip", "conv_t128x64.hip", "conv_t64x64.hip", "conv_t64x128.hip",
+SOURCES = ["api.hip", "plan.hip", "conv_gemm.hip", "conv_t128x128.hip", "conv_t128x64.hip", "conv_t64x64.hip", "conv_t64x128.hip",
            "conv_t256x128.hip", "conv_t256x256.hip", "conv_halo.hip", "conv_c64.hip", "fused_tail.hip", "norm.hip", "attention.hip", "elementwise.hip", "prompt_fold.hip"]
-HEADERS = ["common.h", "conv_kernels.h", "conv_epilogue.inc", "conv_gemm_body.inc", os.path.join("..", "..", "include", "vsd.h")]
+HEADERS = ["common.h", "conv_kernels.h", "conv_epilogue.inc", "conv_gemm_body.inc", "plan_dispatch.inc", os.path.join("..", "..", "include", "vsd.h")]
 # attention keeps its O / S accumulators live across the key loop and touches them with VALU every tile (online-softmax
 # rescale, exp): with the default AGPR placement the compiler moves them through v_accvgpr_read/write every tile
 # (~190 of 1300 instructions in the d=40 kernel); VGPR-form MFMA operands remove those moves.

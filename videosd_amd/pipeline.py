@@ -577,6 +577,21 @@ class VideoSDPipeline:
         self.evictions += dropped
         return dropped
 
+    def export_plan(self, path: str, frames_per_launch: int = 1, **options) -> dict:
+        """The program `infer(img, **options)` runs on this pipeline -- model, prompt, frame size, steps, strength, ControlNet scale --
+        as a FILE for hosts without Python: include/vsd.h vsd_plan_load / vsd_plan_infer (examples/plan_host.c) replay it with the
+        same kernels and arguments, bit for bit this class's frames.  The host feeds frames already cropped / resized to
+        (height, width) (videopipeline.py:92-107 does that with PIL); another size, prompt or step count is another plan.
+        `frames_per_launch` > 1: the coalesced program of `infer_batch`.  Returns the exporter's summary (videosd_amd/plan.py)."""
+        from .plan import export_plan
+
+        self._require_idle("export a plan")
+        w, h = int(options.get("width", 640)), int(options.get("height", 360))
+        imgs = [Image.new("RGB", (w, h), (127, 127, 127)) for _ in range(int(frames_per_launch))]
+        handle = self.submit_batch(imgs, **options)
+        self.collect_batch(handle)
+        return export_plan(handle[0], path)
+
     def set_tuning_mode(self, mode: str):
         """ "auto" (time the candidates of shapes the table lacks at `prepare`) or "table" (never: deterministic heuristic)."""
         if mode not in ("auto", "table"):
