@@ -591,15 +591,16 @@ def run_rank(args):
     #      forms): the sum of workgroup lives per family under captured-graph replay on all lanes, from the instrumented build
     #      (scripts/wg_cu_time.py; a constant of the committed profile, not measured in this run -- like `traffic`)
     in_situ = None
-    cut = os.path.join(ROOT, "profiles", "round5f_wg_cu_time_5x4.txt")
-    if os.path.exists(cut):
+    cut_name = next((n for n in ("round6_wg_cu_time_5x4.txt", "round5f_wg_cu_time_5x4.txt") if os.path.exists(os.path.join(ROOT, "profiles", n))), "")
+    cut = os.path.join(ROOT, "profiles", cut_name)
+    if cut_name:
         try:
             runs = json.loads(open(cut).read().strip().splitlines()[-1])["runs"]
             timed = next(r for r in runs if r["mode"] == 1 and r["lanes"] == 4)
             alone = next(r for r in runs if r["mode"] == 0 and r["lanes"] == 1)
             per_cu_peak = MFMA_PEAK_TFLOPS / 256.0
             fams = [f for f, v in timed["families"].items() if v["wg_ms_per_frame"] > 0]
-            in_situ = {"source": "profiles/round5f_wg_cu_time_5x4.txt (scripts/wg_cu_time.py with the -DVSD_WG_TIMELINE build: every workgroup adds its life to a per-family "
+            in_situ = {"source": f"profiles/{cut_name} (scripts/wg_cu_time.py with the -DVSD_WG_TIMELINE build: every workgroup adds its life to a per-family "
                                  "counter; a constant of the committed profile)",
                        "program": f"{timed['frames_per_launch']} frames per launch x {timed['lanes']} lanes, throughput-mode kernel forms, captured graphs",
                        "wg_ms_per_frame": {f: timed["families"][f]["wg_ms_per_frame"] for f in fams},
