@@ -304,9 +304,19 @@ int vsd_pair_end(vsd_ctx* ctx, int* joined_out);
  * The result is bit for bit the Python engine's.  vsd_plan_info: dims[0..2] = H, W, frames per launch. */
 typedef struct vsd_plan vsd_plan;
 int vsd_plan_load(vsd_ctx* ctx, const char* path, vsd_plan** plan_out);
+/* lane 0..3: the plan launches on that launch stream of the process's pool (vsd_stream_pool) -- up to four plans in flight side by side,
+ * as the Python workers' launch lanes; lane -1 = vsd_plan_load (a stream of the plan's own). */
+int vsd_plan_load_lane(vsd_ctx* ctx, const char* path, int lane, vsd_plan** plan_out);
 int vsd_plan_info(vsd_ctx* ctx, vsd_plan* plan, int* dims);
+/* vsd_plan_infer in two halves: enqueue (upload, launch, download; the host buffers must stay valid and should be pinned for the
+ * copies to overlap other lanes' work) | wait for this plan's stream. */
+int vsd_plan_submit(vsd_ctx* ctx, vsd_plan* plan, const void* frame_u8_host, void* out_u8_host);
+int vsd_plan_wait(vsd_ctx* ctx, vsd_plan* plan);
 int vsd_plan_infer(vsd_ctx* ctx, vsd_plan* plan, const void* frame_u8_host, void* out_u8_host);
 void vsd_plan_free(vsd_ctx* ctx, vsd_plan* plan);
+/* page-locked host memory for a plan's frames (NULL on failure) */
+void* vsd_pinned_alloc(vsd_ctx* ctx, size_t bytes);
+void vsd_pinned_free(vsd_ctx* ctx, void* p);
 
 /* ---- hipGraph capture / replay (reference intent: compile_model, videopipeline.py:35-47) ----------- */
 int vsd_graph_begin(vsd_ctx* ctx, void* stream);

@@ -561,7 +561,8 @@ def test_throughput_mode_tuning_times_candidates_with_four_lanes_busy(ops):
         key1 = ops.conv_key_of(args[2], pw, kw)
         assert key0[:-1] == key1[:-1] and (key0[-1], key1[-1]) == (0, 1)
         assert key0 in ops.tile_override and key1 in ops.tile_override
-        assert 1 <= len(table1) <= len(table0) and all(us > 0 for us, *_ in table1)
+        # (the shortlist of mode 1 is cut from ITS candidates -- the eight-wave forms exist there only -- so it may be the longer table)
+        assert len(table1) >= 1 and len(table0) >= 1 and all(us > 0 for us, *_ in table1)
         ops.conv(*args, **kw)   # (takes the throughput-mode entry: tune_mode is still 1)
         ops.synchronize()
         check(out, F.linear(x.float(), wt.float(), b.float()) + res.float(), "conv with the throughput-mode choice")

@@ -35,6 +35,7 @@ struct vsd_plan {
   std::vector<std::vector<unsigned char>> blobs;  // descriptor arrays of the calls (the calls point into them: a moved vector keeps its buffer)
   std::vector<PlanCall> calls;
   hipStream_t stream = nullptr;
+  bool own_stream = true;  // (a launch lane's stream belongs to the process-wide pool)
   void* graph = nullptr;
   void *in = nullptr, *out = nullptr;
   size_t io_bytes = 0;
@@ -67,7 +68,7 @@ struct Reader {
 void plan_release(vsd_plan* p) {
   if (!p) return;
   if (p->graph) (void)hipGraphExecDestroy((hipGraphExec_t)p->graph);
-  if (p->stream) (void)hipStreamDestroy(p->stream);
+  if (p->stream && p->own_stream) (void)hipStreamDestroy(p->stream);
   for (void* r : p->regions)
     if (r) (void)hipFree(r);
   delete p;
@@ -75,8 +76,13 @@ void plan_release(vsd_plan* p) {
 
 }  // namespace
 
-extern "C" int vsd_plan_load(vsd_ctx* ctx, const char* path, vsd_plan** plan_out) {
+extern "C" int vsd_plan_load(vsd_ctx* ctx, const char* path, vsd_plan** plan_out) { return vsd_plan_load_lane(ctx, path, -1, plan_out); }
+
+// lane >= 0: the plan launches on launch stream `lane` of the process's pool (vsd_stream_pool: four CU-masked streams = four hardware
+// queues on four command-processor pipes) -- several plans in flight side by side, as the Python workers' launch lanes
+extern "C" int vsd_plan_load_lane(vsd_ctx* ctx, const char* path, int lane, vsd_plan** plan_out) {
   if (!ctx || !path || !plan_out) return VSD_ERR_ARG;
+  if (lane >= VSD_POOL_STREAMS) return vsd_fail(ctx, VSD_ERR_ARG, "plan_load: lane %d (0..%d, or -1 for a stream of the plan's own)", lane, VSD_POOL_STREAMS - 1);
   *plan_out = nullptr;
   FILE* f = fopen(path, "rb");
   if (!f) return vsd_fail(ctx, VSD_ERR_ARG, "plan_load: cannot open %s", path);
@@ -119,7 +125,14 @@ extern "C" int vsd_plan_load(vsd_ctx* ctx, const char* path, vsd_plan** plan_out
     if (hipMalloc(&p->regions[i], size[i] ? size[i] : 16) != hipSuccess) return fail("out of device memory");
     if (!saved[i] && hipMemset(p->regions[i], 0, size[i]) != hipSuccess) return fail("hipMemset failed");
   }
-  if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+  if (lane >= 0) {
+    void* pool[VSD_POOL_STREAMS];
+    if (vsd_stream_pool(ctx, pool) != VSD_OK) return fail("no launch stream pool");
+    p->stream = (hipStream_t)pool[lane];
+    p->own_stream = false;
+  } else if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) {
+    return fail("hipStreamCreate failed");
+  }
   auto at = [&](uint32_t reg, uint64_t off, void** out) {
     if (reg >= nreg || off >= size[reg]) return false;
     *out = (char*)p->regions[reg] + off;
@@ -213,13 +226,34 @@ extern "C" int vsd_plan_info(vsd_ctx* ctx, vsd_plan* plan, int* dims) {
   return VSD_OK;
 }
 
-extern "C" int vsd_plan_infer(vsd_ctx* ctx, vsd_plan* plan, const void* frame_u8_host, void* out_u8_host) {
+extern "C" int vsd_plan_submit(vsd_ctx* ctx, vsd_plan* plan, const void* frame_u8_host, void* out_u8_host) {
   if (!ctx || !plan || !frame_u8_host || !out_u8_host) return VSD_ERR_ARG;
   VSD_HIP(ctx, hipMemcpyAsync(plan->in, frame_u8_host, plan->io_bytes, hipMemcpyHostToDevice, plan->stream));
   VSD_HIP(ctx, hipGraphLaunch((hipGraphExec_t)plan->graph, plan->stream));
   VSD_HIP(ctx, hipMemcpyAsync(out_u8_host, plan->out, plan->io_bytes, hipMemcpyDeviceToHost, plan->stream));
+  return VSD_OK;
+}
+
+extern "C" int vsd_plan_wait(vsd_ctx* ctx, vsd_plan* plan) {
+  if (!ctx || !plan) return VSD_ERR_ARG;
   VSD_HIP(ctx, hipStreamSynchronize(plan->stream));
   return VSD_OK;
+}
+
+extern "C" int vsd_plan_infer(vsd_ctx* ctx, vsd_plan* plan, const void* frame_u8_host, void* out_u8_host) {
+  const int rc = vsd_plan_submit(ctx, plan, frame_u8_host, out_u8_host);
+  return rc != VSD_OK ? rc : vsd_plan_wait(ctx, plan);
+}
+
+// page-locked host memory for a plan's frames (copies from pageable memory are staged by the runtime and do not overlap other lanes)
+extern "C" void* vsd_pinned_alloc(vsd_ctx* ctx, size_t bytes) {
+  void* p = nullptr;
+  if (!ctx || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+extern "C" void vsd_pinned_free(vsd_ctx* ctx, void* p) {
+  (void)ctx;
+  if (p) (void)hipHostFree(p);
 }
 
 extern "C" void vsd_plan_free(vsd_ctx* ctx, vsd_plan* plan) {

@@ -109,9 +109,14 @@ SIGNATURES = {
     "vsd_seq_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vsd_seq_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vsd_plan_load": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "vsd_plan_load_lane": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "vsd_plan_info": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "vsd_plan_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsd_plan_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vsd_plan_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsd_plan_free": (None, [C.c_void_p, C.c_void_p]),
+    "vsd_pinned_alloc": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "vsd_pinned_free": (None, [C.c_void_p, C.c_void_p]),
     "vsd_profile_begin": (C.c_int, [C.c_void_p]),
     "vsd_profile_end": (C.c_int, [C.c_void_p]),
     "vsd_profile_overhead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
