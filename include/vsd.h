@@ -313,6 +313,8 @@ int vsd_plan_info(vsd_ctx* ctx, vsd_plan* plan, int* dims);
 int vsd_plan_submit(vsd_ctx* ctx, vsd_plan* plan, const void* frame_u8_host, void* out_u8_host);
 int vsd_plan_wait(vsd_ctx* ctx, vsd_plan* plan);
 int vsd_plan_infer(vsd_ctx* ctx, vsd_plan* plan, const void* frame_u8_host, void* out_u8_host);
+/* another prompt for a loaded plan: a file written by videosd_amd.plan.export_prompt (the prompt's constant block, same layout) */
+int vsd_plan_load_prompt(vsd_ctx* ctx, vsd_plan* plan, const char* path);
 void vsd_plan_free(vsd_ctx* ctx, vsd_plan* plan);
 /* page-locked host memory for a plan's frames (NULL on failure) */
 void* vsd_pinned_alloc(vsd_ctx* ctx, size_t bytes);

@@ -104,9 +104,53 @@ def test_the_drop_in_class_exports_the_program_of_an_infer_call(tmp_path):
     path = str(tmp_path / "infer.vsdplan")
     info = pipe.export_plan(path, **opts)
     assert info["calls"] > 500
+    # another prompt for the same plan: its constant block as a file
+    other = dict(opts, prompt="a charcoal sketch of a harbour")
+    want_other = np.asarray(pipe.infer(img, **other))
+    assert not np.array_equal(want_other, want)
+    ppath = str(tmp_path / "other.vsdprompt")
+    assert pipe.export_prompt(ppath, other["prompt"]) > 1 << 20
     plan = CPlan(path)
     try:
         assert (plan.H, plan.W, plan.batch) == (192, 256, 1)
         assert np.array_equal(plan.infer(np.asarray(img)), want)
+        plan.load_prompt(ppath)
+        assert np.array_equal(plan.infer(np.asarray(img)), want_other)
+        with pytest.raises(RuntimeError, match="not a prompt file"):
+            plan.load_prompt(path)
     finally:
         plan.close()
+
+
+def test_truncated_and_corrupted_plan_files_are_refused_not_crashed_on(tmp_path):
+    """Every prefix cut of a plan file, and a file with a pointer moved outside its allocation, ends in an error message."""
+    import ctypes as C
+
+    from videosd_amd import lib as L
+    from videosd_amd.plan import export_plan
+
+    eng = _engine(batch=1, cn=False, H=64, W=64, steps=1)
+    eng.infer_u8(np.zeros((64, 64, 3), np.uint8))
+    path = str(tmp_path / "ok.vsdplan")
+    export_plan(eng, path)
+    data = open(path, "rb").read()
+    ctx = L.Context(0)
+    h = C.c_void_p()
+    for cut in (4, 30, 60, 200, 5000, len(data) // 3, len(data) - 1000):
+        bad = tmp_path / f"cut{cut}.vsdplan"
+        bad.write_bytes(data[:cut])
+        with pytest.raises(RuntimeError, match="plan_load"):
+            ctx.call("vsd_plan_load", str(bad).encode(), C.byref(h))
+    # another interface version
+    bad = tmp_path / "ver.vsdplan"
+    bad.write_bytes(data[:8] + (99).to_bytes(4, "little") + data[12:])
+    with pytest.raises(RuntimeError, match="bad header"):
+        ctx.call("vsd_plan_load", str(bad).encode(), C.byref(h))
+    # the frame buffer's offset past its region
+    bad = tmp_path / "off.vsdplan"
+    bad.write_bytes(data[:36] + (1 << 40).to_bytes(8, "little") + data[44:])
+    with pytest.raises(RuntimeError, match="plan_load"):
+        ctx.call("vsd_plan_load", str(bad).encode(), C.byref(h))
+    # and the intact file still loads afterwards (nothing leaked into the context's state)
+    ctx.call("vsd_plan_load", path.encode(), C.byref(h))
+    ctx.lib.vsd_plan_free(ctx.h, h)

@@ -37,8 +37,8 @@ struct vsd_plan {
   hipStream_t stream = nullptr;
   bool own_stream = true;  // (a launch lane's stream belongs to the process-wide pool)
   void* graph = nullptr;
-  void *in = nullptr, *out = nullptr;
-  size_t io_bytes = 0;
+  void *in = nullptr, *out = nullptr, *prompt = nullptr;
+  size_t io_bytes = 0, prompt_bytes = 0;
 };
 
 namespace {
@@ -104,6 +104,8 @@ extern "C" int vsd_plan_load_lane(vsd_ctx* ctx, const char* path, int lane, vsd_
   const uint64_t in_off = r.get<uint64_t>();
   const uint32_t out_r = r.get<uint32_t>();
   const uint64_t out_off = r.get<uint64_t>();
+  const uint32_t pr_r = r.get<uint32_t>();
+  const uint64_t pr_off = r.get<uint64_t>(), pr_bytes = r.get<uint64_t>();
   auto fail = [&](const char* what) {
     fclose(f);
     plan_release(p);
@@ -189,10 +191,11 @@ extern "C" int vsd_plan_load_lane(vsd_ctx* ctx, const char* path, int lane, vsd_
   }
   fclose(f);
   f = nullptr;
-  if (!at(in_r, in_off, &p->in) || !at(out_r, out_off, &p->out)) {
+  if (!at(in_r, in_off, &p->in) || !at(out_r, out_off, &p->out) || !at(pr_r, pr_off, &p->prompt) || pr_off + pr_bytes > size[pr_r]) {
     plan_release(p);
-    return vsd_fail(ctx, VSD_ERR_ARG, "plan_load: frame buffers outside their regions");
+    return vsd_fail(ctx, VSD_ERR_ARG, "plan_load: frame buffers / prompt block outside their regions");
   }
+  p->prompt_bytes = (size_t)pr_bytes;
   p->io_bytes = (size_t)p->batch * p->H * p->W * 3;
   // one eager pass (first-touch of every kernel, the error reports of the ops), then the captured one
   for (int pass = 0; pass < 2; ++pass) {
@@ -243,6 +246,30 @@ extern "C" int vsd_plan_wait(vsd_ctx* ctx, vsd_plan* plan) {
 extern "C" int vsd_plan_infer(vsd_ctx* ctx, vsd_plan* plan, const void* frame_u8_host, void* out_u8_host) {
   const int rc = vsd_plan_submit(ctx, plan, frame_u8_host, out_u8_host);
   return rc != VSD_OK ? rc : vsd_plan_wait(ctx, plan);
+}
+
+// Another prompt for a loaded plan: the bytes of an engine.PromptBlock of the same layout (videosd_amd/plan.py export_prompt) replace
+// the plan's -- the C counterpart of VideoSDPipeline's prompt cache (the reference re-encodes the prompt every frame,
+// lcm_controlnet.py:115-198; here a prompt is ~40 MB of constants built once).  Waits for the plan's stream first.
+extern "C" int vsd_plan_load_prompt(vsd_ctx* ctx, vsd_plan* plan, const char* path) {
+  if (!ctx || !plan || !path) return VSD_ERR_ARG;
+  FILE* f = fopen(path, "rb");
+  if (!f) return vsd_fail(ctx, VSD_ERR_ARG, "plan_load_prompt: cannot open %s", path);
+  char magic[8];
+  uint64_t n = 0;
+  const bool head = fread(magic, 1, 8, f) == 8 && fread(&n, 8, 1, f) == 1 && memcmp(magic, "VSDPRMT1", 8) == 0;
+  if (!head || n != plan->prompt_bytes) {
+    fclose(f);
+    return vsd_fail(ctx, VSD_ERR_ARG, "plan_load_prompt: %s is not a prompt file of this plan's layout (%llu bytes, the plan's block has %zu)", path,
+                    (unsigned long long)n, plan->prompt_bytes);
+  }
+  std::vector<unsigned char> host((size_t)n);
+  const bool ok = fread(host.data(), 1, host.size(), f) == host.size();
+  fclose(f);
+  if (!ok) return vsd_fail(ctx, VSD_ERR_ARG, "plan_load_prompt: %s is truncated", path);
+  VSD_HIP(ctx, hipStreamSynchronize(plan->stream));
+  VSD_HIP(ctx, hipMemcpy(plan->prompt, host.data(), host.size(), hipMemcpyHostToDevice));
+  return VSD_OK;
 }
 
 // page-locked host memory for a plan's frames (copies from pageable memory are staged by the runtime and do not overlap other lanes)

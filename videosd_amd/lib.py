@@ -114,6 +114,7 @@ SIGNATURES = {
     "vsd_plan_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsd_plan_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vsd_plan_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vsd_plan_load_prompt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p]),
     "vsd_plan_free": (None, [C.c_void_p, C.c_void_p]),
     "vsd_pinned_alloc": (C.c_void_p, [C.c_void_p, C.c_size_t]),
     "vsd_pinned_free": (None, [C.c_void_p, C.c_void_p]),

@@ -592,6 +592,13 @@ class VideoSDPipeline:
         self.collect_batch(handle)
         return export_plan(handle[0], path)
 
+    def export_prompt(self, path: str, prompt) -> int:
+        """Another prompt's constants as a file for vsd_plan_load_prompt (a loaded plan takes it without a new plan)."""
+        from .plan import export_prompt
+
+        pkey = prompt if isinstance(prompt, str) else tuple(prompt)
+        return export_prompt(self._cache_prompt(pkey, prompt=prompt), path)
+
     def set_tuning_mode(self, mode: str):
         """ "auto" (time the candidates of shapes the table lacks at `prepare`) or "table" (never: deterministic heuristic)."""
         if mode not in ("auto", "table"):

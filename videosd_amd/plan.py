@@ -11,7 +11,8 @@ produces is bit for bit the engine's (tests/test_plan_gpu.py).  A plan is one (s
 per launch); the reference's per-frame options (videopipeline.py:75-128) mean another plan.
 
 File (little endian): "VSDPLAN1", u32 version, H, W, batch, n_regions, n_calls, u32 in_region, u64 in_offset, u32 out_region, u64
-out_offset; regions: u64 size, u32 saved, u32 0; calls: u32 entry point (PLAN_FUNCS index), u32 nargs, args of 16 bytes
+out_offset, u32 prompt_region, u64 prompt_offset, u64 prompt_bytes (the engine's prompt block: vsd_plan_load_prompt replaces its bytes
+with another prompt's, `export_prompt`); regions: u64 size, u32 saved, u32 0; calls: u32 entry point (PLAN_FUNCS index), u32 nargs, args of 16 bytes
 (u32 tag, u32 aux, u64 value): 0 int32, 1 float32 bits, 2 pointer (aux = region, value = offset), 3 null, 4 the plan's stream,
 5 descriptor array (aux = count, value = bytes; followed by the bytes, u32 nfix, nfix x (u32 byte offset, u32 region, u64 offset));
 then the bytes of the saved regions in order."""
@@ -155,6 +156,7 @@ def export_plan(engine, path: str) -> dict:
                     body += struct.pack("<IIQ", boff, rid, off)
             else:
                 raise RuntimeError(f"plan export: {name}: argument type {t} has no plan encoding")
+    pr_r, pr_off = regs.locate(engine.pblock.buf.data_ptr())
     in_r, in_off = regs.locate(engine.frame_u8.data_ptr())
     out_r, out_off = regs.locate(engine.out_u8.data_ptr())
     # what is scratch (no bytes saved): the activation arena and the op workspaces
@@ -166,6 +168,7 @@ def export_plan(engine, path: str) -> dict:
         f.write(MAGIC)
         f.write(struct.pack("<IIIIII", VERSION, p["H"], p["W"], p["batch"], len(order), len(calls)))
         f.write(struct.pack("<IQIQ", in_r, in_off, out_r, out_off))
+        f.write(struct.pack("<IQQ", pr_r, pr_off, engine.pblock.buf.numel()))
         saved = []
         for bi, rid in order:
             addr, size = regs.blocks[bi]
@@ -188,6 +191,19 @@ def export_plan(engine, path: str) -> dict:
             "scratch_bytes": sum(regs.blocks[bi][1] for (bi, _), k in zip(order, saved) if not k), "calls": len(calls)}
 
 
+PROMPT_MAGIC = b"VSDPRMT1"
+
+
+def export_prompt(pblock, path: str) -> int:
+    """Another prompt's constants (an engine.PromptBlock: cross-attention K / V^T of every layer and the folded weights, built on the GPU
+    from the text encoder's output) as a file for vsd_plan_load_prompt: a C host changes the prompt of a loaded plan without a new plan.
+    The block must have the plan's layout (same networks, same text length)."""
+    data = pblock.buf.cpu().numpy().tobytes()
+    with open(path, "wb") as f:
+        f.write(PROMPT_MAGIC + struct.pack("<Q", len(data)) + data)
+    return len(data)
+
+
 class CPlan:
     """vsd_plan_load / vsd_plan_infer through ctypes (tests, examples): what a C host does with a plan file"""
 
@@ -208,6 +224,9 @@ class CPlan:
         out = np.empty_like(frame)
         self.ctx.call("vsd_plan_infer", self.h, frame.ctypes.data, out.ctypes.data)
         return out
+
+    def load_prompt(self, path: str):
+        self.ctx.call("vsd_plan_load_prompt", self.h, path.encode())
 
     def close(self):
         if getattr(self, "h", None):
