@@ -114,8 +114,30 @@ def build_timeline(verbose: bool = False) -> str:
     return out
 
 
+def build_whatif(verbose: bool = False) -> str:
+    """videosd_amd/libvsd_probe.so: the library built with -DVSD_PROBE -- environment switches that REMOVE a cost (VSD_SKIP_GN /
+    VSD_SKIP_REDUCE / VSD_SKIP_ATTN: the kernels are not launched; VSD_SKIP_EPI: the unsplit GEMM-form layers leave before their
+    epilogue).  Results are garbage: scripts/whatif_probe.sh reads the frame rate only (VSD_LIB selects the library)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.join(HERE, "libvsd_probe.so")
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    procs, objs = [], []
+    for f in SOURCES:
+        o = os.path.join(HERE, "build", "whatif_" + f.replace(".hip", ".o"))
+        objs.append(o)
+        procs.append((subprocess.Popen([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-DVSD_PROBE", "-w"] + EXTRA_FLAGS.get(f, []) +
+                                       ["-c", os.path.join(CSRC, f), "-o", o]), f))
+    for p, f in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {f}")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 if __name__ == "__main__":
-    if "--timeline" in sys.argv:
+    if "--whatif" in sys.argv:
+        print(build_whatif())
+    elif "--timeline" in sys.argv:
         print(build_timeline())
     elif "--probe" in sys.argv:
         print(build_probe())

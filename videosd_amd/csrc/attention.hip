@@ -508,6 +508,9 @@ extern "C" int vsd_attention_batched(vsd_ctx* ctx, const void* q, int ldq, const
                                      void* out, int ldo, int sq, int sk, int heads, int d, float scale, int causal,
                                      int batch, int k_batch_rows, int vt_batch_cols, void* stream) {
   if (!ctx) return VSD_ERR_ARG;
+#ifdef VSD_PROBE
+  { static const bool skip = getenv("VSD_SKIP_ATTN") != nullptr; if (skip) return VSD_OK; }  // (what-if probe builds only)
+#endif
   if (batch < 1 || batch > 65535 || k_batch_rows < 0 || vt_batch_cols < 0 || vt_batch_cols % 8)
     return vsd_fail(ctx, VSD_ERR_ARG, "attention: batch=%d k_batch_rows=%d vt_batch_cols=%d", batch, k_batch_rows, vt_batch_cols);
   if (!q || !k || !vt || !out) return vsd_fail(ctx, VSD_ERR_ARG, "attention: null pointer");

@@ -73,6 +73,9 @@ static int conv_setup(vsd_ctx* ctx, const vsd_conv_desc* d, ConvLaunch& cl, bool
   p.out_scale_dev = (const float*)d->out_scale_dev;
   p.softmax_cols = d->softmax_cols;
   p.act = d->act;
+#ifdef VSD_PROBE
+  { static const bool skip = getenv("VSD_SKIP_EPI") != nullptr; if (skip) p.act |= 0x4000; }  // (what-if probe builds only: scripts/whatif_probe.sh)
+#endif
   p.out = (half_t*)d->out; p.ldo = d->ldo;
   p.out2 = (half_t*)d->out2; p.add2 = (const half_t*)d->add2;
   p.out_t = (half_t*)d->out_t; p.ldt = d->ldt; p.t_col0 = d->t_col0;
@@ -253,6 +256,9 @@ extern "C" int vsd_conv_gemm(vsd_ctx* ctx, const vsd_conv_desc* d, void* stream)
     int rc = ls.finish();
     if (rc) return rc;
   }
+#ifdef VSD_PROBE
+  { static const bool skip = getenv("VSD_SKIP_REDUCE") != nullptr; if (skip) return VSD_OK; }
+#endif
   if (p.split_k > 1 && !p.counters) {
     LaunchScope ls(ctx, s, VSD_FAM_SPLITK_REDUCE, 0.0);
     size_t total = (size_t)p.M * ((p.N + 7) / 8);

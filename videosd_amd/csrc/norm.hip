@@ -443,6 +443,9 @@ extern "C" int vsd_groupnorm_batched(vsd_ctx* ctx, const void* src0, const void*
                                      int groups, float eps, const void* gamma, const void* beta, int silu, void* out,
                                      void* workspace, void* stream) {
   if (!ctx) return VSD_ERR_ARG;
+#ifdef VSD_PROBE
+  { static const bool skip = getenv("VSD_SKIP_GN") != nullptr; if (skip) return VSD_OK; }  // (what-if probe builds only)
+#endif
   if (batch < 1 || batch > 65535) return vsd_fail(ctx, VSD_ERR_ARG, "groupnorm: batch=%d", batch);
   GnParams p;
   p.batch = batch;
