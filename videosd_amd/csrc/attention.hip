@@ -77,7 +77,15 @@ __device__ __forceinline__ float xhalf_max(float x) {  // max over the two half-
 //  already folded into Q, the row sums already come out of the PV MFMA (the ones row below), O is already rescaled only when a
 //  maximum moved; the max-subtract as 16 v_pk_add_f32 measured 9-34 % SLOWER (the compiler no longer shares the two row-sum
 //  branches' code, 174 registers) and was not kept.)
-template <int NQK, int NPV, int NW, int QB, int KSP>
+// LAZY (round 6; head_dim % 16 == 8, i.e. d = 40 -- the 64 x 64 level's 4096-key self-attention -- and not causal): the running maximum
+// is subtracted INSIDE the QK^T MFMA.  The last K step of Q / K has eight padding columns; column d of every key is 1.0 and column d of
+// query q holds -m_off[q] (fp16), so the score tile arrives as S - m_off and the 33 v_sub per 64-key tile -- a quarter of the softmax's
+// VALU stream, which is what this kernel binds on -- are gone.  m_off follows the true maximum lazily: it moves (O rescaled, the pad
+// column rewritten) only when a tile's maximum exceeds it by more than LAZY_T in log2 units, so P stays in [0, 2^LAZY_T] and the largest
+// P of a row in [1, 2^LAZY_T]; the row sum comes out of the PV MFMA's ones row, in the same units.  Other rounding than the plain
+// form (an offset that is not the exact maximum), the same tolerance.
+constexpr float LAZY_T = 5.0f;
+template <int NQK, int NPV, int NW, int QB, int KSP, bool LAZY = false>
 __device__ __forceinline__ void attention_body(const AttnParams& pp, const unsigned image) {
   VSD_CUT(VSD_CUT_ATTENTION, pp.cut)
   constexpr int NTG = 64 * NW;       // threads of one key-split group (they stage that group's tiles)
@@ -225,6 +233,11 @@ __device__ __forceinline__ void attention_body(const AttnParams& pp, const unsig
       for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
   }
 
+  [[maybe_unused]] bool lazy_first = true;  // LAZY: m_run is the offset in the Q pad column (fp16-representable; zero until the first tile)
+  if constexpr (LAZY) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) m_run[qb] = 0.f;
+  }
   int sk_end = p.sk;
   if (p.causal) sk_end = min(p.sk, qblk * (32 * NW * QB) + 32 * NW * QB);  // later keys are never visible
   const int ntiles = (sk_end + 63) / 64;
@@ -280,6 +293,52 @@ __device__ __forceinline__ void attention_body(const AttnParams& pp, const unsig
               if (!ok) s[qb][kb][r] = NEG_BIG;
             }
       }
+      if constexpr (LAZY) {
+        // ---- the score tile is S - m_off already: exponentials straight away unless some query's maximum outgrew its offset
+        float mx[QB];
+        bool need = false;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          float v = NEG_BIG;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v = fmaxf(v, s[qb][kb][r]);
+          mx[qb] = xhalf_max(v);
+          need = need || mx[qb] > LAZY_T;
+        }
+        const bool moved = __builtin_amdgcn_ballot_w64(need) != 0;
+        if (lazy_first || moved) {
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            const bool mine = lazy_first || mx[qb] > LAZY_T;
+            float m_new = mine ? fminf(fmaxf(m_run[qb] + mx[qb], -60000.f), 60000.f) : m_run[qb];
+            m_new = (float)(half_t)m_new;            // what the pad column can hold
+            const float delta = m_new - m_run[qb];   // (both fp16 values: exact)
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) s[qb][kb][r] = __builtin_amdgcn_exp2f(s[qb][kb][r] - delta);
+            if (!lazy_first) {  // (the first tile: O is zero and its offset was zero)
+#pragma unroll
+              for (int i = 0; i < NPV; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
+            }
+            m_run[qb] = m_new;
+            if (lh == 1) qf[qb][NQK - 1][0] = (half_t)(-m_new);  // column d of this query (upper half of the last K step)
+          }
+          lazy_first = false;
+        } else {
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) s[qb][kb][r] = __builtin_amdgcn_exp2f(s[qb][kb][r]);
+        }
+      } else {
       // ---- online softmax (per lane = per query; the two half-waves hold different keys of the same query)
       bool grew_any = false;
       float alpha[QB];
@@ -323,6 +382,7 @@ __device__ __forceinline__ void attention_body(const AttnParams& pp, const unsig
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha[qb];
       }
+      }  // (!LAZY)
 
       PROBE(2)
       __builtin_amdgcn_s_setprio(VSD_ATTN_PV_PRIO);
@@ -358,6 +418,7 @@ __device__ __forceinline__ void attention_body(const AttnParams& pp, const unsig
   if (slot_ok(1)) ATT_LOAD(1, slot_key0(1))
   __syncthreads();  // zero fill complete before the first tile lands on top of it
   if (ones_row && gtid < 2 * 64) Vs[(gtid >> 6) * VTILE + (DV - 1) * VS + (gtid & 63)] = (half_t)1.0f;
+  if (LAZY && gtid < 2 * 64) Ks[(gtid >> 6) * KTILE + (gtid & 63) * KS + d] = (half_t)1.0f;  // column d of every key (the staging stores write columns < d)
   if (slot_ok(0)) ATT_STORE(0, 0)
   __syncthreads();
   auto run_tile = [&](int j) __attribute__((always_inline)) {
@@ -458,15 +519,26 @@ __device__ __forceinline__ void attention_body(const AttnParams& pp, const unsig
   }
 }
 
-template <int NQK, int NPV, int NW, int QB, int KSP>
+template <int NQK, int NPV, int NW, int QB, int KSP, bool LAZY = false>
 __global__ __launch_bounds__(64 * NW * KSP) void attention_kernel(const AttnParams pp) {
-  attention_body<NQK, NPV, NW, QB, KSP>(pp, blockIdx.z);
+  attention_body<NQK, NPV, NW, QB, KSP, LAZY>(pp, blockIdx.z);
+}
+// (the LAZY body of the four-wave form allocates 170 registers on its own -- two past the 168 that three waves per SIMD allow, which is
+//  what the plain form runs at: said here)
+template <int NQK, int NPV, int NW, int QB, int KSP>
+__global__ __launch_bounds__(64 * NW * KSP) __attribute__((amdgpu_waves_per_eu(3))) void attention_lazy_kernel(const AttnParams pp) {
+  attention_body<NQK, NPV, NW, QB, KSP, true>(pp, blockIdx.z);
+}
+template <int NQK, int NPV, int NW, int QB, int KSP>
+__global__ __launch_bounds__(64 * NW * KSP) __attribute__((amdgpu_waves_per_eu(3))) void attention_lazy_pair_kernel(const Pair<AttnParams> g) {
+  const unsigned nb = gridDim.z >> 1, which = blockIdx.z >= nb;
+  attention_body<NQK, NPV, NW, QB, KSP, true>(g.p[which], blockIdx.z - which * nb);
 }
 // two attention problems of one shape as one grid (common.h launch_pairable): the upper half of gridDim.z is the second one
-template <int NQK, int NPV, int NW, int QB, int KSP>
+template <int NQK, int NPV, int NW, int QB, int KSP, bool LAZY = false>
 __global__ __launch_bounds__(64 * NW * KSP) void attention_pair_kernel(const Pair<AttnParams> g) {
   const unsigned nb = gridDim.z >> 1, which = blockIdx.z >= nb;
-  attention_body<NQK, NPV, NW, QB, KSP>(g.p[which], blockIdx.z - which * nb);
+  attention_body<NQK, NPV, NW, QB, KSP, LAZY>(g.p[which], blockIdx.z - which * nb);
 }
 
 // (waves per group, query blocks per wave, key-split groups)
@@ -477,6 +549,16 @@ struct AttnShape {
 template <int NQK, int NPV, int NW, int QB, int KSP>
 void launch_one(vsd_ctx* ctx, const AttnParams& p, int batch, hipStream_t s) {
   dim3 grid(p.heads, (p.sq + 32 * NW * QB - 1) / (32 * NW * QB), batch);
+  if constexpr (NQK == 3 && NPV == 2) {  // head_dim 40: the maximum subtracted inside the QK^T MFMA (attention_body, LAZY)
+    static const bool off = getenv("VSD_ATTN_NO_LAZY") != nullptr;
+    if (p.d == 40 && !p.causal && !off) {
+      if constexpr (NW == 4 && KSP == 1)
+        launch_pairable(ctx, attention_lazy_kernel<NQK, NPV, NW, QB, KSP>, attention_lazy_pair_kernel<NQK, NPV, NW, QB, KSP>, grid, dim3(64 * NW * KSP), 0, s, p);
+      else
+        launch_pairable(ctx, attention_kernel<NQK, NPV, NW, QB, KSP, true>, attention_pair_kernel<NQK, NPV, NW, QB, KSP, true>, grid, dim3(64 * NW * KSP), 0, s, p);
+      return;
+    }
+  }
   launch_pairable(ctx, attention_kernel<NQK, NPV, NW, QB, KSP>, attention_pair_kernel<NQK, NPV, NW, QB, KSP>, grid, dim3(64 * NW * KSP), 0, s, p);
 }
 
