@@ -114,6 +114,24 @@ def build_timeline(verbose: bool = False) -> str:
     return out
 
 
+def build_variant(tag: str, defines, verbose: bool = False) -> str:
+    """videosd_amd/libvsd_<tag>.so: the library with extra -D defines (experiment builds: A/B through VSD_LIB)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.join(HERE, f"libvsd_{tag}.so")
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    procs, objs = [], []
+    for f in SOURCES:
+        o = os.path.join(HERE, "build", f"{tag}_" + f.replace(".hip", ".o"))
+        objs.append(o)
+        procs.append((subprocess.Popen([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-w"] + [f"-D{d}" for d in defines] + EXTRA_FLAGS.get(f, []) +
+                                       ["-c", os.path.join(CSRC, f), "-o", o]), f))
+    for p, f in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {f}")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 def build_whatif(verbose: bool = False) -> str:
     """videosd_amd/libvsd_probe.so: the library built with -DVSD_PROBE -- environment switches that REMOVE a cost (VSD_SKIP_GN /
     VSD_SKIP_REDUCE / VSD_SKIP_ATTN: the kernels are not launched; VSD_SKIP_EPI: the unsplit GEMM-form layers leave before their
@@ -135,7 +153,10 @@ def build_whatif(verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    if "--whatif" in sys.argv:
+    if "--variant" in sys.argv:  # python -m videosd_amd.build --variant nt VSD_NT_STORES
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    elif "--whatif" in sys.argv:
         print(build_whatif())
     elif "--timeline" in sys.argv:
         print(build_timeline())

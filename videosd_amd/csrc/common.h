@@ -158,6 +158,15 @@ __device__ __forceinline__ float erf_as_f(float x) {
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 
+// Output stores of the conv epilogues.  -DVSD_NT_STORES (experiment builds, scripts/r6_*): as non-temporal stores.
+#ifdef VSD_NT_STORES
+#define VSD_OUT_STORE8(PTR_, VAL_) __builtin_nontemporal_store((VAL_), reinterpret_cast<half8*>(PTR_))
+#define VSD_OUT_AUX 2
+#else
+#define VSD_OUT_STORE8(PTR_, VAL_) (*reinterpret_cast<half8*>(PTR_) = (VAL_))
+#define VSD_OUT_AUX 0
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Division by a launch constant without the ~40-instruction runtime integer division (five to eight of them sat in the

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (ACT == 3) x = fmaxf(x, 0.f);
         o[e] = (half_t)x;
       }
-      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), ors, mok[i] ? (mrow[i] * p.ldo + ch0) * 2 : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&o), ors, mok[i] ? (mrow[i] * p.ldo + ch0) * 2 : OOB, 0, VSD_OUT_AUX);
     }
   }
 #undef C64_COORDS

@@ -471,7 +471,7 @@ __global__ __launch_bounds__(128 * WMN) void conv_halo_kernel(const ConvParams p
           if (ACT == 3) x = fmaxf(x, 0.f);
           o[i] = (half_t)x;
         }
-        *reinterpret_cast<half8*>(p.out + (size_t)row_m(r) * p.ldo + n) = o;
+        VSD_OUT_STORE8(p.out + (size_t)row_m(r) * p.ldo + n, o);
       }
     }
   };

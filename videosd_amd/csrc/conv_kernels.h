@@ -251,7 +251,7 @@ __device__ __forceinline__ void epilogue_store8(const ConvParams& p, int m, int 
       rsum += f;
       rsq += f * f;
     }
-    *reinterpret_cast<half8*>(p.out + (size_t)m * p.ldo + n) = o;
+    VSD_OUT_STORE8(p.out + (size_t)m * p.ldo + n, o);
     if (p.out2) {
       half8 a = *reinterpret_cast<const half8*>(p.add2 + (size_t)m * p.ldo + n);
 #pragma unroll
