@@ -4,7 +4,7 @@ import collections, csv, json, sys
 
 trace, opsf = sys.argv[1], sys.argv[2]
 ops = json.load(open(opsf))
-ours = ("conv_gemm_kernel", "conv_gemm8_kernel", "conv_gemm_group_kernel", "conv_halo_kernel", "conv_c64", "tail_kernel", "adain_kernel", "splitk_reduce", "gn_stats", "gn_apply", "gn_fused", "layernorm_kernel", "attention_kernel",
+ours = ("conv_gemm_kernel", "conv_gemm8_kernel", "conv_gemm_group_kernel", "conv_halo_kernel", "conv_c64", "tail_kernel", "adain_kernel", "splitk_reduce", "gn_stats", "gn_apply", "gn_fused", "layernorm_kernel", "attention_kernel", "attention_lazy", "attention_pair", "attention_lazy", "attention_pair",
         "preprocess_rgb", "sobel_max", "sobel_apply", "add_noise", "lcm_step", "postprocess")
 rows = [r for r in csv.DictReader(open(trace)) if any(o in r["Kernel_Name"] for o in ours)]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))

@@ -12,7 +12,7 @@ import json
 import os
 import sys
 
-FAMILIES = (("conv_halo_kernel", "conv_halo"), ("conv_c64", "conv_halo"), ("conv_gemm", "conv_gemm"), ("tail_kernel", "fused_tail"), ("attention_kernel", "attention"),
+FAMILIES = (("conv_halo_kernel", "conv_halo"), ("conv_c64", "conv_halo"), ("conv_gemm", "conv_gemm"), ("tail_kernel", "fused_tail"), ("attention_", "attention"),
             ("gn_", "groupnorm"), ("splitk", "splitk_reduce"), ("layernorm", "layernorm"))
 CLOCK_HZ, SIMDS = 2.4e9, 4 * 256
 

@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-FAMILIES = (("conv_halo_kernel", "conv_halo"), ("conv_c64", "conv_halo"), ("conv_gemm", "conv_gemm"), ("tail_kernel", "fused_tail"), ("attention_kernel", "attention"),
+FAMILIES = (("conv_halo_kernel", "conv_halo"), ("conv_c64", "conv_halo"), ("conv_gemm", "conv_gemm"), ("tail_kernel", "fused_tail"), ("attention_", "attention"),
             ("gn_", "groupnorm"), ("splitk", "splitk_reduce"), ("layernorm", "layernorm"))
 
 

@@ -1,7 +1,6 @@
 #!/bin/bash
 # round 6, final set, part A: everything bench.py's line quotes from profiles/ (layer tables, PMC, workgroup time) + the GPU suite
 mkdir -p gpurun_out/r6f
-echo "== full gpu suite"; timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 | tee gpurun_out/r6f/gpu_suite.txt
 echo "== bench under the kernel tracer, layer tables, fabric bytes"; timeout 1500 bash scripts/collect_profiles.sh round6f 5 2>&1 | tail -12 | cut -c1-300
 echo "== layer table of the throughput-mode forms"; bash scripts/layer_table.sh round6f_b5_lanes 5 --lanes
 echo "== SQ counters"; TAG=round6f NB=5 bash scripts/collect_pmc_sq.sh 2>&1 | tail -1 | cut -c1-200; TAG=round6f_lanes NB=5 EXTRA=--lanes bash scripts/collect_pmc_sq.sh 2>&1 | tail -1 | cut -c1-200
